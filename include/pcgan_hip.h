@@ -1,0 +1,174 @@
+/*
+ * pcgan_hip.h -- C-ABI of libpcgan_hip.so: the MI355X (gfx950) kernels behind the
+ * PC-GAN wsgan_emb training step.
+ *
+ * The reference (phymhan pc-gan) has no FFI: every op on the hot path is a stock
+ * torch.nn module.  Each entry point below therefore names the
+ * torch.nn call site in the reference that it replaces (file:line relative to the
+ * reference root).  The host side (pc-gan_amd/hip/*.py) binds these with ctypes and
+ * wraps them in torch.autograd.Function objects used by the define_G/define_D/
+ * define_E/define_IP modules.
+ *
+ * Conventions
+ *   - all tensors are fp32, NCHW, contiguous, device pointers (tensor.data_ptr()).
+ *   - no hidden allocation, no device synchronisation, no global mutable state:
+ *     the caller provides the workspace (query *_workspace_bytes first) and the
+ *     hipStream_t (torch.cuda.current_stream().cuda_stream); every launch is
+ *     asynchronous on that stream, so calls are graph-capturable and may run
+ *     concurrently on distinct streams.
+ *   - return value 0 = ok; non-zero = error, text via pcgan_last_error()
+ *     (thread-local).  The Python side turns non-zero into RuntimeError.
+ */
+#ifndef PCGAN_HIP_H
+#define PCGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pcgan_stream_t; /* hipStream_t */
+
+/* ---- status ------------------------------------------------------------------ */
+const char* pcgan_last_error(void);
+int pcgan_version(void);
+/* number of compute units / arch string of device 0 (diagnostics) */
+int pcgan_device_info(int* cu_count, char* arch, int arch_len);
+
+/* ---- convolution family ------------------------------------------------------
+ * One descriptor covers nn.Conv2d and (with the roles swapped by the caller)
+ * nn.ConvTranspose2d.  Replaces:
+ *   ResnetGenerator convs      models/networks.py:578-605
+ *   ResnetBlock convs          models/networks.py:621-648 (ReflectionPad2d folded in)
+ *   NLayerDiscriminator convs  models/networks.py:747-772
+ *   ResNet-18 / Elo head convs models/resnet.py:20-28,134 ; models/networks.py:1020-1026
+ *   AlexNetFeature convs       models/networks.py:1223-1233
+ * pad_mode: 0 = zero padding, 1 = reflection padding (ReflectionPad2d(pad) + conv pad 0).
+ * stride must be 1, 2 or 4.
+ */
+typedef struct {
+    int N, C, H, W; /* input  [N][C][H][W]            */
+    int K, R, S;    /* weight [K][C][R][S]            */
+    int stride, pad, pad_mode;
+    int P, Q;       /* output [N][K][P][Q]            */
+} pcgan_conv_desc;
+
+enum { PCGAN_ACT_NONE = 0, PCGAN_ACT_RELU = 1, PCGAN_ACT_LRELU = 2, PCGAN_ACT_TANH = 3, PCGAN_ACT_SIGMOID = 4 };
+enum { PCGAN_PASS_FWD = 0, PCGAN_PASS_BWD_DATA = 1, PCGAN_PASS_BWD_WEIGHT = 2 };
+
+size_t pcgan_conv2d_workspace_bytes(const pcgan_conv_desc* d, int pass);
+
+/* y = act(conv(x, w) + bias); bias may be NULL. */
+int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const float* w, const float* bias,
+                     float* y, int act, float slope, void* ws, size_t ws_bytes, pcgan_stream_t s);
+/* dx = conv^T(dy, w) (+ bias per dx-channel, used when this entry serves as the
+ * forward of nn.ConvTranspose2d, models/networks.py:597-600). */
+int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, const float* w, const float* bias,
+                          float* dx, void* ws, size_t ws_bytes, pcgan_stream_t s);
+/* dw[K][C][R][S] = sum_{n,p,q} dy * gather(x). */
+int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw,
+                            void* ws, size_t ws_bytes, pcgan_stream_t s);
+
+/* ---- per-channel reductions / pointwise ---------------------------------------- */
+/* out[c] = sum over n,h,w of x[n][c][h][w]  (bias gradients); scratch_nc: N*C floats. */
+int pcgan_channel_sum(const float* x, float* out, float* scratch_nc, int N, int C, int HW, pcgan_stream_t s);
+/* dx = dy * act'(y)  where y is the activation OUTPUT (relu/lrelu/tanh/sigmoid). */
+int pcgan_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float slope, pcgan_stream_t s);
+/* y = act(x) standalone (nn.ReLU in AlexNetFeature, models/networks.py:1224-1234). */
+int pcgan_act_fwd(const float* x, float* y, size_t n, int act, float slope, pcgan_stream_t s);
+/* out[n][0..C)[hw] = img, out[n][C..C+nz)[hw] = z[n or 0][j] broadcast
+ * (torch.cat((input, z_img), 1), models/networks.py:610-611, 781-782).  z_batch is 1 or N. */
+int pcgan_concat_z(const float* img, const float* z, float* out, int N, int C, int nz, int HW, int z_batch,
+                   pcgan_stream_t s);
+/* y = a + b; y = alpha * scalar_dev[0] * x (scalar_dev may be NULL): the upstream
+ * gradient of a scalar loss stays on the device -- helpers for the autograd glue. */
+int pcgan_add(const float* a, const float* b, float* y, size_t n, pcgan_stream_t s);
+int pcgan_scale(const float* x, const float* scalar_dev, float alpha, float* y, size_t n, pcgan_stream_t s);
+/* Dropout2d with an explicit keep mask per (n,c) (models/resnet.py:38-51): y = x*mask[nc]*scale. */
+int pcgan_channel_scale(const float* x, const float* mask_nc, float* y, int NC, int HW, float scale,
+                        pcgan_stream_t s);
+
+/* ---- normalisation (+ fused activation / residual) -----------------------------
+ * InstanceNorm2d(affine=False, track_running_stats=True)  models/networks.py:26
+ * BatchNorm2d(affine=True) in train mode                   models/networks.py:24,
+ *                                                          models/resnet.py:47-51,136
+ * plane_stats: per (n,c) plane mean and M2 = sum (x-mean)^2 (exact two-pass). */
+int pcgan_plane_stats(const float* x, float* mean_nc, float* m2_nc, int NC, int HW, pcgan_stream_t s);
+/* merge the N per-plane (mean,M2) of each channel (Chan's formula) into batch
+ * statistics: mean_c, var_c (biased) and update running stats
+ * (momentum m: r = (1-m) r + m stat, unbiased variance), either pointer may be NULL. */
+int pcgan_bn_merge(const float* mean_nc, const float* m2_nc, float* mean_c, float* var_c,
+                   float* running_mean, float* running_var, int N, int C, int HW, float momentum,
+                   pcgan_stream_t s);
+/* instance-norm running-stat update: r_mean = (1-m) r_mean + m * mean_n(mean_nc),
+ * r_var = (1-m) r_var + m * mean_n(unbiased var_nc). */
+int pcgan_in_running_update(const float* mean_nc, const float* m2_nc, float* running_mean,
+                            float* running_var, int N, int C, int HW, float momentum, pcgan_stream_t s);
+/* y = act( (x - mean[i]) * rsqrt(var[i] + eps) * gamma[c] + beta[c] + residual )
+ * with i = n*C+c (per_plane=1, instance norm: `var` then holds the plane M2 from
+ * pcgan_plane_stats and the kernel divides by HW) or i = c (per_plane=0, batch norm or
+ * eval-mode running statistics: `var` is the variance).  gamma/beta/residual may be NULL. */
+int pcgan_norm_act_fwd(const float* x, const float* mean, const float* var, const float* gamma,
+                       const float* beta, const float* residual, float* y, int N, int C, int HW,
+                       int per_plane, float eps, int act, float slope, pcgan_stream_t s);
+/* backward statistics per plane: s1[nc] = sum g, s2[nc] = sum g*xhat where
+ * g = dy * act'(y) (y = forward output, used only for the activation mask; may be NULL
+ * when act == NONE). */
+int pcgan_norm_bwd_stats(const float* dy, const float* x, const float* y, const float* mean,
+                         const float* var, float* s1_nc, float* s2_nc, int N, int C, int HW,
+                         int per_plane, float eps, int act, float slope, pcgan_stream_t s);
+/* dx = rstd*gamma*( g - s1/cnt - xhat*s2/cnt ); s1/s2 indexed like mean;
+ * d_residual (optional) = g.  For batch norm the caller first sums s1/s2 over n
+ * (pcgan_bn_bwd_reduce) which also yields dgamma, dbeta. */
+int pcgan_norm_bwd_apply(const float* dy, const float* x, const float* y, const float* mean,
+                         const float* var, const float* gamma, const float* s1, const float* s2,
+                         float* dx, float* d_residual, int N, int C, int HW, int per_plane, float eps,
+                         int act, float slope, pcgan_stream_t s);
+int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, float* s2_c, int N, int C,
+                        pcgan_stream_t s);
+
+/* ---- pooling / resize ------------------------------------------------------------
+ * MaxPool2d(k, stride, pad)   models/resnet.py:138 ; models/networks.py:1225-1235
+ * AvgPool2d(H) / MaxPool2d(H) global pooling  models/networks.py:1056-1059
+ * F.interpolate(bilinear, align_corners=True)  util/util.py:111-117 */
+int pcgan_maxpool_fwd(const float* x, float* y, int32_t* argmax, int NC, int H, int W, int k, int stride,
+                      int pad, int P, int Q, pcgan_stream_t s);
+int pcgan_maxpool_bwd(const float* dy, const int32_t* argmax, float* dx, int NC, int H, int W, int k, int stride,
+                      int pad, int P, int Q, pcgan_stream_t s);
+int pcgan_global_pool_fwd(const float* x, float* y, int32_t* argmax, int NC, int HW, int is_max,
+                          pcgan_stream_t s);
+int pcgan_global_pool_bwd(const float* dy, const int32_t* argmax, float* dx, int NC, int HW, int is_max,
+                          pcgan_stream_t s);
+int pcgan_bilinear_fwd(const float* x, float* y, int NC, int H, int W, int P, int Q, pcgan_stream_t s);
+int pcgan_bilinear_bwd(const float* dy, float* dx, int NC, int H, int W, int P, int Q, pcgan_stream_t s);
+
+/* ---- losses ----------------------------------------------------------------------
+ * nn.BCELoss(mean) against a per-sample target broadcast over the patch map
+ * (GANLoss, models/networks.py:386-420; log clamped at -100 like torch);
+ * nn.L1Loss / nn.MSELoss (models/wsgan_emb_model.py:141-149).
+ * Each writes the scalar loss to loss[0] and, when grad != NULL, dloss/dpred * gscale. */
+int pcgan_bce_loss(const float* pred, const float* target_n, float* loss, float* grad, int N, int per_n,
+                   float gscale, void* ws, size_t ws_bytes, pcgan_stream_t s);
+int pcgan_l1_loss(const float* a, const float* b, float* loss, float* grad_a, size_t n, float gscale,
+                  void* ws, size_t ws_bytes, pcgan_stream_t s);
+int pcgan_mse_loss(const float* a, const float* b, float* loss, float* grad_a, size_t n, float gscale,
+                   void* ws, size_t ws_bytes, pcgan_stream_t s);
+size_t pcgan_loss_workspace_bytes(size_t n);
+
+/* ---- optimizer -------------------------------------------------------------------
+ * torch.optim.Adam(lr, betas=(beta1, 0.999), eps=1e-8) on a flat fp32 parameter
+ * buffer (models/wsgan_emb_model.py:153-156).  step is the 1-based step count. */
+int pcgan_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                    float beta1, float beta2, float eps, int step, pcgan_stream_t s);
+/* hipGraph-capturable variant: lr_dev[0] (float) and step_dev[0] (int) live in device
+ * memory; the step counter is incremented on the stream before the update reads it. */
+int pcgan_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                        const float* lr_dev, int* step_dev, float beta1, float beta2, float eps,
+                        pcgan_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCGAN_HIP_H */

@@ -1,0 +1,243 @@
+// Pooling and bilinear resize (HBM-bound gathers).  Backward passes are written as
+// GATHERS over the input grid (each input element sums the few outputs that reference
+// it) so they are deterministic and need no atomics.
+//
+// Reference: nn.MaxPool2d in models/resnet.py:138 and models/networks.py:1225-1235,
+// nn.AvgPool2d(H)/nn.MaxPool2d(H) in models/networks.py:1056-1059,
+// F.interpolate(mode='bilinear', align_corners=True) in util/util.py:111-117.
+#include "common.h"
+#include <float.h>
+
+namespace pcgan {
+
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ arg,
+                                   int H, int W, int k, int stride, int pad, int P, int Q, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q);
+        const int p = (int)((i / Q) % P);
+        const size_t nc = i / ((size_t)P * Q);
+        const float* xp = x + nc * (size_t)H * W;
+        const int y0 = p * stride - pad, x0 = q * stride - pad;
+        float best = -FLT_MAX;
+        int bi = -1;
+        for (int r = 0; r < k; ++r) {
+            const int iy = y0 + r;
+            if (iy < 0 || iy >= H) continue;
+            for (int s = 0; s < k; ++s) {
+                const int ix = x0 + s;
+                if (ix < 0 || ix >= W) continue;
+                const float v = xp[iy * W + ix];
+                if (bi < 0 || v > best || v != v) {  // first maximum in scan order; NaN propagates
+                    best = v;
+                    bi = iy * W + ix;
+                }
+            }
+        }
+        y[i] = best;
+        arg[i] = bi;
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, float* __restrict__ dx,
+                                   int H, int W, int k, int stride, int pad, int P, int Q, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % W);
+        const int iy = (int)((i / W) % H);
+        const size_t nc = i / ((size_t)H * W);
+        const int me = iy * W + ix;
+        // output rows p with p*stride - pad <= iy <= p*stride - pad + k - 1
+        int p_lo = (iy + pad - k + 1 + stride - 1);
+        p_lo = p_lo <= 0 ? 0 : p_lo / stride;
+        int p_hi = (iy + pad) / stride;
+        if (p_hi > P - 1) p_hi = P - 1;
+        int q_lo = (ix + pad - k + 1 + stride - 1);
+        q_lo = q_lo <= 0 ? 0 : q_lo / stride;
+        int q_hi = (ix + pad) / stride;
+        if (q_hi > Q - 1) q_hi = Q - 1;
+        float acc = 0.f;
+        const size_t ob = nc * (size_t)P * Q;
+        for (int p = p_lo; p <= p_hi; ++p)
+            for (int q = q_lo; q <= q_hi; ++q)
+                if (arg[ob + p * Q + q] == me) acc += dy[ob + p * Q + q];
+        dx[i] = acc;
+    }
+}
+
+// one wave per plane
+__global__ void global_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ arg,
+                                       int NC, int HW, int is_max) {
+    const int plane = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (plane >= NC) return;
+    const int lane = threadIdx.x & 63;
+    const float* xp = x + (size_t)plane * HW;
+    if (is_max) {
+        float best = -FLT_MAX;
+        int bi = 0x7fffffff;
+        for (int i = lane; i < HW; i += 64) {
+            const float v = xp[i];
+            if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { y[plane] = best; arg[plane] = bi; }
+    } else {
+        float s = 0.f;
+        for (int i = lane; i < HW; i += 64) s += xp[i];
+        s = wave_sum(s);
+        if (lane == 0) y[plane] = s / (float)HW;
+    }
+}
+
+__global__ void global_pool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg,
+                                       float* __restrict__ dx, int HW, int is_max, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t plane = i / HW;
+        const int e = (int)(i - plane * HW);
+        if (is_max) dx[i] = (arg[plane] == e) ? dy[plane] : 0.f;
+        else dx[i] = dy[plane] / (float)HW;
+    }
+}
+
+// source index arithmetic identical to ATen's area_pixel_compute_source_index for
+// align_corners=True: scale = (in-1)/(out-1) in fp32, src = scale * dst
+__device__ __forceinline__ void bilin_src(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    const float src = scale * (float)dst;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int P, int Q,
+                                    float sh, float sw, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q);
+        const int p = (int)((i / Q) % P);
+        const size_t nc = i / ((size_t)P * Q);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilin_src(p, sh, H, y0, y1, ly);
+        bilin_src(q, sw, W, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* xp = x + nc * (size_t)H * W;
+        y[i] = hy * (hx * xp[y0 * W + x0] + lx * xp[y0 * W + x1]) + ly * (hx * xp[y1 * W + x0] + lx * xp[y1 * W + x1]);
+    }
+}
+
+// gather form of the backward: for input row iy the output rows p whose (y0,y1) touch it
+// lie in [ceil((iy-1)/sh), floor((iy+1)/sh)]; every candidate is re-derived exactly.
+__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int P, int Q,
+                                    float sh, float sw, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % W);
+        const int iy = (int)((i / W) % H);
+        const size_t nc = i / ((size_t)H * W);
+        int p_lo = 0, p_hi = P - 1, q_lo = 0, q_hi = Q - 1;
+        if (sh > 0.f) {
+            p_lo = (int)floorf((float)(iy - 1) / sh) - 1;
+            p_hi = (int)ceilf((float)(iy + 1) / sh) + 1;
+            if (p_lo < 0) p_lo = 0;
+            if (p_hi > P - 1) p_hi = P - 1;
+        }
+        if (sw > 0.f) {
+            q_lo = (int)floorf((float)(ix - 1) / sw) - 1;
+            q_hi = (int)ceilf((float)(ix + 1) / sw) + 1;
+            if (q_lo < 0) q_lo = 0;
+            if (q_hi > Q - 1) q_hi = Q - 1;
+        }
+        const float* dp = dy + nc * (size_t)P * Q;
+        float acc = 0.f;
+        for (int p = p_lo; p <= p_hi; ++p) {
+            int y0, y1;
+            float ly;
+            bilin_src(p, sh, H, y0, y1, ly);
+            float wy = 0.f;
+            if (y0 == iy) wy += 1.f - ly;
+            if (y1 == iy) wy += ly;
+            if (wy == 0.f) continue;
+            for (int q = q_lo; q <= q_hi; ++q) {
+                int x0, x1;
+                float lx;
+                bilin_src(q, sw, W, x0, x1, lx);
+                float wx = 0.f;
+                if (x0 == ix) wx += 1.f - lx;
+                if (x1 == ix) wx += lx;
+                if (wx != 0.f) acc += wy * wx * dp[p * Q + q];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+static inline int ew_blocks(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b > 16384 ? 16384 : (b == 0 ? 1 : b));
+}
+
+}  // namespace pcgan
+
+using namespace pcgan;
+
+extern "C" int pcgan_maxpool_fwd(const float* x, float* y, int32_t* argmax, int NC, int H, int W, int k, int stride,
+                                 int pad, int P, int Q, pcgan_stream_t s) {
+    PCGAN_CHECK(x && y && argmax && NC > 0 && H > 0 && W > 0 && k > 0 && stride > 0, "maxpool_fwd: bad arguments");
+    PCGAN_CHECK(P == (H + 2 * pad - k) / stride + 1 && Q == (W + 2 * pad - k) / stride + 1,
+                "maxpool_fwd: output dims do not match (floor mode)");
+    const size_t total = (size_t)NC * P * Q;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, x, y, argmax, H, W, k,
+                       stride, pad, P, Q, total);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_maxpool_bwd(const float* dy, const int32_t* argmax, float* dx, int NC, int H, int W, int k,
+                                 int stride, int pad, int P, int Q, pcgan_stream_t s) {
+    PCGAN_CHECK(dy && argmax && dx && NC > 0, "maxpool_bwd: bad arguments");
+    const size_t total = (size_t)NC * H * W;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, dy, argmax, dx, H, W,
+                       k, stride, pad, P, Q, total);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_global_pool_fwd(const float* x, float* y, int32_t* argmax, int NC, int HW, int is_max,
+                                     pcgan_stream_t s) {
+    PCGAN_CHECK(x && y && NC > 0 && HW > 0 && (!is_max || argmax), "global_pool_fwd: bad arguments");
+    hipLaunchKernelGGL(global_pool_fwd_kernel, dim3((NC + 3) / 4), dim3(256), 0, (hipStream_t)s, x, y, argmax, NC, HW,
+                       is_max);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_global_pool_bwd(const float* dy, const int32_t* argmax, float* dx, int NC, int HW, int is_max,
+                                     pcgan_stream_t s) {
+    PCGAN_CHECK(dy && dx && NC > 0 && HW > 0 && (!is_max || argmax), "global_pool_bwd: bad arguments");
+    const size_t total = (size_t)NC * HW;
+    hipLaunchKernelGGL(global_pool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, dy, argmax, dx, HW,
+                       is_max, total);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+extern "C" int pcgan_bilinear_fwd(const float* x, float* y, int NC, int H, int W, int P, int Q, pcgan_stream_t s) {
+    PCGAN_CHECK(x && y && NC > 0 && H > 0 && W > 0 && P > 0 && Q > 0, "bilinear_fwd: bad arguments");
+    const size_t total = (size_t)NC * P * Q;
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, x, y, H, W, P, Q,
+                       ac_scale(H, P), ac_scale(W, Q), total);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_bilinear_bwd(const float* dy, float* dx, int NC, int H, int W, int P, int Q, pcgan_stream_t s) {
+    PCGAN_CHECK(dy && dx && NC > 0 && H > 0 && W > 0 && P > 0 && Q > 0, "bilinear_bwd: bad arguments");
+    const size_t total = (size_t)NC * H * W;
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, dy, dx, H, W, P, Q,
+                       ac_scale(H, P), ac_scale(W, Q), total);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}

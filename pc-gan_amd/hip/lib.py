@@ -1,0 +1,88 @@
+"""ctypes binding of libpcgan_hip.so (the C-ABI declared in include/pcgan_hip.h).
+
+The library is the product path: there is no CPU or eager-PyTorch fallback.  If the
+shared object is missing or a tensor is not a contiguous fp32 tensor on an AMD GPU the
+call raises -- loudly -- instead of computing something else.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libpcgan_hip.so')
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+PASS_FWD, PASS_BWD_DATA, PASS_BWD_WEIGHT = 0, 1, 2
+
+
+class ConvDesc(ctypes.Structure):
+    """pcgan_conv_desc (include/pcgan_hip.h)."""
+    _fields_ = [(n, ctypes.c_int) for n in
+                ('N', 'C', 'H', 'W', 'K', 'R', 'S', 'stride', 'pad', 'pad_mode', 'P', 'Q')]
+
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_dp = ctypes.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); kept in one table so tests can check that the library
+# exports every symbol the header declares.
+SIGNATURES = {
+    'pcgan_last_error': (ctypes.c_char_p, []),
+    'pcgan_version': (_i, []),
+    'pcgan_device_info': (_i, [ctypes.POINTER(_i), ctypes.c_char_p, _i]),
+    'pcgan_conv2d_workspace_bytes': (_sz, [_dp, _i]),
+    'pcgan_conv2d_fwd': (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
+    'pcgan_conv2d_bwd_data': (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'pcgan_conv2d_bwd_weight': (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'pcgan_channel_sum': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pcgan_act_bwd': (_i, [_vp, _vp, _vp, _sz, _i, _f, _vp]),
+    'pcgan_act_fwd': (_i, [_vp, _vp, _sz, _i, _f, _vp]),
+    'pcgan_concat_z': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_add': (_i, [_vp, _vp, _vp, _sz, _vp]),
+    'pcgan_scale': (_i, [_vp, _vp, _f, _vp, _sz, _vp]),
+    'pcgan_channel_scale': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    'pcgan_plane_stats': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'pcgan_bn_merge': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    'pcgan_in_running_update': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    'pcgan_norm_act_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp]),
+    'pcgan_norm_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp]),
+    'pcgan_norm_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp]),
+    'pcgan_bn_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'pcgan_maxpool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_maxpool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_global_pool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pcgan_global_pool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pcgan_bilinear_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_bilinear_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_bce_loss': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),
+    'pcgan_l1_loss': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _vp, _sz, _vp]),
+    'pcgan_mse_loss': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _vp, _sz, _vp]),
+    'pcgan_loss_workspace_bytes': (_sz, [_sz]),
+    'pcgan_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _vp]),
+    'pcgan_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _f, _f, _f, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises RuntimeError if the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'pcgan_amd: %s not found -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(or `make -C pc-gan_amd/csrc`). There is no fallback path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().pcgan_last_error()
+        raise RuntimeError('pcgan_hip %s failed (status %d): %s' % (what, status, msg.decode() if msg else '?'))

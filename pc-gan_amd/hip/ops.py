@@ -1,0 +1,337 @@
+"""Tensor-level wrappers over the C-ABI: validate, allocate outputs/workspace through
+torch's caching allocator (device memory plumbing only) and launch on torch's current
+stream.  No arithmetic happens in Python or in torch here.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _L
+from .lib import ConvDesc, ACT_NONE
+
+_vp = ctypes.c_void_p
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('pcgan_amd: tensor on %s -- the HIP path needs GPU tensors (no CPU fallback)' % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError('pcgan_amd: expected float32, got %s' % t.dtype)
+        if not t.is_contiguous():
+            raise RuntimeError('pcgan_amd: tensor must be contiguous')
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def conv_out_size(H, k, stride, pad):
+    return (H + 2 * pad - k) // stride + 1
+
+
+def make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode):
+    return ConvDesc(N, C, H, W, K, R, S, stride, pad, pad_mode,
+                    conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad))
+
+
+# ---------------------------------------------------------------- convolution family
+def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0):
+    _chk(x, w, bias)
+    lib = _L.load()
+    N, C, H, W = x.shape
+    K, C2, R, S = w.shape
+    assert C == C2, 'conv2d_fwd: channel mismatch %d vs %d' % (C, C2)
+    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode)
+    y = torch.empty((N, K, d.P, d.Q), dtype=torch.float32, device=x.device)
+    nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_FWD)
+    ws = _ws(nb, x.device)
+    _L.check(lib.pcgan_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), act, float(slope),
+                                  _p(ws), ws.numel(), _stream()), 'conv2d_fwd')
+    return y
+
+
+def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None):
+    """dx[N][C][H][W] for a conv with weight w[K][C][R][S]; in_hw = (H, W) of the conv input."""
+    _chk(dy, w, bias)
+    lib = _L.load()
+    N, K, P, Q = dy.shape
+    K2, C, R, S = w.shape
+    assert K == K2, 'conv2d_bwd_data: channel mismatch'
+    H, W = in_hw
+    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode)
+    assert (d.P, d.Q) == (P, Q), 'conv2d_bwd_data: geometry mismatch %s vs %s' % ((d.P, d.Q), (P, Q))
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_BWD_DATA)
+    ws = _ws(nb, dy.device)
+    _L.check(lib.pcgan_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(w), _p(bias), _p(dx), _p(ws), ws.numel(),
+                                       _stream()), 'conv2d_bwd_data')
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0):
+    _chk(x, dy)
+    lib = _L.load()
+    N, C, H, W = x.shape
+    K, C2, R, S = w_shape
+    assert C == C2 and dy.shape[1] == K
+    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode)
+    assert (d.P, d.Q) == tuple(dy.shape[2:]), 'conv2d_bwd_weight: geometry mismatch'
+    dw = torch.empty((K, C, R, S), dtype=torch.float32, device=x.device)
+    nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_BWD_WEIGHT)
+    ws = _ws(nb, x.device)
+    _L.check(lib.pcgan_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), _stream()),
+             'conv2d_bwd_weight')
+    return dw
+
+
+# ---------------------------------------------------------------- pointwise
+def channel_sum(x):
+    _chk(x)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().pcgan_channel_sum(_p(x), _p(out), _p(scratch), N, C, HW, _stream()), 'channel_sum')
+    return out
+
+
+def act_fwd(x, act, slope=0.0):
+    _chk(x)
+    y = torch.empty_like(x)
+    _L.check(_L.load().pcgan_act_fwd(_p(x), _p(y), x.numel(), act, float(slope), _stream()), 'act_fwd')
+    return y
+
+
+def act_bwd(dy, y, act, slope=0.0):
+    _chk(dy, y)
+    dx = torch.empty_like(dy)
+    _L.check(_L.load().pcgan_act_bwd(_p(dy), _p(y), _p(dx), dy.numel(), act, float(slope), _stream()), 'act_bwd')
+    return dx
+
+
+def add(a, b):
+    _chk(a, b)
+    assert a.shape == b.shape
+    y = torch.empty_like(a)
+    _L.check(_L.load().pcgan_add(_p(a), _p(b), _p(y), a.numel(), _stream()), 'add')
+    return y
+
+
+def scale(x, scalar_dev=None, alpha=1.0):
+    _chk(x, scalar_dev)
+    y = torch.empty_like(x)
+    _L.check(_L.load().pcgan_scale(_p(x), _p(scalar_dev), float(alpha), _p(y), x.numel(), _stream()), 'scale')
+    return y
+
+
+def concat_z(img, z):
+    _chk(img, z)
+    N, C, H, W = img.shape
+    zb, nz = z.shape[0], z.shape[1]
+    out = torch.empty((N, C + nz, H, W), dtype=torch.float32, device=img.device)
+    _L.check(_L.load().pcgan_concat_z(_p(img), _p(z), _p(out), N, C, nz, H * W, zb, _stream()), 'concat_z')
+    return out
+
+
+def channel_scale(x, mask_nc, scale_):
+    _chk(x, mask_nc)
+    N, C = x.shape[0], x.shape[1]
+    y = torch.empty_like(x)
+    _L.check(_L.load().pcgan_channel_scale(_p(x), _p(mask_nc), _p(y), N * C, x.numel() // (N * C), float(scale_),
+                                           _stream()), 'channel_scale')
+    return y
+
+
+# ---------------------------------------------------------------- normalisation
+def plane_stats(x):
+    _chk(x)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    m2 = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().pcgan_plane_stats(_p(x), _p(mean), _p(m2), N * C, HW, _stream()), 'plane_stats')
+    return mean, m2
+
+
+def bn_merge(mean_nc, m2_nc, N, C, HW, running_mean, running_var, momentum):
+    _chk(mean_nc, m2_nc, running_mean, running_var)
+    mean_c = torch.empty(C, dtype=torch.float32, device=mean_nc.device)
+    var_c = torch.empty(C, dtype=torch.float32, device=mean_nc.device)
+    _L.check(_L.load().pcgan_bn_merge(_p(mean_nc), _p(m2_nc), _p(mean_c), _p(var_c), _p(running_mean),
+                                      _p(running_var), N, C, HW, float(momentum), _stream()), 'bn_merge')
+    return mean_c, var_c
+
+
+def in_running_update(mean_nc, m2_nc, running_mean, running_var, N, C, HW, momentum):
+    _chk(mean_nc, m2_nc, running_mean, running_var)
+    _L.check(_L.load().pcgan_in_running_update(_p(mean_nc), _p(m2_nc), _p(running_mean), _p(running_var), N, C, HW,
+                                               float(momentum), _stream()), 'in_running_update')
+
+
+def norm_act_fwd(x, mean, var, gamma, beta, residual, per_plane, eps, act, slope):
+    _chk(x, mean, var, gamma, beta, residual)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    y = torch.empty_like(x)
+    _L.check(_L.load().pcgan_norm_act_fwd(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(residual), _p(y), N, C,
+                                          HW, int(per_plane), float(eps), act, float(slope), _stream()),
+             'norm_act_fwd')
+    return y
+
+
+def norm_bwd_stats(dy, x, y, mean, var, per_plane, eps, act, slope):
+    _chk(dy, x, y, mean, var)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    s1 = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    s2 = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().pcgan_norm_bwd_stats(_p(dy), _p(x), _p(y), _p(mean), _p(var), _p(s1), _p(s2), N, C, HW,
+                                            int(per_plane), float(eps), act, float(slope), _stream()),
+             'norm_bwd_stats')
+    return s1, s2
+
+
+def bn_bwd_reduce(s1_nc, s2_nc, N, C):
+    _chk(s1_nc, s2_nc)
+    s1 = torch.empty(C, dtype=torch.float32, device=s1_nc.device)
+    s2 = torch.empty(C, dtype=torch.float32, device=s1_nc.device)
+    _L.check(_L.load().pcgan_bn_bwd_reduce(_p(s1_nc), _p(s2_nc), _p(s1), _p(s2), N, C, _stream()), 'bn_bwd_reduce')
+    return s1, s2
+
+
+def norm_bwd_apply(dy, x, y, mean, var, gamma, s1, s2, per_plane, eps, act, slope, want_residual_grad):
+    _chk(dy, x, y, mean, var, gamma, s1, s2)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_residual_grad else None
+    _L.check(_L.load().pcgan_norm_bwd_apply(_p(dy), _p(x), _p(y), _p(mean), _p(var), _p(gamma), _p(s1), _p(s2),
+                                            _p(dx), _p(dres), N, C, HW, int(per_plane), float(eps), act,
+                                            float(slope), _stream()), 'norm_bwd_apply')
+    return dx, dres
+
+
+# ---------------------------------------------------------------- pooling / resize
+def maxpool_fwd(x, k, stride, pad):
+    _chk(x)
+    N, C, H, W = x.shape
+    P, Q = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    y = torch.empty((N, C, P, Q), dtype=torch.float32, device=x.device)
+    arg = torch.empty((N, C, P, Q), dtype=torch.int32, device=x.device)
+    _L.check(_L.load().pcgan_maxpool_fwd(_p(x), _p(y), _vp(arg.data_ptr()), N * C, H, W, k, stride, pad, P, Q,
+                                         _stream()), 'maxpool_fwd')
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, in_hw, k, stride, pad):
+    _chk(dy)
+    N, C, P, Q = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    _L.check(_L.load().pcgan_maxpool_bwd(_p(dy), _vp(arg.data_ptr()), _p(dx), N * C, H, W, k, stride, pad, P, Q,
+                                         _stream()), 'maxpool_bwd')
+    return dx
+
+
+def global_pool_fwd(x, is_max):
+    _chk(x)
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, 1, 1), dtype=torch.float32, device=x.device)
+    arg = torch.empty((N, C), dtype=torch.int32, device=x.device) if is_max else None
+    _L.check(_L.load().pcgan_global_pool_fwd(_p(x), _p(y), _vp(arg.data_ptr()) if is_max else _vp(0), N * C, H * W,
+                                             int(is_max), _stream()), 'global_pool_fwd')
+    return y, arg
+
+
+def global_pool_bwd(dy, arg, in_hw, is_max):
+    _chk(dy)
+    N, C = dy.shape[0], dy.shape[1]
+    H, W = in_hw
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    _L.check(_L.load().pcgan_global_pool_bwd(_p(dy), _vp(arg.data_ptr()) if is_max else _vp(0), _p(dx), N * C, H * W,
+                                             int(is_max), _stream()), 'global_pool_bwd')
+    return dx
+
+
+def bilinear_fwd(x, size):
+    _chk(x)
+    N, C, H, W = x.shape
+    P, Q = size
+    y = torch.empty((N, C, P, Q), dtype=torch.float32, device=x.device)
+    _L.check(_L.load().pcgan_bilinear_fwd(_p(x), _p(y), N * C, H, W, P, Q, _stream()), 'bilinear_fwd')
+    return y
+
+
+def bilinear_bwd(dy, in_hw):
+    _chk(dy)
+    N, C, P, Q = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    _L.check(_L.load().pcgan_bilinear_bwd(_p(dy), _p(dx), N * C, H, W, P, Q, _stream()), 'bilinear_bwd')
+    return dx
+
+
+# ---------------------------------------------------------------- losses / optimizer
+def _loss(fn_name, a, b, n_or_N, per_n, want_grad):
+    lib = _L.load()
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    grad = torch.empty_like(a) if want_grad else None
+    ws = _ws(lib.pcgan_loss_workspace_bytes(a.numel()), a.device)
+    fn = getattr(lib, fn_name)
+    if fn_name == 'pcgan_bce_loss':
+        st = fn(_p(a), _p(b), _p(loss), _p(grad), n_or_N, per_n, 1.0, _p(ws), ws.numel(), _stream())
+    else:
+        st = fn(_p(a), _p(b), _p(loss), _p(grad), a.numel(), 1.0, _p(ws), ws.numel(), _stream())
+    _L.check(st, fn_name)
+    return loss, grad
+
+
+def bce_loss(pred, target_n, want_grad=True):
+    """mean BCE of pred[N][...] against target_n[N] broadcast over each sample."""
+    _chk(pred, target_n)
+    N = pred.shape[0]
+    assert target_n.numel() == N
+    return _loss('pcgan_bce_loss', pred, target_n, N, pred.numel() // N, want_grad)
+
+
+def l1_loss(a, b, want_grad=True):
+    _chk(a, b)
+    assert a.shape == b.shape
+    return _loss('pcgan_l1_loss', a, b, 0, 1, want_grad)
+
+
+def mse_loss(a, b, want_grad=True):
+    _chk(a, b)
+    assert a.shape == b.shape
+    return _loss('pcgan_mse_loss', a, b, 0, 1, want_grad)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    _chk(param, grad, exp_avg, exp_avg_sq)
+    _L.check(_L.load().pcgan_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr),
+                                       float(beta1), float(beta2), float(eps), int(step), _stream()), 'adam_step')
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1, beta2, eps):
+    _chk(param, grad, exp_avg, exp_avg_sq, lr_dev)
+    _L.check(_L.load().pcgan_adam_step_dev(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(),
+                                           _p(lr_dev), _vp(step_dev.data_ptr()), float(beta1), float(beta2),
+                                           float(eps), _stream()), 'adam_step_dev')
+
+
+def device_info():
+    cu = ctypes.c_int(0)
+    buf = ctypes.create_string_buffer(64)
+    _L.check(_L.load().pcgan_device_info(ctypes.byref(cu), buf, 64), 'device_info')
+    return cu.value, buf.value.decode()

@@ -1,0 +1,305 @@
+"""GPU parity tests of the raw C-ABI kernels against the oracle's per-op restatement
+(oracle/ops_ref.py), judged against its float64 twin.
+
+Tolerances (relative to the largest reference magnitude, SURVEY.md 8c basis):
+  forward / data-gradient of one op       2e-5   (fp32 fma chain over K <= 4608 terms)
+  weight-gradient (reduction over pixels) 1e-4   (up to 5e5-term fp32 sums)
+  index outputs (argmax)                  exact
+"""
+import pytest
+import torch
+
+from oracle import ops_ref as R
+from util_cmp import assert_close
+
+pytestmark = pytest.mark.gpu
+
+# (name, N, C, H, W, K, R, stride, pad, pad_mode)
+CONV_CASES = [
+    ('res3x3_reflect_small', 2, 16, 8, 8, 16, 3, 1, 1, 1),
+    ('res3x3_reflect_256', 2, 256, 32, 32, 256, 3, 1, 1, 1),
+    ('stem7x7_reflect_c4', 2, 4, 16, 16, 8, 7, 1, 3, 1),
+    ('stem7x7_reflect_c4_k64', 1, 4, 32, 32, 64, 7, 1, 3, 1),
+    ('head7x7_reflect_k3', 2, 16, 16, 16, 3, 7, 1, 3, 1),
+    ('down3x3_s2', 2, 8, 16, 16, 16, 3, 2, 1, 0),
+    ('down3x3_s2_64_128', 2, 64, 32, 32, 128, 3, 2, 1, 0),
+    ('d4x4_s2_c4', 2, 4, 16, 16, 8, 4, 2, 1, 0),
+    ('d4x4_s2_64_128', 2, 64, 16, 16, 128, 4, 2, 1, 0),
+    ('d4x4_s1_odd', 2, 16, 16, 16, 32, 4, 1, 1, 0),
+    ('d4x4_s1_k1', 3, 32, 15, 15, 1, 4, 1, 1, 0),
+    ('e7x7_s2_c3', 2, 3, 20, 20, 16, 7, 2, 3, 0),
+    ('ip11x11_s4_c3', 2, 3, 35, 35, 8, 11, 4, 2, 0),
+    ('ip5x5_p2', 2, 8, 13, 13, 24, 5, 1, 2, 0),
+    ('e1x1_s2', 2, 16, 14, 14, 32, 1, 2, 0, 0),
+    ('e3x3_7x7plane', 3, 32, 7, 7, 48, 3, 1, 1, 0),
+    ('e3x3_k1', 3, 32, 7, 7, 1, 3, 1, 1, 0),
+    ('e3x3_s2_odd', 2, 16, 14, 14, 24, 3, 2, 1, 0),
+    ('c192', 1, 192, 13, 13, 96, 3, 1, 1, 0),
+]
+
+
+def _conv_ref(x, w, b, stride, pad, pad_mode, dy):
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    y = R.conv2d(x64, w64, b64, stride, pad, pad_mode)
+    y.backward(dy.double())
+    return y.detach(), x64.grad, w64.grad, b64.grad
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_fwd_bwd(case, dev):
+    from pcgan_amd.hip import ops
+    name, N, C, H, W, K, Rk, stride, pad, pm = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    x = torch.rand(N, C, H, W, generator=g) * 2 - 1
+    w = torch.randn(K, C, Rk, Rk, generator=g) * 0.1
+    b = torch.randn(K, generator=g) * 0.1
+    P = (H + 2 * pad - Rk) // stride + 1
+    dy = torch.randn(N, K, P, P, generator=g)
+    y_ref, dx_ref, dw_ref, db_ref = _conv_ref(x, w, b, stride, pad, pm, dy)
+
+    xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    y = ops.conv2d_fwd(xd, wd, bd, stride, pad, pm)
+    assert_close(y, y_ref, 2e-5, name + ' fwd')
+    dx = ops.conv2d_bwd_data(dyd, wd, (H, W), stride, pad, pm)
+    assert_close(dx, dx_ref, 2e-5, name + ' bwd_data')
+    dw = ops.conv2d_bwd_weight(xd, dyd, tuple(w.shape), stride, pad, pm)
+    assert_close(dw, dw_ref, 1e-4, name + ' bwd_weight')
+    db = ops.channel_sum(dyd)
+    assert_close(db, db_ref, 1e-4, name + ' bias grad')
+
+
+@pytest.mark.parametrize('act,slope', [(1, 0.0), (2, 0.2), (3, 0.0), (4, 0.0)])
+def test_conv2d_fused_activation(act, slope, dev):
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 8, 12, 12, generator=g) * 2 - 1
+    w = torch.randn(16, 8, 3, 3, generator=g) * 0.2
+    b = torch.randn(16, generator=g) * 0.1
+    ref = R.activation(R.conv2d(x.double(), w.double(), b.double(), 1, 1, 0), act, slope)
+    y = ops.conv2d_fwd(x.to(dev), w.to(dev), b.to(dev), 1, 1, 0, act, slope)
+    assert_close(y, ref, 2e-5, 'conv+act %d' % act)
+    dy = torch.randn(ref.shape, generator=g)
+    y64 = ref.clone().requires_grad_(False)
+    pre = R.conv2d(x.double(), w.double(), b.double(), 1, 1, 0).requires_grad_(True)
+    R.activation(pre, act, slope).backward(dy.double())
+    dpre = ops.act_bwd(dy.to(dev), y, act, slope)
+    assert_close(dpre, pre.grad, 5e-5, 'act_bwd %d' % act)
+
+
+@pytest.mark.parametrize('cin,cout,hw', [(16, 8, 8), (256, 128, 32), (128, 64, 16)])
+def test_conv_transpose_via_conv_entry_points(cin, cout, hw, dev):
+    """nn.ConvTranspose2d(k3,s2,p1,op1) = bwd_data of the conv (C=cout -> K=cin)."""
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(11)
+    N = 2
+    x = torch.rand(N, cin, hw, hw, generator=g) * 2 - 1
+    w = torch.randn(cin, cout, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g) * 0.1
+    x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y_ref = R.conv_transpose2d(x64, w64, b64)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+    xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    y = ops.conv2d_bwd_data(xd, wd, (2 * hw, 2 * hw), 2, 1, 0, bias=bd)
+    assert_close(y, y_ref, 2e-5, 'convT fwd')
+    dx = ops.conv2d_fwd(dyd, wd, None, 2, 1, 0)
+    assert_close(dx, x64.grad, 2e-5, 'convT dgrad')
+    dw = ops.conv2d_bwd_weight(dyd, xd, tuple(w.shape), 2, 1, 0)
+    assert_close(dw, w64.grad, 1e-4, 'convT wgrad')
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 32, 32), (3, 5, 7, 7), (2, 4, 128, 128), (2, 6, 15, 15)])
+@pytest.mark.parametrize('act,slope,res', [(0, 0.0, False), (1, 0.0, False), (0, 0.0, True)])
+def test_instance_norm(shape, act, slope, res, dev):
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W = shape
+    x = torch.randn(shape, generator=g) * 1.5 + 0.3
+    r = torch.randn(shape, generator=g) if res else None
+    rm, rv = torch.zeros(C), torch.ones(C)
+    rm64, rv64 = rm.double(), rv.double()
+    x64 = x.double().requires_grad_(True)
+    r64 = r.double().requires_grad_(True) if res else None
+    y64 = R.instance_norm(x64, rm64, rv64)
+    if res:
+        y64 = y64 + r64
+    y64 = R.activation(y64, act, slope)
+    dy = torch.randn(shape, generator=g)
+    y64.backward(dy.double())
+
+    xd = x.to(dev)
+    rd = r.to(dev) if res else None
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    mean, m2 = ops.plane_stats(xd)
+    ops.in_running_update(mean, m2, rmd, rvd, N, C, H * W, 0.1)
+    y = ops.norm_act_fwd(xd, mean, m2, None, None, rd, True, 1e-5, act, slope)
+    assert_close(y, y64, 2e-5, 'instnorm fwd')
+    assert_close(rmd, rm64, 2e-5, 'running_mean')
+    assert_close(rvd, rv64, 2e-5, 'running_var')
+    dyd = dy.to(dev)
+    s1, s2 = ops.norm_bwd_stats(dyd, xd, y, mean, m2, True, 1e-5, act, slope)
+    dx, dres = ops.norm_bwd_apply(dyd, xd, y, mean, m2, None, s1, s2, True, 1e-5, act, slope, res)
+    assert_close(dx, x64.grad, 5e-5, 'instnorm bwd')
+    if res:
+        assert_close(dres, r64.grad, 1e-6, 'instnorm residual grad')
+
+
+@pytest.mark.parametrize('shape', [(4, 8, 16, 16), (3, 5, 7, 7), (2, 16, 64, 64)])
+@pytest.mark.parametrize('act,slope,res', [(2, 0.2, False), (1, 0.0, True), (2, 0.7, False), (0, 0.0, False)])
+def test_batch_norm_train(shape, act, slope, res, dev):
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(4)
+    N, C, H, W = shape
+    x = torch.randn(shape, generator=g) * 2.0 - 0.5
+    gamma = torch.randn(C, generator=g) * 0.2 + 1.0
+    beta = torch.randn(C, generator=g) * 0.1
+    r = torch.randn(shape, generator=g) if res else None
+    rm64, rv64 = torch.zeros(C).double(), torch.ones(C).double()
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    r64 = r.double().requires_grad_(True) if res else None
+    y64 = R.batch_norm(x64, g64, b64, rm64, rv64)
+    if res:
+        y64 = y64 + r64
+    y64 = R.activation(y64, act, slope)
+    dy = torch.randn(shape, generator=g)
+    y64.backward(dy.double())
+
+    xd, gd, bd = x.to(dev), gamma.to(dev), beta.to(dev)
+    rd = r.to(dev) if res else None
+    rmd, rvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mean_nc, m2_nc = ops.plane_stats(xd)
+    mean_c, var_c = ops.bn_merge(mean_nc, m2_nc, N, C, H * W, rmd, rvd, 0.1)
+    y = ops.norm_act_fwd(xd, mean_c, var_c, gd, bd, rd, False, 1e-5, act, slope)
+    assert_close(y, y64, 2e-5, 'bn fwd')
+    assert_close(rmd, rm64, 2e-5, 'bn running_mean')
+    assert_close(rvd, rv64, 2e-5, 'bn running_var')
+    dyd = dy.to(dev)
+    s1n, s2n = ops.norm_bwd_stats(dyd, xd, y, mean_c, var_c, False, 1e-5, act, slope)
+    s1, s2 = ops.bn_bwd_reduce(s1n, s2n, N, C)
+    dx, dres = ops.norm_bwd_apply(dyd, xd, y, mean_c, var_c, gd, s1, s2, False, 1e-5, act, slope, res)
+    assert_close(dx, x64.grad, 5e-5, 'bn dx')
+    assert_close(s2, g64.grad, 5e-5, 'bn dgamma')
+    assert_close(s1, b64.grad, 5e-5, 'bn dbeta')
+    if res:
+        assert_close(dres, r64.grad, 1e-6, 'bn residual grad')
+
+
+@pytest.mark.parametrize('shape,k,stride,pad', [((2, 4, 16, 16), 3, 2, 1), ((2, 3, 55, 55), 3, 2, 0),
+                                               ((1, 2, 13, 13), 3, 2, 0), ((2, 3, 112, 112), 3, 2, 1)])
+def test_maxpool(shape, k, stride, pad, dev):
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(shape, generator=g)
+    x64 = x.double().requires_grad_(True)
+    y64 = R.max_pool2d(x64, k, stride, pad)
+    dy = torch.randn(y64.shape, generator=g)
+    y64.backward(dy.double())
+    y, arg = ops.maxpool_fwd(x.to(dev), k, stride, pad)
+    assert torch.equal(y.cpu(), y64.detach().float()), 'maxpool values must be exact'
+    _, idx = torch.nn.functional.max_pool2d(x, k, stride, pad, return_indices=True)
+    assert torch.equal(arg.cpu().long(), idx), 'argmax indices must be bit-exact'
+    dx = ops.maxpool_bwd(dy.to(dev), arg, shape[2:], k, stride, pad)
+    assert_close(dx, x64.grad, 1e-6, 'maxpool bwd')
+
+
+@pytest.mark.parametrize('is_max', [False, True])
+def test_global_pool(is_max, dev):
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(5, 3, 7, 7, generator=g)
+    x64 = x.double().requires_grad_(True)
+    y64 = R.global_pool(x64, is_max)
+    dy = torch.randn(y64.shape, generator=g)
+    y64.backward(dy.double())
+    y, arg = ops.global_pool_fwd(x.to(dev), is_max)
+    assert_close(y, y64, 1e-6, 'global pool fwd')
+    dx = ops.global_pool_bwd(dy.to(dev), arg, (7, 7), is_max)
+    assert_close(dx, x64.grad, 1e-6, 'global pool bwd')
+
+
+@pytest.mark.parametrize('hin,hout', [(128, 224), (32, 64), (16, 28), (20, 9), (7, 7)])
+def test_bilinear_align_corners(hin, hout, dev):
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(2, 3, hin, hin, generator=g) * 2 - 1
+    x64 = x.double().requires_grad_(True)
+    y64 = torch.nn.functional.interpolate(x64, size=(hout, hout), mode='bilinear', align_corners=True)
+    dy = torch.randn(y64.shape, generator=g)
+    y64.backward(dy.double())
+    y = ops.bilinear_fwd(x.to(dev), (hout, hout))
+    assert_close(y, y64, 2e-5, 'bilinear fwd')   # fp32 source-index arithmetic vs fp64 twin
+    y32 = torch.nn.functional.interpolate(x, size=(hout, hout), mode='bilinear', align_corners=True)
+    assert_close(y, y32, 2e-6, 'bilinear fwd vs fp32 oracle')
+    dx = ops.bilinear_bwd(dy.to(dev), (hin, hin))
+    assert_close(dx, x64.grad, 5e-5, 'bilinear bwd')
+
+
+def test_concat_z_and_channel_scale(dev):
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(4, 3, 9, 9, generator=g)
+    for zb in (4, 1):
+        z = torch.randn(zb, 2, 1, 1, generator=g)
+        ref = R.concat_z(img, z)
+        out = ops.concat_z(img.to(dev), z.to(dev).contiguous())
+        assert torch.equal(out.cpu(), ref)
+    mask = (torch.rand(4 * 3, generator=g) > 0.3).float()
+    ref = R.dropout2d_with_mask(img.double(), mask.view(4, 3).double(), 0.2)
+    out = ops.channel_scale(img.to(dev), mask.to(dev), 1.0 / 0.8)
+    assert_close(out, ref, 1e-6, 'dropout2d')
+
+
+def test_losses(dev):
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(10)
+    pred = torch.rand(6, 1, 14, 14, generator=g) * 0.98 + 0.01
+    pred[0, 0, 0, 0] = 0.0      # exercises the -100 log clamp
+    pred[1, 0, 0, 0] = 1.0
+    tgt = torch.tensor([1., 0., 1., 0., 0., 1.])
+    p64 = pred.double().requires_grad_(True)
+    l64 = R.bce_loss(p64, tgt.double())
+    l64.backward()
+    loss, grad = ops.bce_loss(pred.to(dev), tgt.to(dev))
+    assert_close(loss, l64, 1e-5, 'bce loss')
+    # the two clamped elements have a 1e12-scale gradient in torch as well; compare the rest
+    gm = grad.cpu().double().clone()
+    rm = p64.grad.clone()
+    for t in (gm, rm):
+        t[0, 0, 0, 0] = 0
+        t[1, 0, 0, 0] = 0
+    assert_close(gm, rm, 1e-5, 'bce grad')
+    a = torch.randn(4, 3, 16, 16, generator=g)
+    b = torch.randn(4, 3, 16, 16, generator=g)
+    for fn, ref in ((ops.l1_loss, R.l1_loss), (ops.mse_loss, R.mse_loss)):
+        a64 = a.double().requires_grad_(True)
+        l = ref(a64, b.double())
+        l.backward()
+        loss, grad = fn(a.to(dev), b.to(dev))
+        assert_close(loss, l, 1e-5, 'loss')
+        assert_close(grad, a64.grad, 1e-5, 'loss grad')
+
+
+def test_adam_matches_torch(dev):
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(12)
+    p = torch.randn(10007, generator=g)
+    grads = torch.randn(10007, generator=g) * 0.01
+    ref = R.adam_reference([p], [grads], lr=2e-4, beta1=0.5, steps=3)[0]
+    pd, gd = p.to(dev), grads.to(dev)
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    for step in (1, 2, 3):
+        ops.adam_step(pd, gd, m, v, 2e-4, 0.5, 0.999, 1e-8, step)
+    # identical grads fed to both Adams: agreement to fp32 rounding of the update
+    assert (pd.cpu() - ref).abs().max().item() < 2e-7
+    # device-state variant
+    pd2 = p.to(dev)
+    m2, v2 = torch.zeros_like(pd2), torch.zeros_like(pd2)
+    lr_dev = torch.tensor([2e-4], device=dev)
+    step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        ops.adam_step_dev(pd2, gd, m2, v2, lr_dev, step_dev, 0.5, 0.999, 1e-8)
+    assert int(step_dev.item()) == 3
+    assert torch.equal(pd2, pd)
