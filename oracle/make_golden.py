@@ -1,0 +1,235 @@
+"""ORACLE fixture generator (test infrastructure).  Run ONCE in the build container:
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+
+It IMPORTS the reference (read-only, /root/reference) on CPU, feeds it seeded inputs and the
+deterministic weights of oracle/weights.py, and records what the reference computes.  Only
+the resulting data (inputs/expected outputs) is committed; the reference source never leaves
+the container and nothing in tests/, smoke() or bench.py reads /root/reference at run time.
+
+`torchvision` is not installed here; the reference's model file imports
+`torchvision.transforms` at module top without using it on this path, so two empty stub
+modules are registered (an ordinary missing-module workaround).
+"""
+import argparse
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+from oracle import weights as W  # noqa: E402
+
+
+def import_reference():
+    for name in ('torchvision', 'torchvision.transforms'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.path.insert(0, REF)
+    import models.networks as ref_networks           # noqa: E402
+    return ref_networks
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def grads_summary(named_grads, prefix, out, full=True, stride=97):
+    """full tensors for small nets; per-tensor (sum, abs-sum, l2) + strided sample otherwise."""
+    for k, g in named_grads:
+        if g is None:
+            continue
+        a = t2n(g).astype(np.float64)
+        out['%s/stat/%s' % (prefix, k)] = np.array([a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())])
+        if full:
+            out['%s/full/%s' % (prefix, k)] = t2n(g)
+        else:
+            out['%s/samp/%s' % (prefix, k)] = t2n(g).reshape(-1)[::stride].copy()
+
+
+def run_net(net, inputs, seed_dy, out, prefix, full_grads=True, fp64=False):
+    """forward + backward of one net on seeded inputs; records outputs, input grads, param grads,
+    buffers after the call."""
+    if fp64:
+        net = net.double()
+        inputs = [i.double() for i in inputs]
+    xs = [i.clone().requires_grad_(i.is_floating_point()) for i in inputs]
+    y = net(*xs)
+    ys = list(y) if isinstance(y, (tuple, list)) else [y]
+    dys = [W.seeded_normal(tuple(o.shape), seed_dy + j).to(o.dtype) for j, o in enumerate(ys)]
+    torch.autograd.backward(ys, dys)
+    for j, o in enumerate(ys):
+        out['%s/out%d' % (prefix, j)] = t2n(o)
+    for j, x in enumerate(xs):
+        if x.grad is not None:
+            out['%s/din%d' % (prefix, j)] = t2n(x.grad)
+    grads_summary([(k, p.grad) for k, p in net.named_parameters()], prefix + '/dparam', out, full_grads)
+    for k, b in net.named_buffers():
+        if 'running' in k:
+            a = t2n(b).astype(np.float64)
+            out['%s/buf/%s' % (prefix, k)] = np.array([a.sum(), np.abs(a).sum()])
+
+
+def golden_nets(rn, outdir):
+    """Per-network vectors: G (2 and 9 blocks), D, E (plain / noisy), IP."""
+    out = {}
+    torch.manual_seed(0)
+    nl_in = rn.get_norm_layer('instance')
+    nl_bn = rn.get_norm_layer('batch')
+    for nb in (2, 9):
+        g = rn.ResnetGenerator(3, 3, 1, 8, norm_layer=nl_in, n_blocks=nb)
+        g.load_state_dict(W.fill_state_dict(g.state_dict(), 10 + nb))
+        x = W.seeded_tensor((2, 3, 16, 16), 100 + nb)
+        z = W.seeded_normal((2, 1, 1, 1), 200 + nb)
+        run_net(g, [x, z], 300 + nb, out, 'G%d' % nb)
+        # z given once for the whole batch (1,nz,1,1) is broadcast (probe_quirks)
+        g.zero_grad()
+        with torch.no_grad():
+            out['G%d/out_zbroadcast' % nb] = t2n(g(x, z[:1]))
+    d = rn.NLayerDiscriminator(3, 1, 8, n_layers=3, norm_layer=nl_bn, use_sigmoid=True)
+    d.load_state_dict(W.fill_state_dict(d.state_dict(), 20))
+    run_net(d, [W.seeded_tensor((3, 3, 32, 32), 101), W.seeded_normal((3, 1, 1, 1), 201)], 301, out, 'D')
+    for noisy in (False, True):
+        e = rn.SiameseFeature(rn.ResNetFeature(3, 'resnet18'), pooling='avg', cnn_dim=[32, 1], cnn_pad=1,
+                              cnn_relu_slope=0.7, noisy=noisy, drop_layer=rn.get_dropout_layer(0.))
+        e.load_state_dict(W.fill_state_dict(e.state_dict(), 30))
+        run_net(e, [W.seeded_tensor((3, 3, 64, 64), 102)], 302, out, 'E_noisy%d' % int(noisy), full_grads=False)
+    ip = rn.AlexNetFeature(input_nc=3, pooling='None')
+    ip.load_state_dict(W.fill_state_dict(ip.state_dict(), 40))
+    run_net(ip, [W.seeded_tensor((2, 3, 64, 64), 103)], 303, out, 'IP', full_grads=False)
+    np.savez_compressed(os.path.join(outdir, 'nets.npz'), **out)
+    print('nets.npz: %d arrays' % len(out))
+
+
+STEP_VARIANTS = {
+    'default': [],
+    'noisy_a': ['--noisy', 'true', '--noisy_var_type', 'a'],
+    'bayesian_e': ['--bayesian', 'true', '--bnn_dropout', '0.2', '--noisy_var_type', 'e', '--bnn_T', '3'],
+    'bayesian_noisy_ae': ['--bayesian', 'true', '--noisy', 'true', '--bnn_dropout', '0.2', '--noisy_var_type', 'ae',
+                          '--bnn_T', '3'],
+    'use_real_A': ['--use_real_A'],
+    'lambda_A_GAN': ['--lambda_A_GAN', '0.3', '--lambda_L1', '0.7'],
+    'detach_fake_B': ['--detach_fake_B'],
+    'no_ip_no_z': ['--lambda_IP', '0', '--lambda_z', '0'],
+}
+
+
+def golden_steps(rn, outdir):
+    """Full optimize_parameters() x2 through the reference's own option parser and model class."""
+    from options.train_options import TrainOptions
+    from models import create_model
+    tmp = tempfile.mkdtemp(prefix='pcgan_golden_')
+    for name, extra in STEP_VARIANTS.items():
+        noisy = 'true' in [a for i, a in enumerate(extra) if i > 0 and extra[i - 1] == '--noisy']
+        drop = 0.2 if '--bnn_dropout' in extra else 0.0
+        # fabricated "pretrained" checkpoints with deterministic weights
+        e = rn.SiameseFeature(rn.ResNetFeature(3, 'resnet18', dropout=drop), pooling='avg', cnn_dim=[32, 1], cnn_pad=1,
+                              cnn_relu_slope=0.7, noisy=noisy, drop_layer=rn.get_dropout_layer(drop))
+        e_path = os.path.join(tmp, 'E_%s.pth' % name)
+        torch.save(W.fill_state_dict(e.state_dict(), 30), e_path)
+        ip = rn.AlexNetFeature(input_nc=3, pooling='None')
+        ip_path = os.path.join(tmp, 'IP.pth')
+        torch.save(W.fill_state_dict(ip.state_dict(), 40), ip_path)
+        sys.argv = ['train.py', '--dataroot', tmp, '--model', 'wsgan_emb', '--name', 'g_' + name,
+                    '--checkpoints_dir', tmp, '--gpu_ids', '-1', '--which_model_netG', 'resnet_9blocks',
+                    '--which_model_netD', 'n_layers', '--n_layers_D', '3', '--ngf', '8', '--ndf', '8',
+                    '--fineSize', '32', '--loadSize', '32', '--fineSize_E', '64', '--fineSize_IP', '64',
+                    '--batchSize', '4', '--pretrained_model_path_E', e_path, '--pretrained_model_path_IP', ip_path,
+                    '--display_id', '-1', '--embedding_bins', '[-1.0, 0.0, 1.5]', '--embedding_mean', '0.1',
+                    '--embedding_std', '0.8'] + extra
+        opt = TrainOptions().parse()
+        model = create_model(opt)
+        model.setup(opt)
+        model.netG.load_state_dict(W.fill_state_dict(model.netG.state_dict(), 19))
+        model.netD.load_state_dict(W.fill_state_dict(model.netD.state_dict(), 20))
+        out = {}
+        for it in range(2):
+            A = W.seeded_tensor((4, 3, 32, 32), 500 + it)
+            B = W.seeded_tensor((4, 3, 32, 32), 600 + it)
+            label = torch.tensor([0, 2, 2, 0] if it == 0 else [2, 0, 1, 0], dtype=torch.int64)
+            torch.manual_seed(1234 + it)
+            # capture grads at the moment of each optimizer step
+            grabbed, origs = {}, {}
+            for tag, optim, net in (('G', model.optimizer_G, model.netG), ('D', model.optimizer_D, model.netD)):
+                orig = origs[tag] = optim.step
+
+                def stepper(orig=orig, tag=tag, net=net):
+                    grabbed[tag] = [(k, None if p.grad is None else p.grad.detach().clone())
+                                    for k, p in net.named_parameters()]
+                    return orig()
+                optim.step = stepper
+            model.set_input({'A': A, 'B': B, 'label': label, 'A_paths': ['a'] * 4, 'B_paths': ['b'] * 4})
+            model.optimize_parameters()
+            model.optimizer_G.step, model.optimizer_D.step = origs['G'], origs['D']
+            p = 'it%d' % it
+            losses = model.get_current_losses()
+            out[p + '/losses'] = np.array([losses[k] for k in model.loss_names], dtype=np.float64)
+            for k in ('fake_B', 'rec_A', 'embedding_A', 'embedding_B', 'y_A', 'y_B'):
+                out['%s/%s' % (p, k)] = t2n(getattr(model, k))
+            if hasattr(model, 'resample_B') and opt.noisy_var_type:
+                out[p + '/resample_A'] = t2n(model.resample_A)
+                out[p + '/resample_B'] = t2n(model.resample_B)
+            full = (name == 'default')
+            grads_summary(grabbed['G'], p + '/gradG', out, full)
+            grads_summary(grabbed['D'], p + '/gradD', out, full)
+            for tag, net in (('G', model.netG), ('D', model.netD)):
+                for k, v in net.state_dict().items():
+                    a = t2n(v).astype(np.float64)
+                    out['%s/after%s/%s' % (p, tag, k)] = np.array([a.sum(), np.abs(a).sum()])
+            for k, v in model.netE.state_dict().items():
+                if 'running' in k or 'num_batches' in k:
+                    a = t2n(v).astype(np.float64)
+                    out['%s/afterE/%s' % (p, k)] = np.array([a.sum(), np.abs(a).sum()])
+        out['loss_names'] = np.array(model.loss_names)
+        np.savez_compressed(os.path.join(outdir, 'step_%s.npz' % name), **out)
+        print('step_%s.npz: %d arrays, losses it0 %s' % (name, len(out), out['it0/losses']))
+        if name == 'default':
+            # LR schedule through the reference's scheduler (models/networks.py:57-62)
+            lrs = []
+            for _ in range(opt.niter + opt.niter_decay + 1):
+                lrs.append(model.optimizers[0].param_groups[0]['lr'])
+                for s in model.schedulers:
+                    s.step()
+            np.savez(os.path.join(outdir, 'lr_schedule.npz'), lr=np.array(lrs), niter=opt.niter,
+                     niter_decay=opt.niter_decay, epoch_count=opt.epoch_count, base_lr=opt.lr)
+
+
+def golden_ints(outdir):
+    """Integer-exact helpers."""
+    from util import util as ref_util
+    bins = [1, 21, 41, 61, 81, float('inf')]
+    attrs = [-5, 1, 20.999, 21, 80, 81, 1e9, float('nan'), 40.9999, 61]
+    labels = [ref_util.get_attr_label(a, bins) for a in attrs]
+    short = ref_util.get_attr_label(3.0, [5])
+    strs = ['[]', '[1, 2, 3]', ' [0.5, -1.25] ', '[[1, 2], [3, 4]]']
+    parsed = [repr(ref_util.str2list(s)) for s in strs]
+    bools = ['yes', 'True', 't', 'Y', '1', 'no', 'FALSE', 'f', 'n', '0']
+    np.savez(os.path.join(outdir, 'ints.npz'), bins=np.array(bins), attrs=np.array(attrs),
+             labels=np.array(labels, dtype=np.int64), short_is_none=np.array(short is None),
+             strs=np.array(strs), parsed=np.array(parsed), bools=np.array(bools),
+             bool_vals=np.array([ref_util.str2bool(b) for b in bools]))
+    print('ints.npz labels', labels)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
+    ap.add_argument('--only', default='')
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    rn = import_reference()
+    torch.set_num_threads(4)
+    if a.only in ('', 'nets'):
+        golden_nets(rn, a.out)
+    if a.only in ('', 'ints'):
+        golden_ints(a.out)
+    if a.only in ('', 'steps'):
+        golden_steps(rn, a.out)

@@ -1,0 +1,348 @@
+"""torch.autograd.Function wrappers around the HIP kernels.
+
+Each Function saves exactly what its backward needs and is re-entrant (the generator is
+applied twice per step with the first output feeding the second pass; the discriminator
+sees the same fake image in two different graphs).  Autograd bookkeeping is the only
+thing torch does here -- every forward/backward computation is a libpcgan_hip.so kernel.
+"""
+import torch
+
+from . import ops
+from .lib import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID  # noqa: F401
+
+
+def _c(t):
+    return t if (t is None or t.is_contiguous()) else t.contiguous()
+
+
+# ---------------------------------------------------------------------------- conv
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, pad_mode, act, slope):
+        x, w, b = _c(x), _c(w), _c(b)
+        y = ops.conv2d_fwd(x, w, b, stride, pad, pad_mode, act, slope)
+        ctx.cfg = (stride, pad, pad_mode, act, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, pad_mode, act, slope = ctx.cfg
+        dy = _c(dy)
+        if act != ACT_NONE:
+            dy = ops.act_bwd(dy, y, act, slope)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_bwd_data(dy, w, (x.shape[2], x.shape[3]), stride, pad, pad_mode)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv2d_bwd_weight(x, dy, tuple(w.shape), stride, pad, pad_mode)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.channel_sum(dy)
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE, slope=0.0):
+    """nn.Conv2d (optionally preceded by nn.ReflectionPad2d(pad): pad_mode=1) with the
+    following pointwise activation fused into the epilogue."""
+    return _Conv2dFn.apply(x, w, b, stride, pad, pad_mode, act, slope)
+
+
+class _ConvTranspose2dFn(torch.autograd.Function):
+    """nn.ConvTranspose2d(w[Cin][Cout][R][S]) expressed through the conv entry points of the
+    conv (C=Cout -> K=Cin) whose data-gradient it is."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, out_pad):
+        x, w, b = _c(x), _c(w), _c(b)
+        R, S = w.shape[2], w.shape[3]
+        Ho = (x.shape[2] - 1) * stride - 2 * pad + R + out_pad
+        Wo = (x.shape[3] - 1) * stride - 2 * pad + S + out_pad
+        y = ops.conv2d_bwd_data(x, w, (Ho, Wo), stride, pad, 0, bias=b)
+        ctx.cfg = (stride, pad)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        dy = _c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_fwd(dy, w, None, stride, pad, 0)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv2d_bwd_weight(dy, x, tuple(w.shape), stride, pad, 0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.channel_sum(dy)
+        return dx, dw, db, None, None, None
+
+
+def conv_transpose2d(x, w, b=None, stride=2, pad=1, out_pad=1):
+    return _ConvTranspose2dFn.apply(x, w, b, stride, pad, out_pad)
+
+
+# ---------------------------------------------------------------------------- norms
+class _InstanceNormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, running_mean, running_var, momentum, eps, act, slope, training):
+        x, residual = _c(x), _c(residual)
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        if training or running_mean is None:
+            mean, var = ops.plane_stats(x)          # var holds the plane M2
+            per_plane = True
+            if training and running_mean is not None:
+                ops.in_running_update(mean, var, running_mean, running_var, N, C, HW, momentum)
+        else:
+            mean, var, per_plane = running_mean, running_var, False
+        y = ops.norm_act_fwd(x, mean, var, None, None, residual, per_plane, eps, act, slope)
+        ctx.cfg = (eps, act, slope, per_plane, residual is not None)
+        ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, var = ctx.saved_tensors
+        eps, act, slope, per_plane, has_res = ctx.cfg
+        if not per_plane:
+            raise NotImplementedError('pcgan_amd: backward through eval-mode InstanceNorm is not on the hot path')
+        dy = _c(dy)
+        dx = dres = None
+        want_res = has_res and ctx.needs_input_grad[1]
+        if ctx.needs_input_grad[0]:
+            s1, s2 = ops.norm_bwd_stats(dy, x, y, mean, var, True, eps, act, slope)
+            dx, dres = ops.norm_bwd_apply(dy, x, y, mean, var, None, s1, s2, True, eps, act, slope,
+                                          want_res and act != ACT_NONE)
+        if want_res and dres is None:
+            dres = dy if act == ACT_NONE else ops.act_bwd(dy, y, act, slope)
+        return dx, dres, None, None, None, None, None, None, None
+
+
+def instance_norm_act(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
+                      residual=None, training=True):
+    """act( InstanceNorm2d(affine=False)(x) + residual ), running statistics updated in place."""
+    return _InstanceNormActFn.apply(x, residual, running_mean, running_var, momentum, eps, act, slope, training)
+
+
+class _BatchNormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope, training):
+        x, residual = _c(x), _c(residual)
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        if training:
+            mean_nc, m2_nc = ops.plane_stats(x)
+            mean, var = ops.bn_merge(mean_nc, m2_nc, N, C, HW, running_mean, running_var, momentum)
+        else:
+            mean, var = running_mean, running_var
+        y = ops.norm_act_fwd(x, mean, var, gamma, beta, residual, False, eps, act, slope)
+        ctx.cfg = (eps, act, slope, training, residual is not None)
+        ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, var, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, var, gamma = ctx.saved_tensors
+        eps, act, slope, training, has_res = ctx.cfg
+        if not training:
+            raise NotImplementedError('pcgan_amd: backward through eval-mode BatchNorm is not on the hot path')
+        dy = _c(dy)
+        N, C = x.shape[0], x.shape[1]
+        want_res = has_res and ctx.needs_input_grad[3]
+        s1n, s2n = ops.norm_bwd_stats(dy, x, y, mean, var, False, eps, act, slope)
+        s1, s2 = ops.bn_bwd_reduce(s1n, s2n, N, C)
+        dx = dres = None
+        if ctx.needs_input_grad[0] or (want_res and act != ACT_NONE):
+            dx, dres = ops.norm_bwd_apply(dy, x, y, mean, var, gamma, s1, s2, False, eps, act, slope,
+                                          want_res and act != ACT_NONE)
+        if want_res and dres is None:
+            dres = dy
+        dgamma = s2 if ctx.needs_input_grad[1] else None
+        dbeta = s1 if ctx.needs_input_grad[2] else None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
+                   residual=None, training=True):
+    """act( BatchNorm2d(affine=True)(x) + residual ) with batch statistics in train mode."""
+    return _BatchNormActFn.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope,
+                                 training)
+
+
+# ---------------------------------------------------------------------------- pointwise
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        y = ops.act_fwd(_c(x), act, slope)
+        ctx.cfg = (act, slope)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        act, slope = ctx.cfg
+        return ops.act_bwd(_c(dy), y, act, slope), None, None
+
+
+def activation(x, act, slope=0.0):
+    return x if act == ACT_NONE else _ActFn.apply(x, act, slope)
+
+
+class _ConcatZFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, z):
+        img = _c(img)
+        z2 = _c(z.reshape(z.size(0), z.size(1)))
+        ctx.shapes = (img.shape, z.shape)
+        return ops.concat_z(img, z2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ishape, zshape = ctx.shapes
+        C = ishape[1]
+        dimg = dz = None
+        if ctx.needs_input_grad[0]:
+            dimg = dy[:, :C].contiguous()        # strided device copy (memory plumbing)
+        if ctx.needs_input_grad[1]:
+            dzc = dy[:, C:].contiguous()
+            N, nz = dzc.shape[0], dzc.shape[1]
+            # per-(n, j) plane sums: reuse the channel-sum kernel on a [1][N*nz][HW] view
+            s = ops.channel_sum(dzc.view(1, N * nz, dzc.shape[2], dzc.shape[3]))
+            s = s.view(N, nz)
+            if zshape[0] == 1:
+                s = ops.channel_sum(s.t().contiguous().view(1, nz, N, 1)).view(1, nz)
+            dz = s.reshape(zshape)
+        return dimg, dz
+
+
+def concat_z(img, z):
+    """torch.cat((img, z broadcast over H,W), 1); z is (B or 1, nz, 1, 1)."""
+    return _ConcatZFn.apply(img, z)
+
+
+class _ChannelScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask_nc, scale):
+        ctx.scale = scale
+        ctx.save_for_backward(mask_nc)
+        return ops.channel_scale(_c(x), mask_nc, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask_nc,) = ctx.saved_tensors
+        return ops.channel_scale(_c(dy), mask_nc, ctx.scale), None, None
+
+
+def dropout2d(x, p, training=True, mask=None):
+    """nn.Dropout2d: whole (n,c) planes zeroed with probability p, survivors scaled by 1/(1-p).
+    `mask` (N*C keep flags) can be injected for parity tests; otherwise it is drawn with
+    torch's device RNG (host-side RNG plumbing, cannot match a CPU stream anyway)."""
+    if not training or p <= 0.0:
+        return x
+    N, C = x.shape[0], x.shape[1]
+    if mask is None:
+        mask = torch.empty(N * C, dtype=torch.float32, device=x.device).bernoulli_(1.0 - p)
+    return _ChannelScaleFn.apply(x, mask.reshape(-1).contiguous(), 1.0 / (1.0 - p))
+
+
+# ---------------------------------------------------------------------------- pooling / resize
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        x = _c(x)
+        y, arg = ops.maxpool_fwd(x, k, stride, pad)
+        ctx.cfg = (tuple(x.shape[2:]), k, stride, pad)
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        hw, k, stride, pad = ctx.cfg
+        return ops.maxpool_bwd(_c(dy), arg, hw, k, stride, pad), None, None, None
+
+
+def max_pool2d(x, k, stride, pad=0):
+    return _MaxPoolFn.apply(x, k, stride, pad)
+
+
+class _GlobalPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, is_max):
+        x = _c(x)
+        y, arg = ops.global_pool_fwd(x, is_max)
+        ctx.cfg = (tuple(x.shape[2:]), is_max)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        hw, is_max = ctx.cfg
+        return ops.global_pool_bwd(_c(dy), arg, hw, is_max), None
+
+
+def global_pool(x, is_max):
+    """nn.AvgPool2d(H) / nn.MaxPool2d(H) over the whole plane."""
+    return _GlobalPoolFn.apply(x, bool(is_max))
+
+
+class _BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        x = _c(x)
+        ctx.hw = tuple(x.shape[2:])
+        return ops.bilinear_fwd(x, (size, size))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.bilinear_bwd(_c(dy), ctx.hw), None
+
+
+def upsample2d(x, size):
+    """util.upsample2d (util/util.py:111-117): identity if size <= 0 or already that size."""
+    if size <= 0 or x.size(2) == size:
+        return x
+    return _BilinearFn.apply(x, int(size))
+
+
+# ---------------------------------------------------------------------------- losses
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, a, b):
+        a, b = _c(a), _c(b)
+        want = a.requires_grad
+        if kind == 'bce':
+            loss, grad = ops.bce_loss(a, b, want)
+        elif kind == 'l1':
+            loss, grad = ops.l1_loss(a, b, want)
+        else:
+            loss, grad = ops.mse_loss(a, b, want)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        (grad,) = ctx.saved_tensors
+        if grad is None:
+            return None, None, None
+        # d loss / d a, scaled by the upstream scalar which stays on the device
+        return None, ops.scale(grad, _c(dl).reshape(1)), None
+
+
+def bce_loss(pred, target_n):
+    """nn.BCELoss(mean) of pred[N,...] against a per-sample target (float tensor [N])."""
+    return _LossFn.apply('bce', pred, target_n)
+
+
+def l1_loss(a, b):
+    return _LossFn.apply('l1', a, b)
+
+
+def mse_loss(a, b):
+    return _LossFn.apply('mse', a, b)

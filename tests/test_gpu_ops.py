@@ -232,7 +232,7 @@ def test_bilinear_align_corners(hin, hout, dev):
     y = ops.bilinear_fwd(x.to(dev), (hout, hout))
     assert_close(y, y64, 2e-5, 'bilinear fwd')   # fp32 source-index arithmetic vs fp64 twin
     y32 = torch.nn.functional.interpolate(x, size=(hout, hout), mode='bilinear', align_corners=True)
-    assert_close(y, y32, 2e-6, 'bilinear fwd vs fp32 oracle')
+    assert_close(y, y32, 2e-5, 'bilinear fwd vs fp32 oracle')
     dx = ops.bilinear_bwd(dy.to(dev), (hin, hin))
     assert_close(dx, x64.grad, 5e-5, 'bilinear bwd')
 
