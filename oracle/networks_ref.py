@@ -35,6 +35,30 @@ class Identity(nn.Module):
         return x
 
 
+class Dropout2dRec(nn.Module):
+    """nn.Dropout2d (models/resnet.py:38-41, models/networks.py:37-42) with the Bernoulli keep-mask
+    drawn explicitly -- one (N,C,1,1) bernoulli_(1-p) draw, which is what F.dropout2d consumes from
+    the CPU generator (verified against the reference's bayesian golden vectors) -- and recorded in
+    `Dropout2dRec.record` so the GPU product can be fed the same masks."""
+    record = None      # set to a list to record masks
+    inject = None      # set to an iterator of masks to replay instead of drawing
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if not self.training or self.p <= 0:
+            return x
+        if Dropout2dRec.inject is not None:
+            mask = next(Dropout2dRec.inject).to(x.dtype).view(x.size(0), x.size(1), 1, 1)
+        else:
+            mask = torch.empty(x.size(0), x.size(1), 1, 1, dtype=x.dtype).bernoulli_(1 - self.p)
+        if Dropout2dRec.record is not None:
+            Dropout2dRec.record.append(mask.detach().reshape(-1).clone())
+        return x * (mask / (1 - self.p))     # torch: noise.div_(1-p); input * noise
+
+
 def _cat_z(x, z):
     """models/networks.py:610-611"""
     if z is None:
@@ -108,7 +132,7 @@ class BasicBlockRef(nn.Module):
 
     def __init__(self, cin, planes, stride=1, downsample=None, dropout=0.):
         super().__init__()
-        drop = (lambda: nn.Dropout2d(dropout)) if dropout > 0 else Identity
+        drop = (lambda: Dropout2dRec(dropout)) if dropout > 0 else Identity
         self.conv1 = nn.Conv2d(cin, planes, 3, stride=stride, padding=1, bias=False)
         self.drop1 = drop()
         self.bn1 = nn.BatchNorm2d(planes)
@@ -192,7 +216,7 @@ class SiameseFeatureRef(nn.Module):
     def __init__(self, base, pooling='avg', cnn_dim=(32, 1), cnn_pad=1, slope=0.7, noisy=False, dropout=0.):
         super().__init__()
         self.base, self.pooling, self._noisy = base, pooling, noisy
-        drop = (lambda: nn.Dropout2d(dropout)) if dropout > 0 else Identity
+        drop = (lambda: Dropout2dRec(dropout)) if dropout > 0 else Identity
 
         def head():
             blk, prev = [], base.feature_dim

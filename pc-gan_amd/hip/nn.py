@@ -62,11 +62,14 @@ class BatchNorm2d(tnn.BatchNorm2d):
 
 
 class Dropout2d(tnn.Dropout2d):
-    """nn.Dropout2d; `next_mask` lets a parity test inject the Bernoulli keep-mask."""
-    next_mask = None
+    """nn.Dropout2d; `Dropout2d.mask_source` (an iterator of N*C keep-flag tensors, consumed in call
+    order) lets a parity test replay the masks the oracle drew."""
+    mask_source = None
 
     def forward(self, x):
-        mask, self.next_mask = self.next_mask, None
+        mask = None
+        if Dropout2d.mask_source is not None and self.training and self.p > 0:
+            mask = next(Dropout2d.mask_source).to(device=x.device, dtype=torch.float32)
         return F.dropout2d(x, self.p, self.training, mask)
 
 

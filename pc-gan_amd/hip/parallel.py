@@ -1,0 +1,92 @@
+"""Data parallelism: one process per GPU, full replicas, ONE gradient all-reduce (average)
+per optimizer per step over RCCL/xGMI (torch.distributed backend "nccl" on ROCm).
+
+Mathematically this is the reference's nn.DataParallel (models/networks.py:96-102) when rank r
+takes the contiguous slice [r*B/n, (r+1)*B/n) of the global batch: losses are means over the
+batch, so the global gradient is the average of the per-rank gradients; BatchNorm/InstanceNorm
+statistics stay per replica exactly as under DataParallel.
+
+Payload: G 11,381,315 x 4 B = 45.5 MB, D 11.1 MB per step.  xGMI is point-to-point, so one
+large flat all-reduce per optimizer (not per-tensor buckets) keeps the per-link ring cost at
+~0.5 ms against a ~70 ms compute step.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), \
+        int(os.environ.get('LOCAL_RANK', '0'))
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the torchrun environment; no-op for a single process."""
+    world, rank, local = env_world()
+    if world <= 1:
+        return world, rank, local
+    if not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_batch(t, rank=None, world=None):
+    """Contiguous slice of the global batch for this rank (DataParallel's scatter along dim 0)."""
+    if world is None:
+        world, rank = (dist.get_world_size(), dist.get_rank()) if is_distributed() else (1, 0)
+    n = t.shape[0] if hasattr(t, 'shape') else len(t)
+    assert n % world == 0, 'global batch %d not divisible by world size %d' % (n, world)
+    per = n // world
+    return t[rank * per:(rank + 1) * per]
+
+
+def allreduce_mean_(flat):
+    """In-place average of a flat gradient buffer over all ranks."""
+    if not is_distributed():
+        return flat
+    world = dist.get_world_size()
+    if flat.is_cuda:
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)      # RCCL computes the average in the ring
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)      # gloo (CPU tests): no AVG
+        flat.mul_(1.0 / world)
+    return flat
+
+
+def sync_gradients(optimizer):
+    """Average the optimizer's gradients across ranks: one collective when it is a FusedAdam
+    (flat buffer), otherwise one flattened collective over its parameter grads."""
+    if not is_distributed():
+        return
+    gflat = getattr(optimizer, 'gflat', None)
+    if gflat is not None:
+        allreduce_mean_(gflat)
+        return
+    grads = [p.grad for g in optimizer.param_groups for p in g['params'] if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    allreduce_mean_(flat)
+    o = 0
+    for g in grads:
+        g.copy_(flat[o:o + g.numel()].view_as(g))
+        o += g.numel()
+
+
+def broadcast_parameters(net, src=0):
+    """Make every replica start from rank `src`'s weights and buffers."""
+    if not is_distributed():
+        return
+    for t in list(net.parameters()) + list(net.buffers()):
+        dist.broadcast(t.data, src)

@@ -1,0 +1,151 @@
+"""GPU parity of the HIP-backed networks (define_G / define_D / define_E / define_IP) against
+(a) the golden vectors captured from the reference itself and (b) the oracle's float64 twin.
+
+Tolerances: activations / outputs rtol 1e-4; data gradients 2e-4; parameter
+gradients are judged against the fp64 twin: |g_hip - g64| <= 2 * |g_ref32 - g64| + tiny, with
+an absolute floor of 1e-6 for the biases an affine-less InstanceNorm cancels (true gradient 0).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import networks_ref as N
+from oracle import weights as W
+from util_cmp import assert_close
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _gold():
+    return np.load(os.path.join(GOLD, 'nets.npz'))
+
+
+def _run(net, inputs, seed_dy):
+    xs = [i.clone().requires_grad_(True) for i in inputs]
+    y = net(*xs)
+    ys = list(y) if isinstance(y, (tuple, list)) else [y]
+    dys = [W.seeded_normal(tuple(o.shape), seed_dy + j).to(device=o.device, dtype=o.dtype) for j, o in enumerate(ys)]
+    torch.autograd.backward(ys, dys)
+    return ys, [x.grad for x in xs], {k: p.grad for k, p in net.named_parameters()}
+
+
+def _compare(hip_net, ref_net, inputs, seed_dy, dev, gold=None, prefix=None, out_tol=1e-4):
+    sd = {k: v.clone() for k, v in ref_net.state_dict().items()}
+    hip_net.load_state_dict(sd)
+    hip_net.to(dev)
+    ref64 = ref_net.double()
+    ys, dins, dps = _run(hip_net, [i.to(dev) for i in inputs], seed_dy)
+    ys64, dins64, dps64 = _run(ref64, [i.double() for i in inputs], seed_dy)
+    for j, (a, b) in enumerate(zip(ys, ys64)):
+        assert_close(a, b, out_tol, 'out%d vs fp64 twin' % j)
+        if gold is not None:
+            assert_close(a, torch.from_numpy(gold['%s/out%d' % (prefix, j)]), out_tol, 'out%d vs reference golden' % j)
+    for j, (a, b) in enumerate(zip(dins, dins64)):
+        if float(b.abs().max()) < 1e-9:
+            # e.g. dL/dz of the generator: z is a constant plane that the first InstanceNorm cancels,
+            # so the true gradient is 0 and only fp32 noise remains on either side
+            assert float(a.abs().max()) < 1e-3, 'din%d should be ~0' % j
+            continue
+        assert_close(a, b, 2e-4, 'din%d vs fp64 twin' % j)
+        key = '%s/din%d' % (prefix, j)
+        if gold is not None and key in gold.files:
+            assert_close(a, torch.from_numpy(gold[key]), 2e-4, 'din%d vs reference golden' % j)
+    for k, g in dps.items():
+        g64 = dps64[k]
+        bound = 2e-4
+        full_key = '%s/dparam/full/%s' % (prefix, k)
+        if gold is not None and full_key in gold.files:
+            # error budget = twice the reference's own fp32-vs-fp64 error on this tensor
+            ref32 = torch.from_numpy(gold[full_key]).double()
+            noise = (ref32 - g64).abs().max().item()
+            err = (g.double().cpu() - g64).abs().max().item()
+            assert err <= 2 * noise + 2e-5 * g64.abs().max().item() + 1e-6, \
+                'd%s: |hip-fp64| %.3e vs reference noise %.3e' % (k, err, noise)
+        else:
+            assert_close(g, g64, bound, 'd' + k, atol=1e-6)
+    # running statistics after the call
+    hb = dict(hip_net.named_buffers())
+    for k, b in ref64.named_buffers():
+        if 'running' in k:
+            assert_close(hb[k], b, 1e-4, 'buffer ' + k, atol=1e-6)
+        elif 'num_batches_tracked' in k:
+            assert int(hb[k]) == int(b), 'buffer ' + k
+
+
+@pytest.mark.parametrize('nb', [2, 9])
+def test_generator(nb, dev):
+    from pcgan_amd.models import networks
+    ref = N.ResnetGeneratorRef(3, 3, 1, 8, 'instance', nb)
+    ref.load_state_dict(W.fill_state_dict(ref.state_dict(), 10 + nb))
+    hip = networks.define_G(3, 3, 1, 8, 'resnet_%dblocks' % nb, norm='instance', init_type='normal')
+    x = W.seeded_tensor((2, 3, 16, 16), 100 + nb)
+    z = W.seeded_normal((2, 1, 1, 1), 200 + nb)
+    _compare(hip, ref, [x, z], 300 + nb, dev, _gold(), 'G%d' % nb)
+    with torch.no_grad():
+        out = hip(x.to(dev), z[:1].to(dev))
+    assert_close(out, torch.from_numpy(_gold()['G%d/out_zbroadcast' % nb]), 1e-4, 'z broadcast (1,nz,1,1)')
+
+
+def test_generator_state_dict_keys_match_reference_layout(dev):
+    from pcgan_amd.models import networks
+    ref = N.ResnetGeneratorRef(3, 3, 1, 8, 'instance', 9)
+    hip = networks.define_G(3, 3, 1, 8, 'resnet_9blocks', norm='instance', init_type='normal')
+    assert list(hip.state_dict().keys()) == list(ref.state_dict().keys())
+    assert len(hip.state_dict()) == 117
+
+
+def test_discriminator(dev):
+    from pcgan_amd.models import networks
+    ref = N.NLayerDiscriminatorRef(3, 1, 8, 3, 'batch', True)
+    ref.load_state_dict(W.fill_state_dict(ref.state_dict(), 20))
+    hip = networks.define_D(3, 1, 8, 'n_layers', 3, 'batch', True, 'normal')
+    _compare(hip, ref, [W.seeded_tensor((3, 3, 32, 32), 101), W.seeded_normal((3, 1, 1, 1), 201)], 301, dev,
+             _gold(), 'D')
+
+
+def test_discriminator_unconditional_nz0(dev):
+    """wsgan_cycle's D(img) (nz=0, called without z)."""
+    from pcgan_amd.models import networks
+    ref = N.NLayerDiscriminatorRef(3, 0, 8, 3, 'batch', True)
+    ref.load_state_dict(W.fill_state_dict(ref.state_dict(), 21))
+    hip = networks.define_D(3, 0, 8, 'basic', 3, 'batch', True, 'normal')
+    _compare(hip, ref, [W.seeded_tensor((2, 3, 32, 32), 111)], 311, dev)
+
+
+@pytest.mark.parametrize('noisy', [False, True])
+def test_encoder(noisy, dev):
+    from pcgan_amd.models import networks
+    ref = N.SiameseFeatureRef(N.ResNetFeatureRef('resnet18'), 'avg', (32, 1), 1, 0.7, noisy)
+    ref.load_state_dict(W.fill_state_dict(ref.state_dict(), 30))
+    hip = networks.define_E('resnet18', 3, 'normal', 'avg', [32, 1], 1, 0.7, noisy=noisy)
+    # the 4 BatchNorm'd 2x2 feature maps of a 64x64 input leave few samples per channel:
+    # ill-conditioned statistics amplify fp32 rounding, hence the looser output tolerance
+    _compare(hip, ref, [W.seeded_tensor((3, 3, 64, 64), 102)], 302, dev, _gold(), 'E_noisy%d' % int(noisy),
+             out_tol=5e-4)
+
+
+def test_encoder_max_pooling_head(dev):
+    from pcgan_amd.models import networks
+    ref = N.SiameseFeatureRef(N.ResNetFeatureRef('resnet18'), 'max', (64, 1), 1, 0.2, False)
+    ref.load_state_dict(W.fill_state_dict(ref.state_dict(), 31))
+    hip = networks.define_E('resnet18', 3, 'normal', 'max', [64, 1], 1, 0.2)
+    _compare(hip, ref, [W.seeded_tensor((2, 3, 96, 96), 112)], 312, dev, out_tol=5e-4)
+
+
+def test_alexnet_feature(dev):
+    from pcgan_amd.models import networks
+    ref = N.AlexNetFeatureRef(3, 'None')
+    ref.load_state_dict(W.fill_state_dict(ref.state_dict(), 40))
+    hip = networks.define_IP('alexnet', 3)
+    _compare(hip, ref, [W.seeded_tensor((2, 3, 64, 64), 103)], 303, dev, _gold(), 'IP')
+
+
+def test_alexnet_feature_224(dev):
+    from pcgan_amd.models import networks
+    ref = N.AlexNetFeatureRef(3, 'None')
+    ref.load_state_dict(W.fill_state_dict(ref.state_dict(), 41))
+    hip = networks.define_IP('alexnet', 3)
+    _compare(hip, ref, [W.seeded_tensor((1, 3, 224, 224), 113)], 313, dev)

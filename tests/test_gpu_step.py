@@ -1,0 +1,241 @@
+"""GPU parity of the full training step: WSGANEmbModel.optimize_parameters() on the HIP path,
+driven through the unchanged option parser, against
+
+  (a) the golden vectors the REFERENCE's own optimize_parameters() produced (tests/golden/step_*.npz),
+  (b) the oracle step (oracle/step_ref.py) run side by side on the CPU with the same random draws.
+
+Tolerances: losses 1e-4 (abs/rel); images rtol 2e-4; gradients per tensor relative L2 error
+<= 5e-3 (the reference's own fp32-vs-fp64 error on G weight gradients is 3.5e-3),
+noise-level tensors (IN-cancelled biases) by absolute floor 1e-6.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import networks_ref as N
+from oracle import weights as W
+from oracle.make_golden import STEP_VARIANTS
+from test_oracle_golden import build_oracle_step, step_inputs
+from util_cmp import assert_close
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def build_hip_model(variant, tmp_path, extra_args=()):
+    from pcgan_amd.options.train_options import TrainOptions
+    from pcgan_amd.models import create_model
+    extra = STEP_VARIANTS[variant]
+    noisy = 'noisy' in ' '.join(extra) and '--noisy' in extra and extra[extra.index('--noisy') + 1] == 'true'
+    drop = 0.2 if '--bnn_dropout' in extra else 0.0
+    e = N.SiameseFeatureRef(N.ResNetFeatureRef('resnet18', drop), 'avg', (32, 1), 1, 0.7, noisy, drop)
+    e_path = str(tmp_path / ('E_%s.pth' % variant))
+    torch.save(W.fill_state_dict(e.state_dict(), 30), e_path)
+    ip = N.AlexNetFeatureRef(3, 'None')
+    ip_path = str(tmp_path / 'IP.pth')
+    torch.save(W.fill_state_dict(ip.state_dict(), 40), ip_path)
+    argv = ['train.py', '--dataroot', 'synthetic', '--model', 'wsgan_emb', '--name', 'g_' + variant,
+            '--checkpoints_dir', str(tmp_path), '--gpu_ids', '0', '--which_model_netG', 'resnet_9blocks',
+            '--which_model_netD', 'n_layers', '--n_layers_D', '3', '--ngf', '8', '--ndf', '8',
+            '--fineSize', '32', '--loadSize', '32', '--fineSize_E', '64', '--fineSize_IP', '64',
+            '--batchSize', '4', '--pretrained_model_path_E', e_path, '--pretrained_model_path_IP', ip_path,
+            '--display_id', '-1', '--embedding_bins', '[-1.0, 0.0, 1.5]', '--embedding_mean', '0.1',
+            '--embedding_std', '0.8'] + list(extra) + list(extra_args)
+    old = sys.argv
+    sys.argv = argv
+    try:
+        opt = TrainOptions().parse()
+    finally:
+        sys.argv = old
+    model = create_model(opt)
+    model.setup(opt)
+    model.netG.load_state_dict(W.fill_state_dict(model.netG.state_dict(), 19))
+    model.netD.load_state_dict(W.fill_state_dict(model.netD.state_dict(), 20))
+    return model, opt
+
+
+def _grab_grads(model):
+    """record G / D gradients at the moment of their optimizer step"""
+    grabbed = {}
+    for tag, optim, net in (('G', model.optimizer_G, model.netG), ('D', model.optimizer_D, model.netD)):
+        orig = optim.step
+
+        def stepper(orig=orig, tag=tag, net=net):
+            grabbed[tag] = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+            return orig()
+        optim.step = stepper
+    return grabbed
+
+
+def _rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize('variant', ['default', 'use_real_A', 'lambda_A_GAN', 'detach_fake_B', 'no_ip_no_z',
+                                     'noisy_a', 'bayesian_e', 'bayesian_noisy_ae'])
+def test_step_matches_reference_and_oracle(variant, tmp_path, dev):
+    from pcgan_amd.hip import nn as hnn
+    from pcgan_amd.util import util as hutil
+    gold = np.load(os.path.join(GOLD, 'step_%s.npz' % variant))
+    names = list(gold['loss_names'])
+    model, opt = build_hip_model(variant, tmp_path)
+    oracle = build_oracle_step(variant)
+    # float64 twin of the oracle: same weights, same random draws; the judge for gradients
+    twin = build_oracle_step(variant)
+    for net in (twin.netG, twin.netD, twin.netE, twin.netIP):
+        net.double()
+    grabbed = _grab_grads(model)
+    for it in range(2):
+        A, B, label = step_inputs(it)
+        oracle_prev = {'G': {k: v.detach().clone() for k, v in oracle.netG.named_parameters()},
+                       'D': {k: v.detach().clone() for k, v in oracle.netD.named_parameters()}}
+        # 1. oracle on CPU under the reference's seed; record every random draw
+        N.Dropout2dRec.record = []
+        oracle.draws = []
+        torch.manual_seed(1234 + it)
+        oracle.set_input(A, B, label)
+        oracle.optimize_parameters()
+        masks, N.Dropout2dRec.record = N.Dropout2dRec.record, None
+        # 1b. the fp64 twin replays the same draws from the same weights
+        with torch.no_grad():
+            for tnet, onet in ((twin.netG, oracle_prev['G']), (twin.netD, oracle_prev['D'])):
+                for k, tp in tnet.named_parameters():
+                    tp.copy_(onet[k].double())
+        N.Dropout2dRec.inject = iter(masks) if masks else None
+        twin.inject = iter(oracle.draws) if oracle.draws else None
+        try:
+            twin.set_input(A.double(), B.double(), label)
+            twin.optimize_parameters()
+        finally:
+            N.Dropout2dRec.inject = None
+        # 2. HIP model on the GPU, replaying the same draws
+        hnn.Dropout2d.mask_source = iter(masks) if masks else None
+        hutil.inject_noise(iter(oracle.draws) if oracle.draws else None)
+        try:
+            model.set_input({'A': A, 'B': B, 'label': torch.tensor(label), 'A_paths': ['a'] * 4, 'B_paths': ['b'] * 4})
+            model.optimize_parameters()
+        finally:
+            hnn.Dropout2d.mask_source = None
+            hutil.inject_noise(None)
+        p = 'it%d' % it
+        got = model.get_current_losses()
+        ol = oracle.losses()
+        # Iteration 0 starts from bit-identical weights everywhere, so the HIP result is held against the
+        # REFERENCE's golden vectors at full tolerance.  From iteration 1 on the reference's trajectory (golden,
+        # produced in the build container) and the oracle's trajectory on THIS host's cores have already parted
+        # by O(lr): Adam turns the sign of noise-level gradients into +-lr parameter moves.  There the tight
+        # comparison is against the oracle run side by side (identical weights, re-aligned below) and the
+        # golden vectors are only a loose sanity band.
+        g_tol = 1.0 if it == 0 else 50.0
+        hetero = bool(opt.noisy_var_type)      # z_rec divides by an MC/aleatoric variance: ill-conditioned
+        for i, n in enumerate(names):
+            ref = float(gold[p + '/losses'][i])
+            lt = (2e-3 if (hetero and n == 'z_rec') else 1e-4)
+            assert abs(got[n] - ref) <= g_tol * lt * max(1.0, abs(ref)), '%s it%d loss %s: hip %r vs reference %r' % (
+                variant, it, n, got[n], ref)
+            assert abs(got[n] - ol[n]) <= lt * max(1.0, abs(ol[n])), '%s it%d loss %s: hip %r vs oracle %r' % (
+                variant, it, n, got[n], ol[n])
+        for k in ('fake_B', 'rec_A', 'embedding_A', 'embedding_B', 'y_A', 'y_B'):
+            assert_close(getattr(model, k), getattr(oracle, k), 2e-4, '%s it%d %s vs oracle' % (variant, it, k))
+            if it == 0:
+                assert_close(getattr(model, k), torch.from_numpy(gold['%s/%s' % (p, k)]), 2e-4,
+                             '%s it%d %s vs reference golden' % (variant, it, k))
+        for tag, ograds in (('G', oracle.grads_G), ('D', oracle.grads_D)):
+            for k, og in ograds.items():
+                if og is None:
+                    continue
+                hg = grabbed[tag][k]
+                if tag == 'G' and k.endswith('.bias') and k != 'model.26.bias':
+                    # bias in front of an affine-less InstanceNorm: true gradient 0, fp32 noise only;
+                    # bound the noise relative to the weight gradient of the same layer
+                    wmax = float(ograds[k[:-4] + 'weight'].abs().max())
+                    assert float(hg.abs().max()) <= 1e-3 * wmax + 1e-6, '%s grad%s %s should be ~0' % (variant, tag, k)
+                    continue
+                if tag == 'G' and k == 'model.1.weight':
+                    # the rating channel z is a constant plane: its filter slice has a true gradient of 0
+                    # (the following InstanceNorm cancels it) -- noise only, bounded like the biases
+                    nz = opt.embedding_nc
+                    assert float(hg[:, -nz:].abs().max()) <= 1e-3 * float(og.abs().max()) + 1e-6
+                    hg, og = hg[:, :-nz], og[:, :-nz]
+                # judged against the fp64 twin: the HIP error may be at most twice the fp32 oracle's own
+                g64 = (twin.grads_G if tag == 'G' else twin.grads_D)[k]
+                if tag == 'G' and k == 'model.1.weight':
+                    g64 = g64[:, :-opt.embedding_nc]
+                e_hip, e_ref = _rel_l2(hg, g64), _rel_l2(og, g64)
+                # Slack on top of the oracle's own error.  With the z_rec / IP terms switched off the whole
+                # G+D path is smooth and the HIP gradients sit within 1e-5 of the fp64 twin (2e-4 allowed).
+                # With them on, the gradient passes through the encoder's ReLU masks and max-pool argmax on an
+                # input (the tanh-saturated fake image) full of exact ties: it is a DISCONTINUOUS function of
+                # that input, and the 1e-5-level difference between the HIP and CPU fake images flips a few of
+                # those decisions (measured: E alone on identical inputs agrees to 1e-5, scripts/diag_E2.py;
+                # same nets fed each side's own fake image differ by 1.2e-3 at iteration 0 and 1.9e-2 at
+                # iteration 1).  The tight statements are therefore: this test's `no_ip_no_z` variant (whole
+                # G+D step, both iterations, 2e-4) and tests/test_gpu_nets.py (E and IP alone, identical inputs).
+                slack = 2e-4 if variant == 'no_ip_no_z' else (5e-3 if it == 0 else 5e-2)
+                assert e_hip <= 2 * e_ref + slack, '%s it%d grad%s %s: rel-L2 vs fp64 twin hip %.3e, fp32 oracle %.3e' % (
+                    variant, it, tag, k, e_hip, e_ref)
+                e = _rel_l2(hg, og)
+                assert e <= 5e-2, '%s it%d grad%s %s rel-L2 %.3e' % (variant, it, tag, k, e)
+                if it == 0 and not (tag == 'G' and k == 'model.1.weight'):
+                    st = gold['%s/grad%s/stat/%s' % (p, tag, k)]
+                    l2 = float(hg.double().norm())
+                    assert abs(l2 - st[2]) <= 5e-3 * st[2] + 1e-6, '%s grad%s %s l2 vs reference golden' % (variant, tag, k)
+        # parameters after the fused Adam step vs the oracle's torch.optim.Adam: the first steps move
+        # every weight by ~lr regardless of |g| (Adam normalises), so noise-level gradients give
+        # sign-dependent +-lr moves (SURVEY.md 7 "noise-dominated gradients"); compare weights only.
+        for tag, hnet, onet in (('G', model.netG, oracle.netG), ('D', model.netD, oracle.netD)):
+            osd = onet.state_dict()
+            for k, v in hnet.state_dict().items():
+                if k.endswith('num_batches_tracked'):
+                    assert int(v) == int(osd[k]), k
+                elif 'running' in k:
+                    assert_close(v, osd[k], 5e-4, '%s %s after step' % (tag, k), atol=1e-6)
+                elif v.dim() > 1:
+                    assert float((v.cpu() - osd[k]).abs().max()) <= 2.5 * opt.lr * (it + 1), '%s %s after step' % (tag, k)
+        esd = oracle.netE.state_dict()
+        for k, v in model.netE.state_dict().items():
+            if 'running' in k:
+                assert_close(v, esd[k], 1e-3, 'E %s after step' % k, atol=1e-5)
+        # Adam turns noise-level gradients into +-lr moves, so the two trajectories drift apart by
+        # O(lr) per step by construction ("post-Adam parameters compared only by feeding
+        # identical grads to both Adams" -- done in test_gpu_ops.test_adam_matches_torch).  Re-align the
+        # PARAMETERS (not the running statistics) before the next iteration so that iteration 1 again
+        # tests forward/backward/losses on identical weights.
+        with torch.no_grad():
+            for hnet, onet in ((model.netG, oracle.netG), (model.netD, oracle.netD)):
+                op = dict(onet.named_parameters())
+                for k, hp in hnet.named_parameters():
+                    hp.copy_(op[k])
+
+
+def test_checkpoint_roundtrip_and_lr_schedule(tmp_path, dev):
+    model, opt = build_hip_model('default', tmp_path, ['--niter', '3', '--niter_decay', '3'])
+    A, B, label = step_inputs(0)
+    model.set_input({'A': A, 'B': B, 'label': torch.tensor(label), 'A_paths': ['a'] * 4, 'B_paths': ['b'] * 4})
+    model.optimize_parameters()
+    model.save_networks('latest')
+    for n in 'GDE':
+        path = os.path.join(model.save_dir, 'latest_net_%s.pth' % n)
+        sd = torch.load(path, map_location='cpu')
+        live = getattr(model, 'net' + n).state_dict()
+        assert list(sd.keys()) == list(live.keys())
+        for k in sd:
+            assert torch.equal(sd[k], live[k].cpu()), k
+    # parameters are still views of the fused optimizer's flat buffer after saving
+    w = model.netG.model[1].weight
+    assert model.optimizer_G.flat.data_ptr() <= w.data_ptr() < model.optimizer_G.flat.data_ptr() + model.optimizer_G.flat.numel() * 4
+    model.load_networks('latest')
+    lrs = []
+    for _ in range(6):
+        lrs.append(model.optimizers[0].param_groups[0]['lr'])
+        model.update_learning_rate()
+    from oracle.step_ref import lambda_lr
+    for e, lr in enumerate(lrs):
+        assert abs(lr - opt.lr * lambda_lr(e, opt.epoch_count, opt.niter, opt.niter_decay)) < 1e-12
+    # one more step after the LR changed: the device-side lr follows
+    model.optimize_parameters()
+    assert abs(float(model.optimizer_G.lr_dev) - model.optimizer_G.param_groups[0]['lr']) < 1e-10
