@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of one full wsgan_emb optimize_parameters() (G+D adversarial step incl.
+the Elo-encoder and AlexNet identity terms) on synthetic 128x128 batches.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 9-block ResnetGenerator + 3-layer PatchGAN (BatchNorm, sigmoid)
++ ResNet-18 Elo encoder @224 + AlexNet IP @224, default loss weights, fp32, batch 32 PER GPU
+(weak scaling: global batch = 32 x N), synthetic U[-1,1) images, labels in {0,2}, seeded-random
+"pretrained" E/IP weights (no checkpoints ship offline).
+
+One JSON line on rank 0: value = whole-job images/s; `roofline` = the dominant kernel (the 256->256
+3x3 residual convolution, implicit GEMM on fp32 MFMA) timed with HIP events on the launch stream;
+`cpu_baseline` = the oracle's PyTorch-CPU step on this host's cores, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMG_FULL = 183.95      # 2 G + 4 D + 3 E + 2 IP fwd and all backward terms @128^2
+FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PER_GPU_BATCH = 32
+SIZE = 128
+
+
+def build_model(device_index, batch, size, tmpdir, seed=0, ngf=64, ndf=64, fine_e=224, n_blocks=9):
+    from pcgan_amd.options.train_options import TrainOptions
+    from pcgan_amd.models import create_model, networks
+    torch.manual_seed(seed)
+    # seeded-random stand-ins for the pretrained Elo encoder / AlexNet (none available offline)
+    e = networks.define_E('resnet18', 3, 'normal', 'avg', [32, 1], 1, 0.7)
+    ip = networks.define_IP('alexnet', 3)
+    e_path, ip_path = os.path.join(tmpdir, 'E.pth'), os.path.join(tmpdir, 'IP.pth')
+    torch.save(e.state_dict(), e_path)
+    torch.save(ip.state_dict(), ip_path)
+    argv = ['bench.py', '--dataroot', 'synthetic', '--model', 'wsgan_emb', '--name', 'bench',
+            '--checkpoints_dir', tmpdir, '--gpu_ids', str(device_index),
+            '--which_model_netG', 'resnet_%dblocks' % n_blocks, '--which_model_netD', 'n_layers', '--n_layers_D', '3',
+            '--ngf', str(ngf), '--ndf', str(ndf), '--fineSize', str(size), '--loadSize', str(size),
+            '--fineSize_E', str(fine_e), '--fineSize_IP', str(fine_e), '--batchSize', str(batch),
+            '--pretrained_model_path_E', e_path, '--pretrained_model_path_IP', ip_path, '--display_id', '-1']
+    old, sys.argv = sys.argv, argv
+    stdout, sys.stdout = sys.stdout, open(os.devnull, 'w')
+    try:
+        opt = TrainOptions().parse()
+        model = create_model(opt)
+        model.setup(opt)
+    finally:
+        sys.stdout.close()
+        sys.argv, sys.stdout = old, stdout
+    return model, opt
+
+
+def synthetic_batch(batch, size, rank, it=0):
+    g = torch.Generator().manual_seed(1234 + rank + 1000 * it)
+    A = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+    B = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+    label = torch.randint(0, 2, (batch,), generator=g) * 2
+    return {'A': A, 'B': B, 'label': label, 'A_paths': [''] * batch, 'B_paths': [''] * batch}
+
+
+def time_resblock_conv(device, n=PER_GPU_BATCH, iters=30):
+    """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of the
+    dominant kernel: 256->256 3x3 reflect-padded conv on (n,256,32,32)."""
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(n, 256, 32, 32, generator=g) * 2 - 1).to(device)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(device)
+    b = torch.zeros(256, device=device)
+    for _ in range(5):
+        ops.conv2d_fwd(x, w, b, 1, 1, 1)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        ops.conv2d_fwd(x, w, b, 1, 1, 1)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    flop = 2.0 * n * 32 * 32 * 256 * 256 * 9
+    return ms, flop
+
+
+def cpu_baseline(steps=2, batch=8):
+    """The oracle's CPU step (reference-equivalent PyTorch-CPU path) on a bounded sample."""
+    from oracle import networks_ref as N
+    from oracle import step_ref as S
+    from oracle import weights as W
+    threads = torch.get_num_threads()
+    G = N.ResnetGeneratorRef(3, 3, 1, 64, 'instance', 9)
+    D = N.NLayerDiscriminatorRef(3, 1, 64, 3, 'batch', True)
+    E = N.SiameseFeatureRef(N.ResNetFeatureRef('resnet18'), 'avg', (32, 1), 1, 0.7, False)
+    IP = N.AlexNetFeatureRef(3, 'None')
+    for i, net in enumerate((G, D, E, IP)):
+        net.load_state_dict(W.fill_state_dict(net.state_dict(), 50 + i))
+    m = S.WSGANEmbStepRef(G, D, E, IP)
+    b = synthetic_batch(batch, SIZE, 0)
+    m.set_input(b['A'], b['B'], [int(v) for v in b['label']])
+    m.optimize_parameters()                    # warm-up (oneDNN primitive creation)
+    t0 = time.time()
+    for _ in range(steps):
+        m.optimize_parameters()
+    dt = (time.time() - t0) / steps
+    return {'value': batch / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': '%d timed steps (1 warm-up) of the oracle CPU step, batch %d, 128x128, same nets/flags' % (
+                steps, batch)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from pcgan_amd.hip import parallel
+    world, rank, local = parallel.init_process_group()
+    assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    tmpdir = tempfile.mkdtemp(prefix='pcgan_bench_')
+    model, opt = build_model(local, PER_GPU_BATCH, SIZE, tmpdir)
+    batches = [synthetic_batch(PER_GPU_BATCH, SIZE, rank, it) for it in range(2)]
+    # inputs resident in HBM before the timed region (set_input's .to(device) is then a no-op copy)
+    batches = [{k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in b.items()} for b in batches]
+
+    def step(i):
+        model.set_input(batches[i % 2])
+        model.optimize_parameters()
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.get_current_losses()
+    assert all(v == v and abs(v) < 1e6 for v in losses.values()), 'non-finite loss: %r' % losses
+
+    conv_ms, conv_flop = time_resblock_conv(device)
+    if rank != 0:
+        return
+    ms_per_step = dt / args.steps * 1e3
+    value = PER_GPU_BATCH * world * args.steps / dt
+    achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+    out = {
+        'metric': 'images/sec (G+D step) 128x128 bs32 per GPU', 'value': round(value, 3), 'unit': 'images/sec',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'wsgan_emb UTKFace-shaped 128x128 bs32/GPU fp32: 9-block ResnetGenerator + 3-layer '
+                               'PatchGAN + ResNet-18 Elo encoder@224 + AlexNet IP@224, full optimize_parameters()',
+                   'global_batch': PER_GPU_BATCH * world, 'parallelism': 'dp%d' % world},
+        'step_flop_fraction': round(GFLOP_PER_IMG_FULL * 1e9 * value / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4),
+        'roofline': {'bound': 'mfma', 'kernel': 'igemm_kernel<FWD_REFLECT,128> 256->256 3x3 @32x32 (+ weight repack)',
+                     'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'ms_per_launch': round(conv_ms, 4),
+                     'flop_per_launch': conv_flop, 'traffic': None},
+        'losses': {k: round(v, 5) for k, v in losses.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -73,6 +73,13 @@ def load():
         raise RuntimeError(
             'pcgan_amd: %s not found -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(or `make -C pc-gan_amd/csrc`). There is no fallback path.' % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64; the kernels must run in THAT runtime instance (same
+    # device context, streams and allocations), so make sure it is the one already mapped before our
+    # library's DT_NEEDED entry for libamdhip64.so.7 is resolved.
+    import torch
+    bundled = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.exists(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
