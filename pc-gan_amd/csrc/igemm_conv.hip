@@ -19,6 +19,7 @@
 //
 // Reference call sites replaced: see include/pcgan_hip.h.
 #include "common.h"
+#include <stdlib.h>
 
 namespace pcgan {
 
@@ -26,26 +27,52 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { MODE_FWD_ZERO = 0, MODE_FWD_REFLECT = 1, MODE_BWD = 2 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static constexpr unsigned OOB = 0x80000000u;  // byte offset beyond any tensor (< 2 GiB): hardware returns 0
+
+// Range-checked buffer loads: an invalid lane gets voffset = OOB and reads 0 -- no exec-mask
+// branches, no 64-bit address arithmetic in the gather.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float ld_b32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float4 ld_b128(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+struct PhaseArgs {
+    const float* A;  // [M][Kp], k = (tap_index * Cgp + c)
+    int Kp;
+    int Hs, Ws;      // pixel sub-grid of this phase
+    int fy, fx;      // output coordinate = sub * ostep + f
+    int r0, s0, nR, nS;  // taps: r = r0 + i*tstep (i < nR), s = s0 + j*tstep (j < nS)
+    int Ptot;        // N * Hs * Ws
+};
+
 struct IgemmArgs {
-    const float* A;     // [M][Kp], k = (tap_index * Cgp + c)
     const float* X;     // gathered tensor [N][Cg][Hg][Wg]
     float* Y;           // output tensor   [N][M][Yh][Yw]
     const float* bias;  // [M] or null
-    int M, Kp;
-    int N, Cg, Cgp, Hg, Wg;
+    int M, N, Cg, Cgp, Hg, Wg;
     int Yh, Yw;
-    int Hs, Ws;          // pixel sub-grid handled by this launch
-    int ostep, fy, fx;   // output coordinate = sub * ostep + f
-    int sl, pad;         // log2(stride), padding
-    int r0, s0, tstep, nR, nS, S;  // taps: r = r0 + i*tstep (i < nR), s = s0 + j*tstep (j < nS)
+    int ostep, sl, pad, tstep;
     int act;
     float slope;
-    int Ptot;  // N * Hs * Ws
+    unsigned x_bytes;
+    int nphase;
+    PhaseArgs ph[16];
+};
+
+struct Geom {
+    int Hg, Wg, sl, pad;
 };
 
 // spatial offset of tap (r, s) for the pixel (py, px) of this thread
 template <int MODE>
-__device__ __forceinline__ bool tap_offset(const IgemmArgs& a, int py, int px, int r, int s, int& off) {
+__device__ __forceinline__ bool tap_offset(const Geom& a, int py, int px, int r, int s, int& off) {
     if (MODE == MODE_BWD) {
         const int ty = py + a.pad - r, tx = px + a.pad - s;
         const int oy = ty >> a.sl, ox = tx >> a.sl;  // divisible by construction of the phase
@@ -83,93 +110,99 @@ struct KIter {
     }
 };
 
-template <int MODE, int BM>
+// Block tile BM (output channels) x BP (pixels), K stage 16, 4 waves.
+// LDS images (all accesses 128-bit):
+//   As[row][20]      : 16 k of one output channel per row (+4 floats pad => ds_read_b128 conflict-free)
+//   Bs[k/4][pix][4]  : 4 consecutive k of one pixel per 16-byte slot
+// The MFMA consumes K in a permuted order (half-wave h takes k = 4*(2q+h)+j in step (q,j)); A and B use the
+// same permutation so the sum is unchanged.
+template <int MODE, int BM, int BP>
 __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
-    constexpr int WM = (BM == 128) ? 2 : 1;  // waves along M
-    constexpr int WP = 4 / WM;               // waves along pixels
-    constexpr int WMT = BM / WM;             // rows per wave
-    constexpr int WPT = 128 / WP;            // pixels per wave
+    constexpr int WM = (BM == 128 || (BM == 64 && BP == 64)) ? 2 : 1;  // waves along M
+    constexpr int WP = 4 / WM;                                         // waves along pixels
+    constexpr int WMT = BM / WM, WPT = BP / WP;
+    static_assert(WMT % 32 == 0 && WPT % 32 == 0, "wave tile must be a multiple of 32x32");
     constexpr int MI = WMT / 32, PJ = WPT / 32;
-    constexpr int AP = BM + 2;                           // A pitch: conflict-free b32 writes
-    constexpr int ACH = (BM * 4 + 255) / 256;            // float4 chunks per thread
-    __shared__ float As[2][16][AP];
-    __shared__ float Bs[2][16][128];
+    constexpr int AP = 20;
+    constexpr int KPT = BP / 16;                 // K slots per thread per stage (8 or 4)
+    constexpr int ACH = (BM * 4 + 255) / 256;    // float4 chunks of A per thread
+    __shared__ __attribute__((aligned(16))) float As[2][BM * AP];
+    __shared__ __attribute__((aligned(16))) float Bs[2][4 * BP * 4];
 
+    const PhaseArgs& P = a.ph[blockIdx.y];
     const int tid = threadIdx.x;
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WP, wp = wave % WP;
     const int nMt = (a.M + BM - 1) / BM;
     const int mt = blockIdx.x % nMt, pt = blockIdx.x / nMt;
-    const int m0 = mt * BM, p0 = pt * 128;
+    const int m0 = mt * BM, p0 = pt * BP;
+    const int Ptot = P.Ptot, Kp = P.Kp;
+    if (p0 >= Ptot) return;  // phases of unequal size share one grid
+
+    const Geom g{a.Hg, a.Wg, a.sl, a.pad};
+    const int HsWs = P.Hs * P.Ws;
+    const int HgWg = a.Hg * a.Wg;
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(P.A, (unsigned)a.M * (unsigned)Kp * 4u);
 
     // --- this thread's gather pixel -------------------------------------------------
-    const int HsWs = a.Hs * a.Ws;
-    const int HgWg = a.Hg * a.Wg;
-    const int pg = p0 + (tid & 127);
-    const bool pvalid = pg < a.Ptot;
-    int gn = 0, py = 0, px = 0;
+    const int pl = tid % BP;
+    const int pg = p0 + pl;
+    const bool pvalid = pg < Ptot;
+    int vbase = 0, py = 0, px = 0;
     if (pvalid) {
-        gn = pg / HsWs;
+        const int gn = pg / HsWs;
         const int rem = pg - gn * HsWs;
-        const int sy = rem / a.Ws;
-        py = sy * a.ostep + a.fy;
-        px = (rem - sy * a.Ws) * a.ostep + a.fx;
+        const int sy = rem / P.Ws;
+        py = sy * a.ostep + P.fy;
+        px = (rem - sy * P.Ws) * a.ostep + P.fx;
+        vbase = gn * a.Cg * HgWg;
     }
-    const float* Xn = a.X + (size_t)gn * a.Cg * HgWg;
-    const int ksub = wave >> 1;  // waves 0,1 -> k 0..7 ; waves 2,3 -> k 8..15 of each stage
+    const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);  // which KPT-slice of the stage this wave gathers
 
     KIter it{0, 0, 0};
-    it.advance(ksub * 8, a.Cgp, a.nS);
+    it.advance(ksub * KPT, a.Cgp, P.nS);
 
     float4 areg[ACH];
-    float breg[8];
+    float breg[KPT];
 
     auto load_stage = [&](int k0) {
-    // A tile: BM rows x 16 k, float4 chunks along k
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int q = tid + 256 * j;
             const int row = q >> 2, kc = (q & 3) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < BM && m0 + row < a.M && k0 + kc < a.Kp)
-                v = *reinterpret_cast<const float4*>(a.A + (size_t)(m0 + row) * a.Kp + k0 + kc);
-            areg[j] = v;
+            const bool ok = row < BM && m0 + row < a.M && k0 + kc < Kp;
+            areg[j] = ld_b128(rA, ok ? (unsigned)((m0 + row) * Kp + k0 + kc) * 4u : OOB);
         }
-        // B tile: 8 K slots for this thread's pixel; (ri,sj,c) are wave-uniform
         KIter e = it;
-        int off = 0;
-        bool ok = false;
+        unsigned voff = OOB;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i == 0 || e.c == 0) {
-                ok = false;
-                if (e.ri < a.nR) {
-                    ok = tap_offset<MODE>(a, py, px, a.r0 + e.ri * a.tstep, a.s0 + e.sj * a.tstep, off);
-                    ok = ok && pvalid;
+        for (int i = 0; i < KPT; ++i) {
+            if (i == 0 || e.c == 0) {  // wave-uniform: the tap changed
+                voff = OOB;
+                if (e.ri < P.nR) {
+                    int off;
+                    const bool ok = tap_offset<MODE>(g, py, px, P.r0 + e.ri * a.tstep, P.s0 + e.sj * a.tstep, off);
+                    voff = (ok && pvalid) ? (unsigned)(vbase + off) * 4u : OOB;
                 }
             }
-            float v = 0.f;
-            if (ok && e.c < a.Cg) v = Xn[(size_t)e.c * HgWg + off];
-            breg[i] = v;
-            e.advance(1, a.Cgp, a.nS);
+            breg[i] = (e.c < a.Cg) ? ld_b32(rX, voff, (unsigned)(e.c * HgWg) * 4u) : 0.f;
+            e.advance(1, a.Cgp, P.nS);
         }
-        it.advance(16, a.Cgp, a.nS);
+        it.advance(16, a.Cgp, P.nS);
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int q = tid + 256 * j;
             const int row = q >> 2, kc = (q & 3) * 4;
-            if (row < BM) {
-                As[buf][kc + 0][row] = areg[j].x;
-                As[buf][kc + 1][row] = areg[j].y;
-                As[buf][kc + 2][row] = areg[j].z;
-                As[buf][kc + 3][row] = areg[j].w;
-            }
+            if (row < BM) *reinterpret_cast<float4*>(&As[buf][row * AP + kc]) = areg[j];
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) Bs[buf][ksub * 8 + i][tid & 127] = breg[i];
+        for (int gq = 0; gq < KPT / 4; ++gq)
+            *reinterpret_cast<float4*>(&Bs[buf][((ksub * (KPT / 4) + gq) * BP + pl) * 4]) =
+                make_float4(breg[gq * 4 + 0], breg[gq * 4 + 1], breg[gq * 4 + 2], breg[gq * 4 + 3]);
     };
 
     f32x16 acc[MI][PJ];
@@ -180,7 +213,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nst = (a.Kp + 15) / 16;
+    const int nst = (Kp + 15) / 16;
     load_stage(0);
     store_stage(0);
     __syncthreads();
@@ -188,17 +221,25 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         const int buf = st & 1;
         if (st + 1 < nst) load_stage((st + 1) * 16);
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            float av[MI], bv[PJ];
+        for (int q = 0; q < 2; ++q) {
+            float av[MI][4], bv[PJ][4];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) av[i] = As[buf][kk * 2 + hi][wm * WMT + i * 32 + lo];
+            for (int i = 0; i < MI; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(&As[buf][(wm * WMT + i * 32 + lo) * AP + (2 * q + hi) * 4]);
+                av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+            }
 #pragma unroll
-            for (int j = 0; j < PJ; ++j) bv[j] = Bs[buf][kk * 2 + hi][wp * WPT + j * 32 + lo];
+            for (int j = 0; j < PJ; ++j) {
+                const float4 t = *reinterpret_cast<const float4*>(&Bs[buf][((2 * q + hi) * BP + wp * WPT + j * 32 + lo) * 4]);
+                bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
+            }
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int j = 0; j < PJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < PJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][jj], bv[j][jj], acc[i][j], 0, 0, 0);
         }
         if (st + 1 < nst) store_stage(buf ^ 1);
         __syncthreads();
@@ -209,12 +250,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
         const int pix = p0 + wp * WPT + j * 32 + lo;
-        if (pix >= a.Ptot) continue;
+        if (pix >= Ptot) continue;
         const int n = pix / HsWs;
         const int rem = pix - n * HsWs;
-        const int sy = rem / a.Ws;
-        const int oy = sy * a.ostep + a.fy;
-        const int ox = (rem - sy * a.Ws) * a.ostep + a.fx;
+        const int sy = rem / P.Ws;
+        const int oy = sy * a.ostep + P.fy;
+        const int ox = (rem - sy * P.Ws) * a.ostep + P.fx;
         float* Yp = a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -295,21 +336,27 @@ struct WgradArgs {
     float* Wp;        // [splits][M][Kp]   (k = tap*Cgp + c)
     int M, Kp, N, Cg, Cgp, Hg, Wg, Ho, Wo;
     int sl, pad, S;
-    int magicS;  // ceil(65536 / S): tap / S == (tap * magicS) >> 16 for tap < 4096
+    int magicS;  // ceil(65536 / S): tap / S == (tap * magicS) >> 16 for tap <= 512
     int Ptot, chunks_per_split;
+    unsigned x_bytes, dy_bytes;
 };
 
-template <int MODE, int BM, bool SMALLC>
+// Wp[m][kcol] = sum over a pixel range of dY[m][pix] * G(kcol; pix).  Tile BM x 128 (kcol), stage = 32
+// pixels.  LDS rows hold 32 pixels of one m / one kcol at pitch 36 floats (ds_read_b128 conflict-free);
+// the MFMA consumes the pixels in the same permuted order for both operands.
+// VECA: dY planes are a multiple of 4 pixels, so a thread fetches 4 consecutive pixels with one 16-byte load.
+template <int MODE, int BM, bool SMALLC, bool VECA>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     constexpr int BN = 128;
     constexpr int WM = (BM == 128) ? 2 : 1;
     constexpr int WN = 4 / WM;
     constexpr int WMT = BM / WM, WNT = BN / WN;
     constexpr int MI = WMT / 32, NJ = WNT / 32;
-    constexpr int PT = 33;  // pitch (pixels + 1): conflict-free column reads
+    constexpr int PT = 36;
     constexpr int AR = BM / 8, BR = BN / 8;
-    __shared__ float As[2][BM][PT];
-    __shared__ float Gs[2][BN][PT];
+    constexpr int AV = BM / 32;  // float4 chunks of dY per thread (VECA)
+    __shared__ __attribute__((aligned(16))) float As[2][BM * PT];
+    __shared__ __attribute__((aligned(16))) float Gs[2][BN * PT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
@@ -322,9 +369,12 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     const int m0 = mt * BM, kb = kt * BN;
     const int split = blockIdx.y;
     const int HoWo = a.Ho * a.Wo, HgWg = a.Hg * a.Wg;
+    const Geom g{a.Hg, a.Wg, a.sl, a.pad};
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.dY, a.dy_bytes);
 
-    // K-column bookkeeping.  Fast path (Cgp % 8 == 0): for row-group offset i the tap of
-    // column kb + 8*i + rg is block-uniform and c = cb_i + rg.
+    // K-column bookkeeping.  Fast path (Cgp % 8 == 0): for row-group offset i the tap of column
+    // kb + 8*i + rg is block-uniform and c = c_i + rg.
     int tap_b = 0, c_b = 0;
     if (!SMALLC) {
         tap_b = kb / a.Cgp;
@@ -333,6 +383,23 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 
     float areg[AR], breg[BR];
     auto load_stage = [&](int chunk) {
+        // ---- dY tile -----------------------------------------------------------------
+        if (VECA) {
+            const int pc = (tid & 7) * 4;  // same pixel quad for all of this thread's rows
+            const int pg = chunk * 32 + pc;
+            unsigned vb = OOB;
+            if (pg < a.Ptot) {
+                const int n = pg / HoWo;
+                vb = (unsigned)((n * a.M + m0) * HoWo + (pg - n * HoWo)) * 4u;
+            }
+#pragma unroll
+            for (int j = 0; j < AV; ++j) {
+                const int row = (tid >> 3) + 32 * j;
+                const float4 v = ld_b128(rY, (vb != OOB && m0 + row < a.M) ? vb + (unsigned)(row * HoWo) * 4u : OOB);
+                areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
+            }
+        }
+        // ---- this thread's gather pixel ------------------------------------------------
         const int pg = chunk * 32 + pl;
         const bool pvalid = pg < a.Ptot;
         int n = 0, oy = 0, ox = 0, rem = 0;
@@ -342,32 +409,27 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
             oy = rem / a.Wo;
             ox = rem - oy * a.Wo;
         }
-        const float* dYp = a.dY + ((size_t)n * a.M + m0 + rg) * HoWo + rem;
+        if (!VECA) {
+            const unsigned vb = pvalid ? (unsigned)((n * a.M + m0 + rg) * HoWo + rem) * 4u : OOB;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            float v = 0.f;
-            if (pvalid && m0 + rg + 8 * i < a.M) v = dYp[(size_t)8 * i * HoWo];
-            areg[i] = v;
+            for (int i = 0; i < AR; ++i)
+                areg[i] = ld_b32(rY, (pvalid && m0 + rg + 8 * i < a.M) ? vb : OOB, (unsigned)(8 * i * HoWo) * 4u);
         }
-        const float* Xn = a.X + (size_t)n * a.Cg * HgWg;
-        // IgemmArgs-like view for tap_offset
-        IgemmArgs g;
-        g.Hg = a.Hg; g.Wg = a.Wg; g.sl = a.sl; g.pad = a.pad;
+        const int vbase = n * a.Cg * HgWg;
         if (!SMALLC) {
-            int tap = tap_b, c = c_b, off = 0;
-            bool ok = false;
+            int tap = tap_b, c = c_b;
+            unsigned voff = OOB;
 #pragma unroll
             for (int i = 0; i < BR; ++i) {
-                // recompute when the (uniform) tap changed (c is a multiple of 8)
-                if (i == 0 || c == 0) {
+                if (i == 0 || c == 0) {  // block-uniform: the tap changed (c is a multiple of 8)
                     const int r = (tap * a.magicS) >> 16;
                     const int s = tap - r * a.S;
-                    ok = tap_offset<MODE>(g, oy, ox, r, s, off) && pvalid;
+                    int off;
+                    const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off) && pvalid;
+                    voff = ok ? (unsigned)(vbase + off + rg * HgWg) * 4u : OOB;
                 }
-                const int cc = c + rg;
-                float v = 0.f;
-                if (ok && cc < a.Cg && kb + 8 * i + rg < a.Kp) v = Xn[(size_t)cc * HgWg + off];
-                breg[i] = v;
+                const bool okc = (c + rg < a.Cg) && (kb + 8 * i + rg < a.Kp);
+                breg[i] = ld_b32(rX, okc ? voff : OOB, (unsigned)(c * HgWg) * 4u);
                 c += 8;
                 if (c >= a.Cgp) {
                     c -= a.Cgp;
@@ -383,15 +445,22 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
                 const int s = tap - r * a.S;
                 int off;
                 const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off) && pvalid && kcol < a.Kp && c < a.Cg;
-                breg[i] = ok ? Xn[(size_t)c * HgWg + off] : 0.f;
+                breg[i] = ld_b32(rX, ok ? (unsigned)(vbase + c * HgWg + off) * 4u : OOB, 0u);
             }
         }
     };
     auto store_stage = [&](int buf) {
+        if (VECA) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i) As[buf][rg + 8 * i][pl] = areg[i];
+            for (int j = 0; j < AV; ++j)
+                *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * j) * PT + (tid & 7) * 4]) =
+                    make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < BR; ++i) Gs[buf][rg + 8 * i][pl] = breg[i];
+            for (int i = 0; i < AR; ++i) As[buf][(rg + 8 * i) * PT + pl] = areg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) Gs[buf][(rg + 8 * i) * PT + pl] = breg[i];
     };
 
     f32x16 acc[MI][NJ];
@@ -415,17 +484,25 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
             const int buf = st & 1;
             if (st + 1 < nst) load_stage(c_begin + st + 1);
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                float av[MI], bv[NJ];
+            for (int q = 0; q < 4; ++q) {
+                float av[MI][4], bv[NJ][4];
 #pragma unroll
-                for (int i = 0; i < MI; ++i) av[i] = As[buf][wm * WMT + i * 32 + lo][kk * 2 + hi];
+                for (int i = 0; i < MI; ++i) {
+                    const float4 t = *reinterpret_cast<const float4*>(&As[buf][(wm * WMT + i * 32 + lo) * PT + (2 * q + hi) * 4]);
+                    av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+                }
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) bv[j] = Gs[buf][wn * WNT + j * 32 + lo][kk * 2 + hi];
+                for (int j = 0; j < NJ; ++j) {
+                    const float4 t = *reinterpret_cast<const float4*>(&Gs[buf][(wn * WNT + j * 32 + lo) * PT + (2 * q + hi) * 4]);
+                    bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
+                }
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][jj], bv[j][jj], acc[i][j], 0, 0, 0);
             }
             if (st + 1 < nst) store_stage(buf ^ 1);
             __syncthreads();
@@ -468,7 +545,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ Wp, float* __restr
 // host side
 // ------------------------------------------------------------------------------------
 static inline int round4(int v) { return (v + 3) & ~3; }
-static inline int pick_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
 
 static int check_desc(const pcgan_conv_desc* d) {
     PCGAN_CHECK(d != nullptr, "conv: null descriptor");
@@ -480,27 +556,53 @@ static int check_desc(const pcgan_conv_desc* d) {
     PCGAN_CHECK(P == d->P && Q == d->Q, "conv: output dims %dx%d do not match geometry %dx%d", d->P, d->Q, P, Q);
     if (d->pad_mode == 1)
         PCGAN_CHECK(d->pad < d->H && d->pad < d->W, "conv: reflection pad %d >= input size", d->pad);
-    PCGAN_CHECK((size_t)d->C * d->H * d->W < (1u << 30) && (size_t)d->K * d->P * d->Q < (1u << 30),
-                "conv: per-image tensor too large for 32-bit offsets");
-    PCGAN_CHECK((size_t)d->N * d->P * d->Q < (1u << 30) && (size_t)d->N * d->H * d->W < (1u << 30),
-                "conv: pixel count too large");
+    // range-checked buffer loads address tensors with 32-bit byte offsets; the out-of-range marker is 2 GiB
+    const size_t xin = (size_t)d->N * d->C * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * 4;
+    const size_t yout = (size_t)d->N * d->K * d->P * d->Q * 4;
+    PCGAN_CHECK(xin < (1ull << 31) && yout < (1ull << 31),
+                "conv: tensor of %zu bytes exceeds the 2 GiB addressing limit of one launch (split the batch)",
+                xin > yout ? xin : yout);
+    PCGAN_CHECK((size_t)d->K * round4(d->C) * d->R * d->S * 4 < (1ull << 31) &&
+                    (size_t)d->C * round4(d->K) * d->R * d->S * 4 < (1ull << 31), "conv: weight tensor too large");
     PCGAN_CHECK(d->R * d->S <= 512, "conv: filter too large");
     return 0;
 }
 
+// tile choice: the largest tile that still gives the 256 CUs >= ~1.5 workgroups each
+static void choose_tile(int M, int ptot_max, int nphase, int* bm, int* bp) {
+    int m = M > 64 ? 128 : (M > 32 ? 64 : 32);
+    int p = 128;
+    auto blocks = [&](int mm, int pp) { return (long)((M + mm - 1) / mm) * ((ptot_max + pp - 1) / pp) * nphase; };
+    if (m >= 64 && blocks(m, p) < 384) p = 64;
+    if (m == 128 && blocks(m, p) < 384) m = 64;
+    const char* env = getenv("PCGAN_TILE");  // experiments: "BM,BP"
+    if (env) {
+        int em = 0, ep = 0;
+        if (sscanf(env, "%d,%d", &em, &ep) == 2 && (em == 128 || em == 64 || em == 32) && (ep == 128 || ep == 64) &&
+            !(em == 32 && ep == 64) && em <= (M > 64 ? 128 : (M > 32 ? 64 : 32))) {
+            m = em;
+            p = ep;
+        }
+    }
+    *bm = m;
+    *bp = p;
+}
+
 template <int MODE>
 static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
-    if (a.Ptot <= 0 || a.Kp <= 0) return 0;
-    const int bm = pick_bm(a.M);
-    const int nMt = (a.M + bm - 1) / bm;
-    const int nPt = (a.Ptot + 127) / 128;
-    const dim3 grid((unsigned)(nMt * nPt));
-    if (bm == 128)
-        hipLaunchKernelGGL((igemm_kernel<MODE, 128>), grid, dim3(256), 0, st, a);
-    else if (bm == 64)
-        hipLaunchKernelGGL((igemm_kernel<MODE, 64>), grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((igemm_kernel<MODE, 32>), grid, dim3(256), 0, st, a);
+    int pmax = 0;
+    for (int i = 0; i < a.nphase; ++i) pmax = a.ph[i].Ptot > pmax ? a.ph[i].Ptot : pmax;
+    if (pmax <= 0 || a.nphase <= 0) return 0;
+    int bm, bp;
+    choose_tile(a.M, pmax, a.nphase, &bm, &bp);
+    const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((pmax + bp - 1) / bp)), (unsigned)a.nphase);
+#define LI(BMV, BPV) hipLaunchKernelGGL((igemm_kernel<MODE, BMV, BPV>), grid, dim3(256), 0, st, a)
+    if (bm == 128 && bp == 128) LI(128, 128);
+    else if (bm == 128) LI(128, 64);
+    else if (bm == 64 && bp == 128) LI(64, 128);
+    else if (bm == 64) LI(64, 64);
+    else LI(32, 128);
+#undef LI
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -508,7 +610,7 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
 static int wgrad_splits(const pcgan_conv_desc* d, int* chunks_per_split) {
     const int Cgp = round4(d->C);
     const int Kp = d->R * d->S * Cgp;
-    const int bm = pick_bm(d->K);
+    const int bm = d->K > 64 ? 128 : (d->K > 32 ? 64 : 32);
     const int tiles = ((d->K + bm - 1) / bm) * ((Kp + 127) / 128);
     const int Ptot = d->N * d->P * d->Q;
     const int chunks = (Ptot + 31) / 32;
@@ -558,15 +660,16 @@ extern "C" int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const 
     }
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.A = A; a.X = x; a.Y = y; a.bias = bias;
-    a.M = d->K; a.Kp = RS * Cgp;
-    a.N = d->N; a.Cg = d->C; a.Cgp = Cgp; a.Hg = d->H; a.Wg = d->W;
-    a.Yh = d->P; a.Yw = d->Q; a.Hs = d->P; a.Ws = d->Q;
-    a.ostep = 1; a.fy = 0; a.fx = 0;
-    a.sl = ilog2_exact(d->stride); a.pad = d->pad;
-    a.r0 = 0; a.s0 = 0; a.tstep = 1; a.nR = d->R; a.nS = d->S; a.S = d->S;
+    a.X = x; a.Y = y; a.bias = bias;
+    a.M = d->K; a.N = d->N; a.Cg = d->C; a.Cgp = Cgp; a.Hg = d->H; a.Wg = d->W;
+    a.Yh = d->P; a.Yw = d->Q;
+    a.ostep = 1; a.sl = ilog2_exact(d->stride); a.pad = d->pad; a.tstep = 1;
     a.act = act; a.slope = slope;
-    a.Ptot = d->N * d->P * d->Q;
+    a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
+    a.nphase = 1;
+    PhaseArgs& p = a.ph[0];
+    p.A = A; p.Kp = RS * Cgp; p.Hs = d->P; p.Ws = d->Q; p.fy = 0; p.fx = 0;
+    p.r0 = 0; p.s0 = 0; p.nR = d->R; p.nS = d->S; p.Ptot = d->N * d->P * d->Q;
     return d->pad_mode == 1 ? launch_igemm<MODE_FWD_REFLECT>(a, st) : launch_igemm<MODE_FWD_ZERO>(a, st);
 }
 
@@ -590,16 +693,17 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
     float* out = reflect ? (float*)((char*)ws + a_bytes) : dx;
     const int stv = d->stride;
 
-    // does every output pixel receive at least one tap?  (not for e.g. 1x1 stride 2)
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = dy; a.Y = out; a.bias = bias;
+    a.M = d->C; a.N = d->N; a.Cg = d->K; a.Cgp = Kgp; a.Hg = d->P; a.Wg = d->Q;
+    a.Yh = H; a.Yw = W;
+    a.ostep = stv; a.sl = ilog2_exact(stv); a.pad = pad; a.tstep = stv;
+    a.act = PCGAN_ACT_NONE; a.slope = 0.f;
+    a.x_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * 4);
+
+    // one phase per (iy % stride, ix % stride): only the taps that are structurally non-zero for it
     bool need_zero = false;
-    for (int f = 0; f < stv; ++f) {
-        const int r0 = (f + pad) % stv;
-        if (r0 >= d->R || r0 >= d->S) need_zero = true;
-    }
-    if (need_zero) {
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)d->N * d->C * H * W * 4, st);
-        PCGAN_CHECK(e == hipSuccess, "memset failed: %s", hipGetErrorString(e));
-    }
     size_t a_off = 0;
     for (int fy = 0; fy < stv; ++fy) {
         for (int fx = 0; fx < stv; ++fx) {
@@ -608,7 +712,11 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
             const int nS = s0 < d->S ? (d->S - s0 + stv - 1) / stv : 0;
             const int Hs = fy < H ? (H - fy + stv - 1) / stv : 0;
             const int Ws = fx < W ? (W - fx + stv - 1) / stv : 0;
-            if (nR * nS == 0 || Hs * Ws == 0) continue;
+            if (Hs * Ws == 0) continue;
+            if (nR * nS == 0) {  // e.g. 1x1 stride 2: these pixels receive nothing
+                need_zero = true;
+                continue;
+            }
             float* A = Abase + a_off;
             const size_t total = (size_t)d->C * nR * nS * Kgp;
             a_off += total;
@@ -616,25 +724,18 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
             hipLaunchKernelGGL(repack_bwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Kgp, d->R,
                                d->S, r0, s0, stv, nR, nS);
             PCGAN_LAUNCH_CHECK();
-            IgemmArgs a;
-            memset(&a, 0, sizeof(a));
-            a.A = A; a.X = dy; a.Y = out; a.bias = bias;
-            a.M = d->C; a.Kp = nR * nS * Kgp;
-            a.N = d->N; a.Cg = d->K; a.Cgp = Kgp; a.Hg = d->P; a.Wg = d->Q;
-            a.Yh = H; a.Yw = W; a.Hs = Hs; a.Ws = Ws;
-            a.ostep = stv; a.fy = fy; a.fx = fx;
-            a.sl = ilog2_exact(stv); a.pad = pad;
-            a.r0 = r0; a.s0 = s0; a.tstep = stv; a.nR = nR; a.nS = nS; a.S = d->S;
-            a.act = PCGAN_ACT_NONE; a.slope = 0.f;
-            a.Ptot = d->N * Hs * Ws;
-            if (launch_igemm<MODE_BWD>(a, st)) return 2;
+            PhaseArgs& p = a.ph[a.nphase++];
+            p.A = A; p.Kp = nR * nS * Kgp; p.Hs = Hs; p.Ws = Ws; p.fy = fy; p.fx = fx;
+            p.r0 = r0; p.s0 = s0; p.nR = nR; p.nS = nS; p.Ptot = d->N * Hs * Ws;
         }
     }
-    if (need_zero && bias) {
-        // pixels that no phase wrote still need the bias; never happens for the nets on the
-        // hot path (bias is only passed for ConvTranspose2d 3x3/s2), so refuse loudly.
-        PCGAN_CHECK(false, "conv2d_bwd_data: bias with uncovered phases is unsupported");
+    if (need_zero) {
+        // pixels that no phase writes would also miss the bias; never happens for the nets on the hot path
+        PCGAN_CHECK(!bias, "conv2d_bwd_data: bias with uncovered phases is unsupported");
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)d->N * d->C * H * W * 4, st);
+        PCGAN_CHECK(e == hipSuccess, "memset failed: %s", hipGetErrorString(e));
     }
+    if (launch_igemm<MODE_BWD>(a, st)) return 2;
     if (reflect) {
         const size_t total = (size_t)d->N * d->C * d->H * d->W;
         const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
@@ -661,26 +762,23 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
     a.sl = ilog2_exact(d->stride); a.pad = d->pad; a.S = d->S;
     a.magicS = (65536 + d->S - 1) / d->S;
     a.Ptot = d->N * d->P * d->Q;
+    a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
+    a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * 4);
     const int splits = wgrad_splits(d, &a.chunks_per_split);
-    const int bm = pick_bm(a.M);
+    const int bm = a.M > 64 ? 128 : (a.M > 32 ? 64 : 32);
     const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((a.Kp + 127) / 128)), (unsigned)splits);
     const bool smallc = (Cgp % 8) != 0;
     const bool reflect = d->pad_mode == 1;
-#define LAUNCH_WG(MODE, BMV, SC) \
-    hipLaunchKernelGGL((wgrad_kernel<MODE, BMV, SC>), grid, dim3(256), 0, st, a)
-#define LAUNCH_WG_BM(MODE, SC)                  \
-    do {                                        \
-        if (bm == 128) LAUNCH_WG(MODE, 128, SC); \
-        else if (bm == 64) LAUNCH_WG(MODE, 64, SC); \
-        else LAUNCH_WG(MODE, 32, SC);            \
-    } while (0)
-    if (reflect) {
-        if (smallc) LAUNCH_WG_BM(MODE_FWD_REFLECT, true); else LAUNCH_WG_BM(MODE_FWD_REFLECT, false);
-    } else {
-        if (smallc) LAUNCH_WG_BM(MODE_FWD_ZERO, true); else LAUNCH_WG_BM(MODE_FWD_ZERO, false);
-    }
-#undef LAUNCH_WG_BM
-#undef LAUNCH_WG
+    const bool veca = ((d->P * d->Q) % 4) == 0;
+#define LW(MODE, BMV, SC, VA) hipLaunchKernelGGL((wgrad_kernel<MODE, BMV, SC, VA>), grid, dim3(256), 0, st, a)
+#define LW_VA(MODE, BMV, SC) do { if (veca) LW(MODE, BMV, SC, true); else LW(MODE, BMV, SC, false); } while (0)
+#define LW_SC(MODE, BMV) do { if (smallc) LW_VA(MODE, BMV, true); else LW_VA(MODE, BMV, false); } while (0)
+#define LW_BM(MODE) do { if (bm == 128) LW_SC(MODE, 128); else if (bm == 64) LW_SC(MODE, 64); else LW_SC(MODE, 32); } while (0)
+    if (reflect) LW_BM(MODE_FWD_REFLECT); else LW_BM(MODE_FWD_ZERO);
+#undef LW_BM
+#undef LW_SC
+#undef LW_VA
+#undef LW
     PCGAN_LAUNCH_CHECK();
     {
         const size_t total = (size_t)d->K * RS * Cgp;
