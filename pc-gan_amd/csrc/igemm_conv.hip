@@ -116,7 +116,9 @@ struct KIter {
 //   Bs[k/4][pix][4]  : 4 consecutive k of one pixel per 16-byte slot
 // The MFMA consumes K in a permuted order (half-wave h takes k = 4*(2q+h)+j in step (q,j)); A and B use the
 // same permutation so the sum is unchanged.
-template <int MODE, int BM, int BP>
+// CG16: the padded channel count is a multiple of 16, so a K stage never straddles a filter tap: one
+// spatial offset per stage and a two-compare iterator (keeps the gather code short and branch-free).
+template <int MODE, int BM, int BP, bool CG16>
 __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     constexpr int WM = (BM == 128 || (BM == 64 && BP == 64)) ? 2 : 1;  // waves along M
     constexpr int WP = 4 / WM;                                         // waves along pixels
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);  // which KPT-slice of the stage this wave gathers
 
     KIter it{0, 0, 0};
-    it.advance(ksub * KPT, a.Cgp, P.nS);
+    if (!CG16) it.advance(ksub * KPT, a.Cgp, P.nS);
 
     float4 areg[ACH];
     float breg[KPT];
@@ -174,6 +176,28 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             const int row = q >> 2, kc = (q & 3) * 4;
             const bool ok = row < BM && m0 + row < a.M && k0 + kc < Kp;
             areg[j] = ld_b128(rA, ok ? (unsigned)((m0 + row) * Kp + k0 + kc) * 4u : OOB);
+        }
+        if (CG16) {
+            // whole stage inside tap (it.ri, it.sj); this wave gathers channels it.c + ksub*KPT + i
+            unsigned voff = OOB;
+            if (it.ri < P.nR) {
+                int off;
+                const bool ok = tap_offset<MODE>(g, py, px, P.r0 + it.ri * a.tstep, P.s0 + it.sj * a.tstep, off);
+                voff = (ok && pvalid) ? (unsigned)(vbase + off) * 4u : OOB;
+            }
+            const int c0 = it.c + ksub * KPT;
+#pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                breg[i] = (c0 + i < a.Cg) ? ld_b32(rX, voff, (unsigned)((c0 + i) * HgWg) * 4u) : 0.f;
+            it.c += 16;
+            if (it.c == a.Cgp) {
+                it.c = 0;
+                if (++it.sj == P.nS) {
+                    it.sj = 0;
+                    ++it.ri;
+                }
+            }
+            return;
         }
         KIter e = it;
         unsigned voff = OOB;
@@ -596,7 +620,12 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
     int bm, bp;
     choose_tile(a.M, pmax, a.nphase, &bm, &bp);
     const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((pmax + bp - 1) / bp)), (unsigned)a.nphase);
-#define LI(BMV, BPV) hipLaunchKernelGGL((igemm_kernel<MODE, BMV, BPV>), grid, dim3(256), 0, st, a)
+    const bool cg16 = (a.Cgp % 16) == 0;
+#define LI(BMV, BPV)                                                                                   \
+    do {                                                                                               \
+        if (cg16) hipLaunchKernelGGL((igemm_kernel<MODE, BMV, BPV, true>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((igemm_kernel<MODE, BMV, BPV, false>), grid, dim3(256), 0, st, a);     \
+    } while (0)
     if (bm == 128 && bp == 128) LI(128, 128);
     else if (bm == 128) LI(128, 64);
     else if (bm == 64 && bp == 128) LI(64, 128);
