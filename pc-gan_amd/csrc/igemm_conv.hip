@@ -25,7 +25,7 @@ namespace pcgan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { MODE_FWD_ZERO = 0, MODE_FWD_REFLECT = 1, MODE_BWD = 2 };
+enum { MODE_FWD_ZERO = 0, MODE_FWD_REFLECT = 1, MODE_BWD = 2, MODE_BWD_REFLECT = 3 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 static constexpr unsigned OOB = 0x80000000u;  // byte offset beyond any tensor (< 2 GiB): hardware returns 0
@@ -73,7 +73,7 @@ struct Geom {
 // spatial offset of tap (r, s) for the pixel (py, px) of this thread
 template <int MODE>
 __device__ __forceinline__ bool tap_offset(const Geom& a, int py, int px, int r, int s, int& off) {
-    if (MODE == MODE_BWD) {
+    if (MODE == MODE_BWD || MODE == MODE_BWD_REFLECT) {
         const int ty = py + a.pad - r, tx = px + a.pad - s;
         const int oy = ty >> a.sl, ox = tx >> a.sl;  // divisible by construction of the phase
         off = oy * a.Wg + ox;
@@ -161,6 +161,16 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         px = (rem - sy * P.Ws) * a.ostep + P.fx;
         vbase = gn * a.Cg * HgWg;
     }
+    // MODE_BWD_REFLECT: padded-grid index of the mirror image of this pixel's row / column (-1: none).
+    // Padded row j holds input row reflect(j - pad); row py therefore also appears at j = pad - py when
+    // 1 <= py <= pad and at j = pad + 2(H-1) - py when H-1-pad <= py <= H-2 (H >= 2 pad + 2 checked on host).
+    int myr = -1, mxr = -1;
+    if (MODE == MODE_BWD_REFLECT) {
+        if (py >= 1 && py <= a.pad) myr = a.pad - py;
+        else if (py >= a.Yh - 1 - a.pad && py <= a.Yh - 2) myr = a.pad + 2 * (a.Yh - 1) - py;
+        if (px >= 1 && px <= a.pad) mxr = a.pad - px;
+        else if (px >= a.Yw - 1 - a.pad && px <= a.Yw - 2) mxr = a.pad + 2 * (a.Yw - 1) - px;
+    }
     const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);  // which KPT-slice of the stage this wave gathers
 
     KIter it{0, 0, 0};
@@ -168,6 +178,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
 
     float4 areg[ACH];
     float breg[KPT];
+    float bmir[MODE == MODE_BWD_REFLECT ? 3 : 1][MODE == MODE_BWD_REFLECT ? KPT : 1];  // mirror-image gathers
 
     auto load_stage = [&](int k0) {
 #pragma unroll
@@ -176,6 +187,60 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             const int row = q >> 2, kc = (q & 3) * 4;
             const bool ok = row < BM && m0 + row < a.M && k0 + kc < Kp;
             areg[j] = ld_b128(rA, ok ? (unsigned)((m0 + row) * Kp + k0 + kc) * 4u : OOB);
+        }
+        if (CG16 && MODE == MODE_BWD_REFLECT) {
+            // Data gradient of ReflectionPad2d(pad)+conv (stride 1), gathered directly on the UNPADDED grid:
+            // input row py collects the padded rows {py+pad} U {its mirror image, if py is within pad of an
+            // edge}; same for columns => up to 2x2 sources per tap.  The extra loads are skipped by
+            // wave-uniform votes when no lane of the wave needs them (rows: only waves touching the
+            // mirrored rows; columns: the two mirrored columns of every row).
+            unsigned v00 = OOB, v01 = OOB, v10 = OOB, v11 = OOB;
+            if (it.ri < P.nR && pvalid) {
+                const int r = it.ri, s = it.sj;
+                const int ya = py + a.pad - r, yb = myr - r, xa = px + a.pad - s, xb = mxr - s;
+                const bool oya = (unsigned)ya < (unsigned)a.Hg, oyb = myr >= 0 && (unsigned)yb < (unsigned)a.Hg;
+                const bool oxa = (unsigned)xa < (unsigned)a.Wg, oxb = mxr >= 0 && (unsigned)xb < (unsigned)a.Wg;
+                v00 = (oya && oxa) ? (unsigned)(vbase + ya * a.Wg + xa) * 4u : OOB;
+                v01 = (oya && oxb) ? (unsigned)(vbase + ya * a.Wg + xb) * 4u : OOB;
+                v10 = (oyb && oxa) ? (unsigned)(vbase + yb * a.Wg + xa) * 4u : OOB;
+                v11 = (oyb && oxb) ? (unsigned)(vbase + yb * a.Wg + xb) * 4u : OOB;
+            }
+            // all loads are issued back to back into separate registers and only summed when the stage is
+            // written to LDS (after the MFMA phase), so the mirror loads add issue slots, not latency
+            const bool any01 = __any(v01 != OOB), any10 = __any(v10 != OOB), any11 = __any(v11 != OOB);
+            const int c0 = it.c + ksub * KPT;
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) breg[i] = ld_b32(rX, v00, (unsigned)((c0 + i) * HgWg) * 4u);
+            if (any01) {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) bmir[0][i] = ld_b32(rX, v01, (unsigned)((c0 + i) * HgWg) * 4u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) bmir[0][i] = 0.f;
+            }
+            if (any10) {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) bmir[1][i] = ld_b32(rX, v10, (unsigned)((c0 + i) * HgWg) * 4u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) bmir[1][i] = 0.f;
+            }
+            if (any11) {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) bmir[2][i] = ld_b32(rX, v11, (unsigned)((c0 + i) * HgWg) * 4u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) bmir[2][i] = 0.f;
+            }
+            it.c += 16;
+            if (it.c == a.Cgp) {
+                it.c = 0;
+                if (++it.sj == P.nS) {
+                    it.sj = 0;
+                    ++it.ri;
+                }
+            }
+            return;
         }
         if (CG16) {
             // whole stage inside tap (it.ri, it.sj); this wave gathers channels it.c + ksub*KPT + i
@@ -222,6 +287,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             const int q = tid + 256 * j;
             const int row = q >> 2, kc = (q & 3) * 4;
             if (row < BM) *reinterpret_cast<float4*>(&As[buf][row * AP + kc]) = areg[j];
+        }
+        if (MODE == MODE_BWD_REFLECT) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) breg[i] += (bmir[0][i] + bmir[1][i]) + bmir[2][i];
         }
 #pragma unroll
         for (int gq = 0; gq < KPT / 4; ++gq)
@@ -621,10 +690,13 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
     choose_tile(a.M, pmax, a.nphase, &bm, &bp);
     const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((pmax + bp - 1) / bp)), (unsigned)a.nphase);
     const bool cg16 = (a.Cgp % 16) == 0;
+    PCGAN_CHECK(cg16 || MODE != MODE_BWD_REFLECT, "igemm: fused reflect data-gradient needs K %% 16 == 0");
 #define LI(BMV, BPV)                                                                                   \
     do {                                                                                               \
         if (cg16) hipLaunchKernelGGL((igemm_kernel<MODE, BMV, BPV, true>), grid, dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((igemm_kernel<MODE, BMV, BPV, false>), grid, dim3(256), 0, st, a);     \
+        else if (MODE != MODE_BWD_REFLECT)                                                             \
+            hipLaunchKernelGGL((igemm_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV, false>), grid, \
+                               dim3(256), 0, st, a);                                                   \
     } while (0)
     if (bm == 128 && bp == 128) LI(128, 128);
     else if (bm == 128) LI(128, 64);
@@ -714,8 +786,10 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
     const int Kgp = round4(d->K), RS = d->R * d->S;
     float* Abase = (float*)ws;
     const size_t a_bytes = align_up((size_t)d->C * RS * Kgp * 4, 256);
-    // reflection: compute the gradient of the PADDED input (pad 0 on a larger grid), then fold
-    const bool reflect = d->pad_mode == 1;
+    // reflection: gather the mirror images directly (fused, needs K % 16 == 0 and H,W >= 2 pad + 2); otherwise
+    // compute the gradient of the PADDED input (pad 0 on a larger grid) and fold it back
+    const bool fused = d->pad_mode == 1 && (Kgp % 16) == 0 && d->H >= 2 * d->pad + 2 && d->W >= 2 * d->pad + 2;
+    const bool reflect = d->pad_mode == 1 && !fused;
     const int H = reflect ? d->H + 2 * d->pad : d->H;
     const int W = reflect ? d->W + 2 * d->pad : d->W;
     const int pad = reflect ? 0 : d->pad;
@@ -764,7 +838,7 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
         hipError_t e = hipMemsetAsync(out, 0, (size_t)d->N * d->C * H * W * 4, st);
         PCGAN_CHECK(e == hipSuccess, "memset failed: %s", hipGetErrorString(e));
     }
-    if (launch_igemm<MODE_BWD>(a, st)) return 2;
+    if (fused ? launch_igemm<MODE_BWD_REFLECT>(a, st) : launch_igemm<MODE_BWD>(a, st)) return 2;
     if (reflect) {
         const size_t total = (size_t)d->N * d->C * d->H * d->W;
         const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
