@@ -366,6 +366,147 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     }
 }
 
+struct WgradArgs {
+    const float* dY;  // [N][M][Ho][Wo]
+    const float* X;   // [N][Cg][Hg][Wg]
+    float* Wp;        // [splits][M][Kp]   (k = tap*Cgp + c)
+    int M, Kp, N, Cg, Cgp, Hg, Wg, Ho, Wo;
+    int sl, pad, S;
+    int magicS;  // ceil(65536 / S): tap / S == (tap * magicS) >> 16 for tap <= 512
+    int Ptot, chunks_per_split;
+    unsigned x_bytes, dy_bytes;
+};
+
+// ------------------------------------------------------------------------------------
+// Small-M path (M <= 4 output channels): the generator head (64->3), the last PatchGAN / Elo-head conv
+// (->1) and every data gradient that lands on an image (3-4 channels).  A 32-row MFMA tile would be >= 87 %
+// padding there, so these run on the vector ALU: one thread = one pixel x 4 outputs, weights broadcast
+// through the scalar cache as [k][4] rows, gathers coalesced along pixels.  Bound: L1/TA (one 4-byte
+// gather per 4 FMA).
+// ------------------------------------------------------------------------------------
+__global__ void transpose4_kernel(const float* __restrict__ A, float* __restrict__ At, int M, int Kp) {
+    const int total = Kp * 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int k = i >> 2, m = i & 3;
+        At[i] = m < M ? A[(size_t)m * Kp + k] : 0.f;
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) smallm_conv_kernel(IgemmArgs a) {
+    const PhaseArgs& P = a.ph[blockIdx.y];
+    const int Ptot = P.Ptot;
+    if ((int)(blockIdx.x * 256) >= Ptot) return;
+    const int pg = blockIdx.x * 256 + threadIdx.x;
+    const bool pvalid = pg < Ptot;
+    const Geom g{a.Hg, a.Wg, a.sl, a.pad};
+    const int HsWs = P.Hs * P.Ws, HgWg = a.Hg * a.Wg;
+    int n = 0, py = 0, px = 0;
+    if (pvalid) {
+        n = pg / HsWs;
+        const int rem = pg - n * HsWs;
+        const int sy = rem / P.Ws;
+        py = sy * a.ostep + P.fy;
+        px = (rem - sy * P.Ws) * a.ostep + P.fx;
+    }
+    const int vbase = n * a.Cg * HgWg;
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
+    const float4* __restrict__ At = reinterpret_cast<const float4*>(P.A);  // [Kp][4]
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int ri = 0; ri < P.nR; ++ri) {
+        for (int sj = 0; sj < P.nS; ++sj) {
+            int off;
+            const bool ok = tap_offset<MODE>(g, py, px, P.r0 + ri * a.tstep, P.s0 + sj * a.tstep, off) && pvalid;
+            const unsigned voff = ok ? (unsigned)(vbase + off) * 4u : OOB;
+            const int kbase = (ri * P.nS + sj) * a.Cgp;
+            int c = 0;
+            for (; c + 8 <= a.Cg; c += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = ld_b32(rX, voff, (unsigned)((c + u) * HgWg) * 4u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float4 w = At[kbase + c + u];  // wave-uniform address -> scalar load
+                    acc0 += x[u] * w.x; acc1 += x[u] * w.y; acc2 += x[u] * w.z; acc3 += x[u] * w.w;
+                }
+            }
+            for (; c < a.Cg; ++c) {
+                const float x = ld_b32(rX, voff, (unsigned)(c * HgWg) * 4u);
+                const float4 w = At[kbase + c];
+                acc0 += x * w.x; acc1 += x * w.y; acc2 += x * w.z; acc3 += x * w.w;
+            }
+        }
+    }
+    if (!pvalid) return;
+    const int YhYw = a.Yh * a.Yw;
+    float* Yp = a.Y + (size_t)n * a.M * YhYw + py * a.Yw + px;
+    const float out[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (m < a.M) {
+            float v = out[m];
+            if (a.bias) v += a.bias[m];
+            Yp[(size_t)m * YhYw] = act_apply(v, a.act, a.slope);
+        }
+    }
+}
+
+// Weight gradient for M <= 4: Wp[split][m][kb..kb+15] = sum_pix dY[m][pix] * G(k; pix).  One workgroup per
+// 16-column slab of K (one tap, 16 channels: needs Cgp % 16 == 0) and pixel split; every thread keeps the
+// 4x16 partial sums of its pixels in registers and the workgroup reduces them once at the end.
+template <int MODE>
+__global__ void __launch_bounds__(256) smallm_wgrad_kernel(WgradArgs a) {
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x;
+    const int kb = blockIdx.x * 16;
+    const int tap = kb / a.Cgp, c0 = kb - tap * a.Cgp;
+    const int r = (tap * a.magicS) >> 16, s = tap - r * a.S;
+    const Geom g{a.Hg, a.Wg, a.sl, a.pad};
+    const int HoWo = a.Ho * a.Wo, HgWg = a.Hg * a.Wg;
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.dY, a.dy_bytes);
+    float acc[4][16];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[m][j] = 0.f;
+    const int pbeg = blockIdx.y * a.chunks_per_split * 32;
+    int pend = pbeg + a.chunks_per_split * 32;
+    if (pend > a.Ptot) pend = a.Ptot;
+    for (int pg = pbeg + tid; pg < pend; pg += 256) {
+        const int n = pg / HoWo;
+        const int rem = pg - n * HoWo;
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        int off;
+        const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off);
+        const unsigned voff = ok ? (unsigned)(n * a.Cg * HgWg + off) * 4u : OOB;
+        const unsigned yoff = (unsigned)(n * a.M * HoWo + rem) * 4u;
+        float dy[4], x[16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dy[m] = ld_b32(rY, m < a.M ? yoff : OOB, (unsigned)(m * HoWo) * 4u);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = ld_b32(rX, (c0 + j < a.Cg) ? voff : OOB, (unsigned)((c0 + j) * HgWg) * 4u);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[m][j] += dy[m] * x[j];
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float v = wave_sum(acc[m][j]);
+            if (lane == 0) red[wave][m * 16 + j] = v;
+        }
+    __syncthreads();
+    if (tid < 64) {
+        const int m = tid >> 4, j = tid & 15;
+        if (m < a.M && kb + j < a.Kp)
+            a.Wp[((size_t)blockIdx.y * a.M + m) * a.Kp + kb + j] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // weight re-layout kernels
 // ------------------------------------------------------------------------------------
@@ -423,16 +564,6 @@ __global__ void reflect_fold_kernel(const float* __restrict__ t, float* __restri
 // ------------------------------------------------------------------------------------
 // backward-weight
 // ------------------------------------------------------------------------------------
-struct WgradArgs {
-    const float* dY;  // [N][M][Ho][Wo]
-    const float* X;   // [N][Cg][Hg][Wg]
-    float* Wp;        // [splits][M][Kp]   (k = tap*Cgp + c)
-    int M, Kp, N, Cg, Cgp, Hg, Wg, Ho, Wo;
-    int sl, pad, S;
-    int magicS;  // ceil(65536 / S): tap / S == (tap * magicS) >> 16 for tap <= 512
-    int Ptot, chunks_per_split;
-    unsigned x_bytes, dy_bytes;
-};
 
 // Wp[m][kcol] = sum over a pixel range of dY[m][pix] * G(kcol; pix).  Tile BM x 128 (kcol), stage = 32
 // pixels.  LDS rows hold 32 pixels of one m / one kcol at pitch 36 floats (ds_read_b128 conflict-free);
@@ -686,6 +817,12 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
     int pmax = 0;
     for (int i = 0; i < a.nphase; ++i) pmax = a.ph[i].Ptot > pmax ? a.ph[i].Ptot : pmax;
     if (pmax <= 0 || a.nphase <= 0) return 0;
+    if (a.M <= 4) {  // vector-ALU path; ph[].A already holds the transposed [Kp][4] weights
+        const dim3 grid((unsigned)((pmax + 255) / 256), (unsigned)a.nphase);
+        hipLaunchKernelGGL((smallm_conv_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE)>), grid, dim3(256), 0, st, a);
+        PCGAN_LAUNCH_CHECK();
+        return 0;
+    }
     int bm, bp;
     choose_tile(a.M, pmax, a.nphase, &bm, &bp);
     const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((pmax + bp - 1) / bp)), (unsigned)a.nphase);
@@ -708,9 +845,20 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
     return 0;
 }
 
+static inline bool smallm_wgrad(const pcgan_conv_desc* d) { return d->K <= 4 && (round4(d->C) % 16) == 0; }
+
 static int wgrad_splits(const pcgan_conv_desc* d, int* chunks_per_split) {
     const int Cgp = round4(d->C);
     const int Kp = d->R * d->S * Cgp;
+    if (smallm_wgrad(d)) {  // one workgroup per 16 K-columns and pixel split; aim at ~2048 workgroups
+        const int chunks = (d->N * d->P * d->Q + 31) / 32;
+        int splits = 2048 / (Kp / 16);
+        if (splits > chunks / 64) splits = chunks / 64;  // >= 8 pixels per thread
+        if (splits < 1) splits = 1;
+        int cps = (chunks + splits - 1) / splits;
+        *chunks_per_split = cps;
+        return (chunks + cps - 1) / cps;
+    }
     const int bm = d->K > 64 ? 128 : (d->K > 32 ? 64 : 32);
     const int tiles = ((d->K + bm - 1) / bm) * ((Kp + 127) / 128);
     const int Ptot = d->N * d->P * d->Q;
@@ -732,9 +880,10 @@ using namespace pcgan;
 extern "C" size_t pcgan_conv2d_workspace_bytes(const pcgan_conv_desc* d, int pass) {
     if (!d) return 0;
     const size_t RS = (size_t)d->R * d->S;
-    if (pass == PCGAN_PASS_FWD) return align_up((size_t)d->K * RS * round4(d->C) * 4, 256);
+    // (+ RS*C*16 bytes: room for the [k][4] transposed weights of the small-M path)
+    if (pass == PCGAN_PASS_FWD) return align_up((size_t)d->K * RS * round4(d->C) * 4 + RS * round4(d->C) * 16, 256);
     if (pass == PCGAN_PASS_BWD_DATA) {
-        size_t b = align_up((size_t)d->C * RS * round4(d->K) * 4, 256);
+        size_t b = align_up((size_t)d->C * RS * round4(d->K) * 4 + RS * round4(d->K) * 16, 256);
         if (d->pad_mode == 1)
             b += align_up((size_t)d->N * d->C * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * 4, 256);
         return b;
@@ -770,6 +919,13 @@ extern "C" int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const 
     a.nphase = 1;
     PhaseArgs& p = a.ph[0];
     p.A = A; p.Kp = RS * Cgp; p.Hs = d->P; p.Ws = d->Q; p.fy = 0; p.fx = 0;
+    if (d->K <= 4) {  // small-M path reads the weights as [k][4]
+        float* At = A + (size_t)d->K * RS * Cgp;
+        hipLaunchKernelGGL(transpose4_kernel, dim3((RS * Cgp * 4 + 255) / 256), dim3(256), 0, st, (const float*)A, At,
+                           d->K, RS * Cgp);
+        PCGAN_LAUNCH_CHECK();
+        p.A = At;
+    }
     p.r0 = 0; p.s0 = 0; p.nR = d->R; p.nS = d->S; p.Ptot = d->N * d->P * d->Q;
     return d->pad_mode == 1 ? launch_igemm<MODE_FWD_REFLECT>(a, st) : launch_igemm<MODE_FWD_ZERO>(a, st);
 }
@@ -785,10 +941,12 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
     hipStream_t st = (hipStream_t)s;
     const int Kgp = round4(d->K), RS = d->R * d->S;
     float* Abase = (float*)ws;
-    const size_t a_bytes = align_up((size_t)d->C * RS * Kgp * 4, 256);
+    const size_t a_bytes = align_up((size_t)d->C * RS * Kgp * 4 + (size_t)RS * Kgp * 16, 256);
+    const bool smallm = d->C <= 4;
+    size_t at_off = (size_t)d->C * RS * Kgp;  // transposed copies for the small-M path live behind the A's
     // reflection: gather the mirror images directly (fused, needs K % 16 == 0 and H,W >= 2 pad + 2); otherwise
     // compute the gradient of the PADDED input (pad 0 on a larger grid) and fold it back
-    const bool fused = d->pad_mode == 1 && (Kgp % 16) == 0 && d->H >= 2 * d->pad + 2 && d->W >= 2 * d->pad + 2;
+    const bool fused = d->pad_mode == 1 && !smallm && (Kgp % 16) == 0 && d->H >= 2 * d->pad + 2 && d->W >= 2 * d->pad + 2;
     const bool reflect = d->pad_mode == 1 && !fused;
     const int H = reflect ? d->H + 2 * d->pad : d->H;
     const int W = reflect ? d->W + 2 * d->pad : d->W;
@@ -829,6 +987,14 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
             PCGAN_LAUNCH_CHECK();
             PhaseArgs& p = a.ph[a.nphase++];
             p.A = A; p.Kp = nR * nS * Kgp; p.Hs = Hs; p.Ws = Ws; p.fy = fy; p.fx = fx;
+            if (smallm) {
+                float* At = Abase + at_off;
+                at_off += (size_t)nR * nS * Kgp * 4;
+                hipLaunchKernelGGL(transpose4_kernel, dim3((nR * nS * Kgp * 4 + 255) / 256), dim3(256), 0, st,
+                                   (const float*)A, At, d->C, nR * nS * Kgp);
+                PCGAN_LAUNCH_CHECK();
+                p.A = At;
+            }
             p.r0 = r0; p.s0 = s0; p.nR = nR; p.nS = nS; p.Ptot = d->N * Hs * Ws;
         }
     }
@@ -868,6 +1034,18 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
     a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
     a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * 4);
     const int splits = wgrad_splits(d, &a.chunks_per_split);
+    if (smallm_wgrad(d)) {
+        const dim3 sgrid((unsigned)(a.Kp / 16), (unsigned)splits);
+        if (d->pad_mode == 1) hipLaunchKernelGGL((smallm_wgrad_kernel<MODE_FWD_REFLECT>), sgrid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((smallm_wgrad_kernel<MODE_FWD_ZERO>), sgrid, dim3(256), 0, st, a);
+        PCGAN_LAUNCH_CHECK();
+        const size_t total = (size_t)d->K * RS * Cgp;
+        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, d->K, d->C,
+                           Cgp, RS);
+        PCGAN_LAUNCH_CHECK();
+        return 0;
+    }
     const int bm = a.M > 64 ? 128 : (a.M > 32 ? 64 : 32);
     const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((a.Kp + 127) / 128)), (unsigned)splits);
     const bool smallc = (Cgp % 8) != 0;
