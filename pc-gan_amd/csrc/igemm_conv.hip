@@ -392,8 +392,116 @@ __global__ void transpose4_kernel(const float* __restrict__ A, float* __restrict
     }
 }
 
+static constexpr unsigned SM_INV = 0x40000000u;  // row/column marker: any sum with it is >= 1 GiB => out of range
+
+// 64 pixels per workgroup; the 4 waves split the channels of the gathered tensor and are summed through
+// LDS.  Loop order channel -> tap keeps one channel's (R x S) neighbourhood L1-resident across its taps;
+// the separable gather offsets (row part, column part) are tabulated per pixel in LDS once per workgroup.
 template <int MODE>
 __global__ void __launch_bounds__(256) smallm_conv_kernel(IgemmArgs a) {
+    __shared__ unsigned rowoff[12][64], coloff[12][64];
+    __shared__ float red[3][4][64];
+    const PhaseArgs& P = a.ph[blockIdx.y];
+    const int Ptot = P.Ptot;
+    const int p0 = blockIdx.x * 64;
+    if (p0 >= Ptot) return;
+    const int tid = threadIdx.x;
+    const int pl = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = p0 + pl;
+    const bool pvalid = pg < Ptot;
+    const int HsWs = P.Hs * P.Ws, HgWg = a.Hg * a.Wg;
+    int n = 0, py = 0, px = 0;
+    if (pvalid) {
+        n = pg / HsWs;
+        const int rem = pg - n * HsWs;
+        const int sy = rem / P.Ws;
+        py = sy * a.ostep + P.fy;
+        px = (rem - sy * P.Ws) * a.ostep + P.fx;
+    }
+    // separable offset tables (bytes): wave w fills entries w, w+4, w+8 of its pixel lane
+    for (int i = wave; i < P.nR; i += 4) {
+        const int r = P.r0 + i * a.tstep;
+        int iy;
+        bool ok = true;
+        if (MODE == MODE_BWD) {
+            const int ty = py + a.pad - r;
+            iy = ty >> a.sl;
+            ok = ty >= 0 && iy < a.Hg;
+        } else {
+            iy = (py << a.sl) - a.pad + r;
+            if (MODE == MODE_FWD_REFLECT) {
+                iy = iy < 0 ? -iy : iy;
+                iy = iy >= a.Hg ? 2 * (a.Hg - 1) - iy : iy;
+            } else {
+                ok = (unsigned)iy < (unsigned)a.Hg;
+            }
+        }
+        rowoff[i][pl] = ok ? (unsigned)(iy * a.Wg) * 4u : SM_INV;
+    }
+    for (int j = wave; j < P.nS; j += 4) {
+        const int s = P.s0 + j * a.tstep;
+        int ix;
+        bool ok = true;
+        if (MODE == MODE_BWD) {
+            const int tx = px + a.pad - s;
+            ix = tx >> a.sl;
+            ok = tx >= 0 && ix < a.Wg;
+        } else {
+            ix = (px << a.sl) - a.pad + s;
+            if (MODE == MODE_FWD_REFLECT) {
+                ix = ix < 0 ? -ix : ix;
+                ix = ix >= a.Wg ? 2 * (a.Wg - 1) - ix : ix;
+            } else {
+                ok = (unsigned)ix < (unsigned)a.Wg;
+            }
+        }
+        coloff[j][pl] = ok ? (unsigned)ix * 4u : SM_INV;
+    }
+    __syncthreads();
+    const unsigned vbase = pvalid ? (unsigned)(n * a.Cg * HgWg) * 4u : SM_INV;
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
+    const float4* __restrict__ At = reinterpret_cast<const float4*>(P.A);  // [Kp][4]
+    const int cpw = (a.Cg + 3) >> 2;
+    const int c_lo = wave * cpw;
+    const int c_hi = (c_lo + cpw < a.Cg) ? c_lo + cpw : a.Cg;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const unsigned soff = (unsigned)(c * HgWg) * 4u;
+        for (int ri = 0; ri < P.nR; ++ri) {
+            const unsigned ro = vbase + rowoff[ri][pl];
+            const float4* __restrict__ wrow = At + (ri * P.nS) * a.Cgp + c;
+#pragma unroll 4
+            for (int sj = 0; sj < P.nS; ++sj) {
+                const float x = ld_b32(rX, ro + coloff[sj][pl], soff);
+                const float4 w = wrow[sj * a.Cgp];  // wave-uniform address -> scalar load
+                acc0 += x * w.x; acc1 += x * w.y; acc2 += x * w.z; acc3 += x * w.w;
+            }
+        }
+    }
+    if (wave > 0) {
+        red[wave - 1][0][pl] = acc0; red[wave - 1][1][pl] = acc1; red[wave - 1][2][pl] = acc2; red[wave - 1][3][pl] = acc3;
+    }
+    __syncthreads();
+    if (wave > 0 || !pvalid) return;
+    const float out[4] = {acc0 + (red[0][0][pl] + red[1][0][pl]) + red[2][0][pl], acc1 + (red[0][1][pl] + red[1][1][pl]) + red[2][1][pl],
+                          acc2 + (red[0][2][pl] + red[1][2][pl]) + red[2][2][pl], acc3 + (red[0][3][pl] + red[1][3][pl]) + red[2][3][pl]};
+    const int YhYw = a.Yh * a.Yw;
+    float* Yp = a.Y + (size_t)n * a.M * YhYw + py * a.Yw + px;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (m < a.M) {
+            float v = out[m];
+            if (a.bias) v += a.bias[m];
+            Yp[(size_t)m * YhYw] = act_apply(v, a.act, a.slope);
+        }
+    }
+}
+
+// Variant for phases with few taps (<= 9, e.g. the stride phases of 4x4/s2 and 11x11/s4 data gradients): one
+// thread per pixel, tap-outer loop; no tables, no cross-wave reduction.
+template <int MODE>
+__global__ void __launch_bounds__(256) smallm_conv_fewtaps_kernel(IgemmArgs a) {
     const PhaseArgs& P = a.ph[blockIdx.y];
     const int Ptot = P.Ptot;
     if ((int)(blockIdx.x * 256) >= Ptot) return;
@@ -818,7 +926,18 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
     for (int i = 0; i < a.nphase; ++i) pmax = a.ph[i].Ptot > pmax ? a.ph[i].Ptot : pmax;
     if (pmax <= 0 || a.nphase <= 0) return 0;
     if (a.M <= 4) {  // vector-ALU path; ph[].A already holds the transposed [Kp][4] weights
-        const dim3 grid((unsigned)((pmax + 255) / 256), (unsigned)a.nphase);
+        PCGAN_CHECK(a.x_bytes < SM_INV, "small-M conv: gathered tensor must be < 1 GiB");
+        for (int i = 0; i < a.nphase; ++i)
+            PCGAN_CHECK(a.ph[i].nR <= 12 && a.ph[i].nS <= 12, "small-M conv: more than 12 taps per axis");
+        int maxtaps = 0;
+        for (int i = 0; i < a.nphase; ++i) maxtaps = a.ph[i].nR * a.ph[i].nS > maxtaps ? a.ph[i].nR * a.ph[i].nS : maxtaps;
+        if (maxtaps <= 9) {
+            const dim3 g1((unsigned)((pmax + 255) / 256), (unsigned)a.nphase);
+            hipLaunchKernelGGL((smallm_conv_fewtaps_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE)>), g1, dim3(256), 0, st, a);
+            PCGAN_LAUNCH_CHECK();
+            return 0;
+        }
+        const dim3 grid((unsigned)((pmax + 63) / 64), (unsigned)a.nphase);
         hipLaunchKernelGGL((smallm_conv_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE)>), grid, dim3(256), 0, st, a);
         PCGAN_LAUNCH_CHECK();
         return 0;
