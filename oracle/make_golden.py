@@ -148,7 +148,7 @@ def golden_steps(rn, outdir):
         opt = TrainOptions().parse()
         model = create_model(opt)
         model.setup(opt)
-        model.netG.load_state_dict(W.fill_state_dict(model.netG.state_dict(), 19))
+        model.netG.load_state_dict(W.damp_generator_head(W.fill_state_dict(model.netG.state_dict(), 19)))
         model.netD.load_state_dict(W.fill_state_dict(model.netD.state_dict(), 20))
         out = {}
         for it in range(2):

@@ -102,7 +102,7 @@ def build_oracle_step(variant):
     bayes = str(kv.get('bayesian', 'false')).lower() == 'true'
     drop = float(kv.get('bnn_dropout', 0.0))
     G = N.ResnetGeneratorRef(3, 3, 1, 8, 'instance', 9)
-    G.load_state_dict(W.fill_state_dict(G.state_dict(), 19))
+    G.load_state_dict(W.damp_generator_head(W.fill_state_dict(G.state_dict(), 19)))
     D = N.NLayerDiscriminatorRef(3, 1, 8, 3, 'batch', True)
     D.load_state_dict(W.fill_state_dict(D.state_dict(), 20))
     E = N.SiameseFeatureRef(N.ResNetFeatureRef('resnet18', drop), 'avg', (32, 1), 1, 0.7, noisy, drop)
