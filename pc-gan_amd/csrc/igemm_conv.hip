@@ -63,6 +63,7 @@ struct IgemmArgs {
     float slope;
     unsigned x_bytes;
     int nphase;
+    int stagger;  // > 0: waves in odd hardware slots sleep this many 64-cycle units before starting
     PhaseArgs ph[16];
 };
 
@@ -77,7 +78,7 @@ __device__ __forceinline__ bool tap_offset(const Geom& a, int py, int px, int r,
         const int ty = py + a.pad - r, tx = px + a.pad - s;
         const int oy = ty >> a.sl, ox = tx >> a.sl;  // divisible by construction of the phase
         off = oy * a.Wg + ox;
-        return ty >= 0 && tx >= 0 && oy < a.Hg && ox < a.Wg;
+        return (ty >= 0) & (tx >= 0) & (oy < a.Hg) & (ox < a.Wg);  // '&': straight-line code, no branches
     } else {
         int iy = (py << a.sl) - a.pad + r;
         int ix = (px << a.sl) - a.pad + s;
@@ -90,7 +91,7 @@ __device__ __forceinline__ bool tap_offset(const Geom& a, int py, int px, int r,
             return true;
         } else {
             off = iy * a.Wg + ix;
-            return (unsigned)iy < (unsigned)a.Hg && (unsigned)ix < (unsigned)a.Wg;
+            return ((unsigned)iy < (unsigned)a.Hg) & ((unsigned)ix < (unsigned)a.Wg);
         }
     }
 }
@@ -141,9 +142,21 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     const int m0 = mt * BM, p0 = pt * BP;
     const int Ptot = P.Ptot, Kp = P.Kp;
     if (p0 >= Ptot) return;  // phases of unequal size share one grid
+    // phase fields in registers: re-reading them from the kernel-argument segment inside the K loop costs a
+    // scalar load + lgkmcnt(0) per stage, which also drains the LDS operand reads
+    const int ph_r0 = P.r0, ph_s0 = P.s0, ph_nR = P.nR, ph_nS = P.nS, ph_Ws = P.Ws, ph_fy = P.fy, ph_fx = P.fx;
+
+    // De-phase the co-resident workgroups of a CU.  Two workgroups that start together run this loop in
+    // lockstep: both gather, both sit in the LDS-read latency and both reach their barrier at the same time, so
+    // the matrix pipe idles through every stage's non-MFMA part (measured 33 % idle).  The waves in the odd
+    // hardware wave slots of each SIMD (HW_ID[3:0]) start half a stage later, so one workgroup's gather /
+    // barrier phase falls under the other's MFMA phase.  Speed only -- no effect on results.
+    if (a.stagger > 0 && (__builtin_amdgcn_s_getreg(6148) & 1)) {
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
 
     const Geom g{a.Hg, a.Wg, a.sl, a.pad};
-    const int HsWs = P.Hs * P.Ws;
+    const int HsWs = P.Hs * ph_Ws;
     const int HgWg = a.Hg * a.Wg;
     const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(P.A, (unsigned)a.M * (unsigned)Kp * 4u);
@@ -156,10 +169,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     if (pvalid) {
         const int gn = pg / HsWs;
         const int rem = pg - gn * HsWs;
-        const int sy = rem / P.Ws;
-        py = sy * a.ostep + P.fy;
-        px = (rem - sy * P.Ws) * a.ostep + P.fx;
-        vbase = gn * a.Cg * HgWg;
+        const int sy = rem / ph_Ws;
+        py = sy * a.ostep + ph_fy;
+        px = (rem - sy * ph_Ws) * a.ostep + ph_fx;
+        vbase = (a.stagger < 0 ? 0 : gn) * a.Cg * HgWg;  // stagger < 0: timing experiment, all images alias image 0
     }
     // MODE_BWD_REFLECT: padded-grid index of the mirror image of this pixel's row / column (-1: none).
     // Padded row j holds input row reflect(j - pad); row py therefore also appears at j = pad - py when
@@ -174,19 +187,26 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);  // which KPT-slice of the stage this wave gathers
 
     KIter it{0, 0, 0};
-    if (!CG16) it.advance(ksub * KPT, a.Cgp, P.nS);
+    if (!CG16) it.advance(ksub * KPT, a.Cgp, ph_nS);
 
     float4 areg[ACH];
     float breg[KPT];
+    bool a_ok[ACH];
+    unsigned a_off[ACH];
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) {
+        const int q = tid + 256 * j;
+        const int row = q >> 2, kc = (q & 3) * 4;
+        a_ok[j] = (row < BM) & (m0 + row < a.M);
+        a_off[j] = (unsigned)((m0 + row) * Kp + kc) * 4u;
+    }
     float bmir[MODE == MODE_BWD_REFLECT ? 3 : 1][MODE == MODE_BWD_REFLECT ? KPT : 1];  // mirror-image gathers
 
     auto load_stage = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
-            const int q = tid + 256 * j;
-            const int row = q >> 2, kc = (q & 3) * 4;
-            const bool ok = row < BM && m0 + row < a.M && k0 + kc < Kp;
-            areg[j] = ld_b128(rA, ok ? (unsigned)((m0 + row) * Kp + k0 + kc) * 4u : OOB);
+            const int kc = ((tid + 256 * j) & 3) * 4;
+            areg[j] = ld_b128(rA, (a_ok[j] & (k0 + kc < Kp)) ? a_off[j] + (unsigned)k0 * 4u : OOB);
         }
         if (CG16 && MODE == MODE_BWD_REFLECT) {
             // Data gradient of ReflectionPad2d(pad)+conv (stride 1), gathered directly on the UNPADDED grid:
@@ -195,7 +215,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             // wave-uniform votes when no lane of the wave needs them (rows: only waves touching the
             // mirrored rows; columns: the two mirrored columns of every row).
             unsigned v00 = OOB, v01 = OOB, v10 = OOB, v11 = OOB;
-            if (it.ri < P.nR && pvalid) {
+            if (it.ri < ph_nR && pvalid) {
                 const int r = it.ri, s = it.sj;
                 const int ya = py + a.pad - r, yb = myr - r, xa = px + a.pad - s, xb = mxr - s;
                 const bool oya = (unsigned)ya < (unsigned)a.Hg, oyb = myr >= 0 && (unsigned)yb < (unsigned)a.Hg;
@@ -235,7 +255,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             it.c += 16;
             if (it.c == a.Cgp) {
                 it.c = 0;
-                if (++it.sj == P.nS) {
+                if (++it.sj == ph_nS) {
                     it.sj = 0;
                     ++it.ri;
                 }
@@ -243,25 +263,23 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             return;
         }
         if (CG16) {
-            // whole stage inside tap (it.ri, it.sj); this wave gathers channels it.c + ksub*KPT + i
-            unsigned voff = OOB;
-            if (it.ri < P.nR) {
-                int off;
-                const bool ok = tap_offset<MODE>(g, py, px, P.r0 + it.ri * a.tstep, P.s0 + it.sj * a.tstep, off);
-                voff = (ok && pvalid) ? (unsigned)(vbase + off) * 4u : OOB;
-            }
+            // whole stage inside tap (it.ri, it.sj); this wave gathers channels it.c + ksub*KPT + i.
+            // Written with selects only (no branches) so the stage body stays ONE basic block and the
+            // scheduler can spread these instructions between the MFMAs.
+            int off;
+            const bool ok = tap_offset<MODE>(g, py, px, ph_r0 + it.ri * a.tstep, ph_s0 + it.sj * a.tstep, off);
+            const unsigned voff = (ok & pvalid & (it.ri < ph_nR)) ? (unsigned)(vbase + off) * 4u : OOB;
             const int c0 = it.c + ksub * KPT;
 #pragma unroll
             for (int i = 0; i < KPT; ++i)
-                breg[i] = (c0 + i < a.Cg) ? ld_b32(rX, voff, (unsigned)((c0 + i) * HgWg) * 4u) : 0.f;
-            it.c += 16;
-            if (it.c == a.Cgp) {
-                it.c = 0;
-                if (++it.sj == P.nS) {
-                    it.sj = 0;
-                    ++it.ri;
-                }
-            }
+                breg[i] = ld_b32(rX, (c0 + i < a.Cg) ? voff : OOB, (unsigned)((c0 + i) * HgWg) * 4u);
+            const int c1 = it.c + 16;
+            const bool wc = c1 == a.Cgp;
+            it.c = wc ? 0 : c1;
+            const int s1 = it.sj + (wc ? 1 : 0);
+            const bool ws = s1 == ph_nS;
+            it.sj = ws ? 0 : s1;
+            it.ri += ws ? 1 : 0;
             return;
         }
         KIter e = it;
@@ -270,23 +288,23 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         for (int i = 0; i < KPT; ++i) {
             if (i == 0 || e.c == 0) {  // wave-uniform: the tap changed
                 voff = OOB;
-                if (e.ri < P.nR) {
+                if (e.ri < ph_nR) {
                     int off;
-                    const bool ok = tap_offset<MODE>(g, py, px, P.r0 + e.ri * a.tstep, P.s0 + e.sj * a.tstep, off);
+                    const bool ok = tap_offset<MODE>(g, py, px, ph_r0 + e.ri * a.tstep, ph_s0 + e.sj * a.tstep, off);
                     voff = (ok && pvalid) ? (unsigned)(vbase + off) * 4u : OOB;
                 }
             }
             breg[i] = (e.c < a.Cg) ? ld_b32(rX, voff, (unsigned)(e.c * HgWg) * 4u) : 0.f;
-            e.advance(1, a.Cgp, P.nS);
+            e.advance(1, a.Cgp, ph_nS);
         }
-        it.advance(16, a.Cgp, P.nS);
+        it.advance(16, a.Cgp, ph_nS);
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int q = tid + 256 * j;
             const int row = q >> 2, kc = (q & 3) * 4;
-            if (row < BM) *reinterpret_cast<float4*>(&As[buf][row * AP + kc]) = areg[j];
+            if (BM * 4 >= 256 || row < BM) *reinterpret_cast<float4*>(&As[buf][row * AP + kc]) = areg[j];
         }
         if (MODE == MODE_BWD_REFLECT) {
 #pragma unroll
@@ -307,35 +325,93 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nst = (Kp + 15) / 16;
+    float av0[MI][4], bv0[PJ][4], av1[MI][4], bv1[PJ][4];
+    auto read_ops = [&](int buf, int q, float (&av)[MI][4], float (&bv)[PJ][4]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(&As[buf][(wm * WMT + i * 32 + lo) * AP + (2 * q + hi) * 4]);
+            av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(&Bs[buf][((2 * q + hi) * BP + wp * WPT + j * 32 + lo) * 4]);
+            bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
+        }
+    };
+    auto mfma_group = [&](const float (&av)[MI][4], const float (&bv)[PJ][4], int jj0) {
+#pragma unroll
+        for (int jj = jj0; jj < jj0 + 2; ++jj)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < PJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][jj], bv[j][jj], acc[i][j], 0, 0, 0);
+    };
+    // Software pipeline inside ONE wave (co-resident workgroups run in lockstep, so a wave cannot count on
+    // its SIMD partner to cover its own non-MFMA work): the MFMA chain of a stage is cut into four groups and
+    // the next stage's global gathers, the second half's LDS operand reads and the address arithmetic are issued
+    // BETWEEN the groups, i.e. in the shadow of matrix instructions that are already executing.
+    // sched_barrier(0) pins that order against the compiler's own clustering.
     load_stage(0);
     store_stage(0);
     __syncthreads();
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nst) load_stage((st + 1) * 16);
+    read_ops(0, 0, av0, bv0);
+    if (CG16 && MODE != MODE_BWD_REFLECT) {
+        // One basic block per stage; the directive sequence below asks the scheduler for
+        //   MFMA, then a few VALU/SALU (gather address arithmetic), one gather load, one LDS operand read
+        // per matrix instruction, so the non-MFMA work of the NEXT stage is issued while matrix instructions
+        // of THIS stage execute (a wave cannot issue past an MFMA that is waiting for the pipe: only
+        // fine-grained interleaving hides that work).
+        constexpr int NMFMA = MI * PJ * 8;
+        for (int st = 0; st + 1 < nst; ++st) {
+            const int buf = st & 1;
+            read_ops(buf, 1, av1, bv1);
+            load_stage((st + 1) * 16);
+            mfma_group(av0, bv0, 0);
+            mfma_group(av0, bv0, 2);
+            mfma_group(av1, bv1, 0);
+            mfma_group(av1, bv1, 2);
+            // first third of the chain: LDS operand reads + all gather loads (they need >= ~1000 cycles to
+            // land before the LDS write at the end); rest: left-over scalar/vector bookkeeping; LDS writes last
+            constexpr int NLD = ACH + KPT;
+            constexpr int LGAPS = NMFMA >= 24 ? 12 : (NMFMA >= 16 ? 8 : 4);   // gaps that carry gather loads
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            float av[MI][4], bv[PJ][4];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const float4 t = *reinterpret_cast<const float4*>(&As[buf][(wm * WMT + i * 32 + lo) * AP + (2 * q + hi) * 4]);
-                av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+            for (int gI = 0; gI < NMFMA; ++gI) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        // 1 MFMA
+                if (gI < MI + PJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // LDS read
+                if (gI < LGAPS) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                    // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);                                    // SALU
+                    __builtin_amdgcn_sched_group_barrier(0x020, (NLD + LGAPS - 1) / LGAPS, 0);            // gathers
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+                }
             }
-#pragma unroll
-            for (int j = 0; j < PJ; ++j) {
-                const float4 t = *reinterpret_cast<const float4*>(&Bs[buf][((2 * q + hi) * BP + wp * WPT + j * 32 + lo) * 4]);
-                bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
-            }
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < PJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][jj], bv[j][jj], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // every MFMA of the stage is issued before the LDS hand-over
+            store_stage(buf ^ 1);
+            __syncthreads();
+            read_ops(buf ^ 1, 0, av0, bv0);
         }
-        if (st + 1 < nst) store_stage(buf ^ 1);
-        __syncthreads();
+        read_ops((nst - 1) & 1, 1, av1, bv1);
+        mfma_group(av0, bv0, 0);
+        mfma_group(av0, bv0, 2);
+        mfma_group(av1, bv1, 0);
+        mfma_group(av1, bv1, 2);
+    } else {
+        for (int st = 0; st < nst; ++st) {
+            const int buf = st & 1;
+            const bool more = st + 1 < nst;
+            read_ops(buf, 1, av1, bv1);
+            if (more) load_stage((st + 1) * 16);
+            mfma_group(av0, bv0, 0);
+            mfma_group(av0, bv0, 2);
+            mfma_group(av1, bv1, 0);
+            mfma_group(av1, bv1, 2);
+            if (more) store_stage(buf ^ 1);
+            __syncthreads();
+            if (more) read_ops(buf ^ 1, 0, av0, bv0);
+        }
     }
 
     // --- epilogue: bias + activation, NCHW store (pixel on the lane -> coalesced) -----
@@ -346,9 +422,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         if (pix >= Ptot) continue;
         const int n = pix / HsWs;
         const int rem = pix - n * HsWs;
-        const int sy = rem / P.Ws;
-        const int oy = sy * a.ostep + P.fy;
-        const int ox = (rem - sy * P.Ws) * a.ostep + P.fx;
+        const int sy = rem / ph_Ws;
+        const int oy = sy * a.ostep + ph_fy;
+        const int ox = (rem - sy * ph_Ws) * a.ostep + ph_fx;
         float* Yp = a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -944,6 +1020,10 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
     }
     int bm, bp;
     choose_tile(a.M, pmax, a.nphase, &bm, &bp);
+    {
+        const char* env = getenv("PCGAN_STAGGER");
+        const_cast<IgemmArgs&>(a).stagger = env ? atoi(env) : 0;
+    }
     const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((pmax + bp - 1) / bp)), (unsigned)a.nphase);
     const bool cg16 = (a.Cgp % 16) == 0;
     PCGAN_CHECK(cg16 || MODE != MODE_BWD_REFLECT, "igemm: fused reflect data-gradient needs K %% 16 == 0");
