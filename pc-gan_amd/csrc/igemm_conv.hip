@@ -20,6 +20,7 @@
 // Reference call sites replaced: see include/pcgan_hip.h.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace pcgan {
 
@@ -202,7 +203,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     }
     float bmir[MODE == MODE_BWD_REFLECT ? 3 : 1][MODE == MODE_BWD_REFLECT ? KPT : 1];  // mirror-image gathers
 
-    auto load_stage = [&](int k0) {
+    auto load_stage = [&](int k0, auto nm_tag) {
+        constexpr int NM = decltype(nm_tag)::value;
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int kc = ((tid + 256 * j) & 3) * 4;
@@ -211,55 +213,36 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         if (CG16 && MODE == MODE_BWD_REFLECT) {
             // Data gradient of ReflectionPad2d(pad)+conv (stride 1), gathered directly on the UNPADDED grid:
             // input row py collects the padded rows {py+pad} U {its mirror image, if py is within pad of an
-            // edge}; same for columns => up to 2x2 sources per tap.  The extra loads are skipped by
-            // wave-uniform votes when no lane of the wave needs them (rows: only waves touching the
-            // mirrored rows; columns: the two mirrored columns of every row).
-            unsigned v00 = OOB, v01 = OOB, v10 = OOB, v11 = OOB;
-            if (it.ri < ph_nR && pvalid) {
-                const int r = it.ri, s = it.sj;
-                const int ya = py + a.pad - r, yb = myr - r, xa = px + a.pad - s, xb = mxr - s;
-                const bool oya = (unsigned)ya < (unsigned)a.Hg, oyb = myr >= 0 && (unsigned)yb < (unsigned)a.Hg;
-                const bool oxa = (unsigned)xa < (unsigned)a.Wg, oxb = mxr >= 0 && (unsigned)xb < (unsigned)a.Wg;
-                v00 = (oya && oxa) ? (unsigned)(vbase + ya * a.Wg + xa) * 4u : OOB;
-                v01 = (oya && oxb) ? (unsigned)(vbase + ya * a.Wg + xb) * 4u : OOB;
-                v10 = (oyb && oxa) ? (unsigned)(vbase + yb * a.Wg + xa) * 4u : OOB;
-                v11 = (oyb && oxb) ? (unsigned)(vbase + yb * a.Wg + xb) * 4u : OOB;
-            }
-            // all loads are issued back to back into separate registers and only summed when the stage is
-            // written to LDS (after the MFMA phase), so the mirror loads add issue slots, not latency
-            const bool any01 = __any(v01 != OOB), any10 = __any(v10 != OOB), any11 = __any(v11 != OOB);
+            // edge}; same for columns => up to 2x2 sources per tap.  NM (compile time, chosen per workgroup)
+            // says which mirror sets exist: 1 = column mirrors only, 3 = row, column and corner mirrors.
+            // Straight-line code; all loads land in separate registers and are summed at the LDS write.
+            const int r = it.ri, sx = it.sj;
+            const int ya = py + a.pad - r, yb = myr - r, xa = px + a.pad - sx, xb = mxr - sx;
+            const bool base = pvalid & (it.ri < ph_nR);
+            const bool oya = base & ((unsigned)ya < (unsigned)a.Hg), oyb = base & (myr >= 0) & ((unsigned)yb < (unsigned)a.Hg);
+            const bool oxa = (unsigned)xa < (unsigned)a.Wg, oxb = (mxr >= 0) & ((unsigned)xb < (unsigned)a.Wg);
+            const unsigned v00 = (oya & oxa) ? (unsigned)(vbase + ya * a.Wg + xa) * 4u : OOB;
+            const unsigned v01 = (oya & oxb) ? (unsigned)(vbase + ya * a.Wg + xb) * 4u : OOB;
+            const unsigned v10 = (oyb & oxa) ? (unsigned)(vbase + yb * a.Wg + xa) * 4u : OOB;
+            const unsigned v11 = (oyb & oxb) ? (unsigned)(vbase + yb * a.Wg + xb) * 4u : OOB;
             const int c0 = it.c + ksub * KPT;
 #pragma unroll
-            for (int i = 0; i < KPT; ++i) breg[i] = ld_b32(rX, v00, (unsigned)((c0 + i) * HgWg) * 4u);
-            if (any01) {
-#pragma unroll
-                for (int i = 0; i < KPT; ++i) bmir[0][i] = ld_b32(rX, v01, (unsigned)((c0 + i) * HgWg) * 4u);
-            } else {
-#pragma unroll
-                for (int i = 0; i < KPT; ++i) bmir[0][i] = 0.f;
-            }
-            if (any10) {
-#pragma unroll
-                for (int i = 0; i < KPT; ++i) bmir[1][i] = ld_b32(rX, v10, (unsigned)((c0 + i) * HgWg) * 4u);
-            } else {
-#pragma unroll
-                for (int i = 0; i < KPT; ++i) bmir[1][i] = 0.f;
-            }
-            if (any11) {
-#pragma unroll
-                for (int i = 0; i < KPT; ++i) bmir[2][i] = ld_b32(rX, v11, (unsigned)((c0 + i) * HgWg) * 4u);
-            } else {
-#pragma unroll
-                for (int i = 0; i < KPT; ++i) bmir[2][i] = 0.f;
-            }
-            it.c += 16;
-            if (it.c == a.Cgp) {
-                it.c = 0;
-                if (++it.sj == ph_nS) {
-                    it.sj = 0;
-                    ++it.ri;
+            for (int i = 0; i < KPT; ++i) {
+                const unsigned so = (unsigned)((c0 + i) * HgWg) * 4u;
+                breg[i] = ld_b32(rX, v00, so);
+                if (NM >= 1) bmir[0][i] = ld_b32(rX, v01, so);
+                if (NM >= 3) {
+                    bmir[1][i] = ld_b32(rX, v10, so);
+                    bmir[2][i] = ld_b32(rX, v11, so);
                 }
             }
+            const int c1 = it.c + 16;
+            const bool wc = c1 == a.Cgp;
+            it.c = wc ? 0 : c1;
+            const int s1 = it.sj + (wc ? 1 : 0);
+            const bool ws = s1 == ph_nS;
+            it.sj = ws ? 0 : s1;
+            it.ri += ws ? 1 : 0;
             return;
         }
         if (CG16) {
@@ -299,14 +282,18 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         }
         it.advance(16, a.Cgp, ph_nS);
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, auto nm_tag) {
+        constexpr int NM = decltype(nm_tag)::value;
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int q = tid + 256 * j;
             const int row = q >> 2, kc = (q & 3) * 4;
             if (BM * 4 >= 256 || row < BM) *reinterpret_cast<float4*>(&As[buf][row * AP + kc]) = areg[j];
         }
-        if (MODE == MODE_BWD_REFLECT) {
+        if (NM == 1) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) breg[i] += bmir[0][i];
+        } else if (NM == 3) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) breg[i] += (bmir[0][i] + bmir[1][i]) + bmir[2][i];
         }
@@ -352,66 +339,77 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     // the next stage's global gathers, the second half's LDS operand reads and the address arithmetic are issued
     // BETWEEN the groups, i.e. in the shadow of matrix instructions that are already executing.
     // sched_barrier(0) pins that order against the compiler's own clustering.
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    read_ops(0, 0, av0, bv0);
-    if (CG16 && MODE != MODE_BWD_REFLECT) {
-        // One basic block per stage; the directive sequence below asks the scheduler for
-        //   MFMA, then a few VALU/SALU (gather address arithmetic), one gather load, one LDS operand read
-        // per matrix instruction, so the non-MFMA work of the NEXT stage is issued while matrix instructions
-        // of THIS stage execute (a wave cannot issue past an MFMA that is waiting for the pipe: only
-        // fine-grained interleaving hides that work).
-        constexpr int NMFMA = MI * PJ * 8;
-        for (int st = 0; st + 1 < nst; ++st) {
-            const int buf = st & 1;
-            read_ops(buf, 1, av1, bv1);
-            load_stage((st + 1) * 16);
-            mfma_group(av0, bv0, 0);
-            mfma_group(av0, bv0, 2);
-            mfma_group(av1, bv1, 0);
-            mfma_group(av1, bv1, 2);
-            // first third of the chain: LDS operand reads + all gather loads (they need >= ~1000 cycles to
-            // land before the LDS write at the end); rest: left-over scalar/vector bookkeeping; LDS writes last
-            constexpr int NLD = ACH + KPT;
+    auto run = [&](auto nm_tag) {
+        constexpr int NM = decltype(nm_tag)::value;
+        load_stage(0, nm_tag);
+        store_stage(0, nm_tag);
+        __syncthreads();
+        read_ops(0, 0, av0, bv0);
+        if (CG16) {
+            // One basic block per stage; the directive sequence below asks the scheduler for
+            //   MFMA, then a few VALU/SALU (gather address arithmetic), gather loads, one LDS operand read
+            // per matrix instruction, so the non-MFMA work of the NEXT stage is issued while matrix
+            // instructions of THIS stage execute (a wave cannot issue past an MFMA that is waiting for the
+            // pipe: only fine-grained interleaving hides that work).
+            constexpr int NMFMA = MI * PJ * 8;
+            constexpr int NLD = ACH + KPT * (1 + NM);
             constexpr int LGAPS = NMFMA >= 24 ? 12 : (NMFMA >= 16 ? 8 : 4);   // gaps that carry gather loads
+            for (int st = 0; st + 1 < nst; ++st) {
+                const int buf = st & 1;
+                read_ops(buf, 1, av1, bv1);
+                load_stage((st + 1) * 16, nm_tag);
+                mfma_group(av0, bv0, 0);
+                mfma_group(av0, bv0, 2);
+                mfma_group(av1, bv1, 0);
+                mfma_group(av1, bv1, 2);
+                // first third of the chain: LDS operand reads + all gather loads (they need >= ~1000 cycles
+                // to land before the LDS write at the end); rest: left-over bookkeeping; LDS writes last
 #pragma unroll
-            for (int gI = 0; gI < NMFMA; ++gI) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        // 1 MFMA
-                if (gI < MI + PJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // LDS read
-                if (gI < LGAPS) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                    // VALU
-                    __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);                                    // SALU
-                    __builtin_amdgcn_sched_group_barrier(0x020, (NLD + LGAPS - 1) / LGAPS, 0);            // gathers
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+                for (int gI = 0; gI < NMFMA; ++gI) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // 1 MFMA
+                    if (gI < MI + PJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // LDS read
+                    if (gI < LGAPS) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                          // VALU
+                        __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);                          // SALU
+                        __builtin_amdgcn_sched_group_barrier(0x020, (NLD + LGAPS - 1) / LGAPS, 0);  // gathers
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);   // every MFMA of the stage is issued before the LDS hand-over
+                store_stage(buf ^ 1, nm_tag);
+                __syncthreads();
+                read_ops(buf ^ 1, 0, av0, bv0);
             }
-            __builtin_amdgcn_sched_barrier(0);   // every MFMA of the stage is issued before the LDS hand-over
-            store_stage(buf ^ 1);
-            __syncthreads();
-            read_ops(buf ^ 1, 0, av0, bv0);
-        }
-        read_ops((nst - 1) & 1, 1, av1, bv1);
-        mfma_group(av0, bv0, 0);
-        mfma_group(av0, bv0, 2);
-        mfma_group(av1, bv1, 0);
-        mfma_group(av1, bv1, 2);
-    } else {
-        for (int st = 0; st < nst; ++st) {
-            const int buf = st & 1;
-            const bool more = st + 1 < nst;
-            read_ops(buf, 1, av1, bv1);
-            if (more) load_stage((st + 1) * 16);
+            read_ops((nst - 1) & 1, 1, av1, bv1);
             mfma_group(av0, bv0, 0);
             mfma_group(av0, bv0, 2);
             mfma_group(av1, bv1, 0);
             mfma_group(av1, bv1, 2);
-            if (more) store_stage(buf ^ 1);
-            __syncthreads();
-            if (more) read_ops(buf ^ 1, 0, av0, bv0);
+        } else {
+            for (int st = 0; st < nst; ++st) {
+                const int buf = st & 1;
+                const bool more = st + 1 < nst;
+                read_ops(buf, 1, av1, bv1);
+                if (more) load_stage((st + 1) * 16, nm_tag);
+                mfma_group(av0, bv0, 0);
+                mfma_group(av0, bv0, 2);
+                mfma_group(av1, bv1, 0);
+                mfma_group(av1, bv1, 2);
+                if (more) store_stage(buf ^ 1, nm_tag);
+                __syncthreads();
+                if (more) read_ops(buf ^ 1, 0, av0, bv0);
+            }
         }
+    };
+    if (MODE == MODE_BWD_REFLECT && CG16) {
+        // row mirrors exist only in workgroups that touch rows 1..pad or H-1-pad..H-2 (a workgroup-uniform,
+        // loop-invariant fact): those run the 4-source loop, the others the 2-source loop
+        if (__syncthreads_or(myr >= 0)) run(std::integral_constant<int, 3>{});
+        else run(std::integral_constant<int, 1>{});
+    } else {
+        run(std::integral_constant<int, 0>{});
     }
 
     // --- epilogue: bias + activation, NCHW store (pixel on the lane -> coalesced) -----
