@@ -751,8 +751,12 @@ __global__ void reflect_fold_kernel(const float* __restrict__ t, float* __restri
 // pixels.  LDS rows hold 32 pixels of one m / one kcol at pitch 36 floats (ds_read_b128 conflict-free);
 // the MFMA consumes the pixels in the same permuted order for both operands.
 // VECA: dY planes are a multiple of 4 pixels, so a thread fetches 4 consecutive pixels with one 16-byte load.
-template <int MODE, int BM, bool SMALLC, bool VECA>
+// KMODE: 0 = generic (Cgp % 8 == 0), 1 = SMALLC (per-thread tap), 2 = ONETAP (Cgp % 128 == 0: the whole 128-column
+// tile lies inside one filter tap -> one spatial offset per stage, straight-line code, interleaved schedule)
+template <int MODE, int BM, int KMODE, bool VECA>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+    constexpr bool SMALLC = KMODE == 1;
+    constexpr bool ONETAP = KMODE == 2;
     constexpr int BN = 128;
     constexpr int WM = (BM == 128) ? 2 : 1;
     constexpr int WN = 4 / WM;
@@ -794,35 +798,43 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
             const int pc = (tid & 7) * 4;  // same pixel quad for all of this thread's rows
             const int pg = chunk * 32 + pc;
             unsigned vb = OOB;
-            if (pg < a.Ptot) {
+            {
                 const int n = pg / HoWo;
-                vb = (unsigned)((n * a.M + m0) * HoWo + (pg - n * HoWo)) * 4u;
+                const unsigned vv = (unsigned)((n * a.M + m0) * HoWo + (pg - n * HoWo)) * 4u;
+                vb = (pg < a.Ptot) ? vv : OOB;
             }
 #pragma unroll
             for (int j = 0; j < AV; ++j) {
                 const int row = (tid >> 3) + 32 * j;
-                const float4 v = ld_b128(rY, (vb != OOB && m0 + row < a.M) ? vb + (unsigned)(row * HoWo) * 4u : OOB);
+                const float4 v = ld_b128(rY, ((vb != OOB) & (m0 + row < a.M)) ? vb + (unsigned)(row * HoWo) * 4u : OOB);
                 areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
             }
         }
         // ---- this thread's gather pixel ------------------------------------------------
         const int pg = chunk * 32 + pl;
         const bool pvalid = pg < a.Ptot;
-        int n = 0, oy = 0, ox = 0, rem = 0;
-        if (pvalid) {
-            n = pg / HoWo;
-            rem = pg - n * HoWo;
-            oy = rem / a.Wo;
-            ox = rem - oy * a.Wo;
-        }
+        // (computed for out-of-range pixels too: selects instead of branches keep the stage one basic block)
+        const int n = pg / HoWo;
+        const int rem = pg - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
         if (!VECA) {
             const unsigned vb = pvalid ? (unsigned)((n * a.M + m0 + rg) * HoWo + rem) * 4u : OOB;
 #pragma unroll
             for (int i = 0; i < AR; ++i)
-                areg[i] = ld_b32(rY, (pvalid && m0 + rg + 8 * i < a.M) ? vb : OOB, (unsigned)(8 * i * HoWo) * 4u);
+                areg[i] = ld_b32(rY, (pvalid & (m0 + rg + 8 * i < a.M)) ? vb : OOB, (unsigned)(8 * i * HoWo) * 4u);
         }
         const int vbase = n * a.Cg * HgWg;
-        if (!SMALLC) {
+        if (ONETAP) {
+            const int r = (tap_b * a.magicS) >> 16;
+            const int s = tap_b - r * a.S;
+            int off;
+            const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off) & pvalid;
+            const unsigned voff = ok ? (unsigned)(vbase + off + rg * HgWg) * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                breg[i] = ld_b32(rX, (c_b + 8 * i + rg < a.Cg) ? voff : OOB, (unsigned)((c_b + 8 * i) * HgWg) * 4u);
+        } else if (!SMALLC) {
             int tap = tap_b, c = c_b;
             unsigned voff = OOB;
 #pragma unroll
@@ -831,10 +843,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
                     const int r = (tap * a.magicS) >> 16;
                     const int s = tap - r * a.S;
                     int off;
-                    const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off) && pvalid;
+                    const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off) & pvalid;
                     voff = ok ? (unsigned)(vbase + off + rg * HgWg) * 4u : OOB;
                 }
-                const bool okc = (c + rg < a.Cg) && (kb + 8 * i + rg < a.Kp);
+                const bool okc = (c + rg < a.Cg) & (kb + 8 * i + rg < a.Kp);
                 breg[i] = ld_b32(rX, okc ? voff : OOB, (unsigned)(c * HgWg) * 4u);
                 c += 8;
                 if (c >= a.Cgp) {
@@ -886,9 +898,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
         load_stage(c_begin);
         store_stage(0);
         __syncthreads();
-        for (int st = 0; st < nst; ++st) {
-            const int buf = st & 1;
-            if (st + 1 < nst) load_stage(c_begin + st + 1);
+        auto compute = [&](int buf) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float av[MI][4], bv[NJ][4];
@@ -910,9 +920,35 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
                         for (int j = 0; j < NJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][jj], bv[j][jj], acc[i][j], 0, 0, 0);
             }
-            if (st + 1 < nst) store_stage(buf ^ 1);
+        };
+        // same fine-grained interleave as the forward kernel: the next stage's gathers and their address
+        // arithmetic are issued between this stage's MFMAs (a wave cannot issue past a waiting MFMA)
+        constexpr int NMFMA = MI * NJ * 16;
+        constexpr int NLD = (VECA ? AV : AR) + BR;
+        for (int st = 0; st + 1 < nst; ++st) {
+            const int buf = st & 1;
+            load_stage(c_begin + st + 1);
+            compute(buf);
+            if (ONETAP) {
+#pragma unroll
+                for (int gI = 0; gI < NMFMA; ++gI) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (gI < 4 * (MI + NJ)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (gI < NMFMA / 2) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, (NLD + NMFMA / 2 - 1) / (NMFMA / 2), 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            store_stage(buf ^ 1);
             __syncthreads();
         }
+        compute((nst - 1) & 1);
     }
     // partial tile store: row = m, column = k (lane) -> coalesced
     float* Wp = a.Wp + (size_t)split * a.M * a.Kp;
@@ -1248,9 +1284,10 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
     const bool smallc = (Cgp % 8) != 0;
     const bool reflect = d->pad_mode == 1;
     const bool veca = ((d->P * d->Q) % 4) == 0;
-#define LW(MODE, BMV, SC, VA) hipLaunchKernelGGL((wgrad_kernel<MODE, BMV, SC, VA>), grid, dim3(256), 0, st, a)
-#define LW_VA(MODE, BMV, SC) do { if (veca) LW(MODE, BMV, SC, true); else LW(MODE, BMV, SC, false); } while (0)
-#define LW_SC(MODE, BMV) do { if (smallc) LW_VA(MODE, BMV, true); else LW_VA(MODE, BMV, false); } while (0)
+    const int kmode = smallc ? 1 : ((Cgp % 128) == 0 ? 2 : 0);
+#define LW(MODE, BMV, KM, VA) hipLaunchKernelGGL((wgrad_kernel<MODE, BMV, KM, VA>), grid, dim3(256), 0, st, a)
+#define LW_VA(MODE, BMV, KM) do { if (veca) LW(MODE, BMV, KM, true); else LW(MODE, BMV, KM, false); } while (0)
+#define LW_SC(MODE, BMV) do { if (kmode == 1) LW_VA(MODE, BMV, 1); else if (kmode == 2) LW_VA(MODE, BMV, 2); else LW_VA(MODE, BMV, 0); } while (0)
 #define LW_BM(MODE) do { if (bm == 128) LW_SC(MODE, 128); else if (bm == 64) LW_SC(MODE, 64); else LW_SC(MODE, 32); } while (0)
     if (reflect) LW_BM(MODE_FWD_REFLECT); else LW_BM(MODE_FWD_ZERO);
 #undef LW_BM
