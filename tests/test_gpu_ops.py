@@ -35,6 +35,20 @@ CONV_CASES = [
     ('e3x3_k1', 3, 32, 7, 7, 1, 3, 1, 1, 0),
     ('e3x3_s2_odd', 2, 16, 14, 14, 24, 3, 2, 1, 0),
     ('c192', 1, 192, 13, 13, 96, 3, 1, 1, 0),
+    # small-M paths (<= 4 image channels on the gradient side / <= 4 output channels) at the real channel counts
+    ('e7x7_s2_c3_k64', 2, 3, 36, 36, 64, 7, 2, 3, 0),
+    ('ip11x11_s4_c3_k64', 2, 3, 51, 51, 64, 11, 4, 2, 0),
+    ('stem7x7_reflect_c4_k64_b', 2, 4, 24, 24, 64, 7, 1, 3, 1),
+    ('d4x4_s2_c4_k64', 2, 4, 32, 32, 64, 4, 2, 1, 0),
+    ('head7x7_reflect_64_3', 2, 64, 24, 24, 3, 7, 1, 3, 1),
+    ('d4x4_s1_512_1', 2, 512, 15, 15, 1, 4, 1, 1, 0),
+    ('e3x3_32_1', 3, 32, 7, 7, 1, 3, 1, 1, 0),
+    # tiny feature maps of the encoder's late stages (fewer pixels than one tile, several stride phases)
+    ('l3a_3x3_s2_128_256_8', 3, 128, 8, 8, 256, 3, 2, 1, 0),
+    ('ds1x1_s2_128_256_8', 3, 128, 8, 8, 256, 1, 2, 0, 0),
+    ('l3_3x3_256_4', 3, 256, 4, 4, 256, 3, 1, 1, 0),
+    ('l4a_3x3_s2_256_512_4', 3, 256, 4, 4, 512, 3, 2, 1, 0),
+    ('l4_3x3_512_2', 3, 512, 2, 2, 512, 3, 1, 1, 0),
 ]
 
 
