@@ -65,6 +65,8 @@ struct IgemmArgs {
     unsigned x_bytes;
     int nphase;
     int stagger;  // > 0: waves in odd hardware slots sleep this many 64-cycle units before starting
+    int ksplit;   // > 1: blockIdx.z takes a contiguous range of K stages and stores a raw partial sum
+    float* Ypart; // [ksplit][N][M][Yh][Yw] partial sums (then reduced + bias + activation by splitk_reduce)
     PhaseArgs ph[16];
 };
 
@@ -187,8 +189,21 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     }
     const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);  // which KPT-slice of the stage this wave gathers
 
+    // K-stage range of this workgroup (split-K: small problems are cut along K to fill the 256 CUs)
+    const int nst_all = (Kp + 15) / 16;
+    const int nst_per = a.ksplit > 1 ? (nst_all + a.ksplit - 1) / a.ksplit : nst_all;
+    const int st_begin = a.ksplit > 1 ? (int)blockIdx.z * nst_per : 0;
+    const int st_end = st_begin + nst_per < nst_all ? st_begin + nst_per : nst_all;
+
     KIter it{0, 0, 0};
-    if (!CG16) it.advance(ksub * KPT, a.Cgp, ph_nS);
+    if (CG16) {
+        const int tap0 = (st_begin * 16) / a.Cgp;
+        it.c = st_begin * 16 - tap0 * a.Cgp;
+        it.ri = tap0 / ph_nS;
+        it.sj = tap0 - it.ri * ph_nS;
+    } else {
+        it.advance(st_begin * 16 + ksub * KPT, a.Cgp, ph_nS);
+    }
 
     float4 areg[ACH];
     float breg[KPT];
@@ -311,7 +326,6 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nst = (Kp + 15) / 16;
     float av0[MI][4], bv0[PJ][4], av1[MI][4], bv1[PJ][4];
     auto read_ops = [&](int buf, int q, float (&av)[MI][4], float (&bv)[PJ][4]) {
 #pragma unroll
@@ -341,7 +355,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     // sched_barrier(0) pins that order against the compiler's own clustering.
     auto run = [&](auto nm_tag) {
         constexpr int NM = decltype(nm_tag)::value;
-        load_stage(0, nm_tag);
+        if (st_begin >= st_end) return;  // empty K range (split-K tail): accumulators stay zero, stored below
+        load_stage(st_begin * 16, nm_tag);
         store_stage(0, nm_tag);
         __syncthreads();
         read_ops(0, 0, av0, bv0);
@@ -354,8 +369,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             constexpr int NMFMA = MI * PJ * 8;
             constexpr int NLD = ACH + KPT * (1 + NM);
             constexpr int LGAPS = NMFMA >= 24 ? 12 : (NMFMA >= 16 ? 8 : 4);   // gaps that carry gather loads
-            for (int st = 0; st + 1 < nst; ++st) {
-                const int buf = st & 1;
+            for (int st = st_begin; st + 1 < st_end; ++st) {
+                const int buf = (st - st_begin) & 1;
                 read_ops(buf, 1, av1, bv1);
                 load_stage((st + 1) * 16, nm_tag);
                 mfma_group(av0, bv0, 0);
@@ -382,15 +397,15 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
                 __syncthreads();
                 read_ops(buf ^ 1, 0, av0, bv0);
             }
-            read_ops((nst - 1) & 1, 1, av1, bv1);
+            read_ops((st_end - 1 - st_begin) & 1, 1, av1, bv1);
             mfma_group(av0, bv0, 0);
             mfma_group(av0, bv0, 2);
             mfma_group(av1, bv1, 0);
             mfma_group(av1, bv1, 2);
         } else {
-            for (int st = 0; st < nst; ++st) {
-                const int buf = st & 1;
-                const bool more = st + 1 < nst;
+            for (int st = st_begin; st < st_end; ++st) {
+                const int buf = (st - st_begin) & 1;
+                const bool more = st + 1 < st_end;
                 read_ops(buf, 1, av1, bv1);
                 if (more) load_stage((st + 1) * 16, nm_tag);
                 mfma_group(av0, bv0, 0);
@@ -423,6 +438,18 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         const int sy = rem / ph_Ws;
         const int oy = sy * a.ostep + ph_fy;
         const int ox = (rem - sy * ph_Ws) * a.ostep + ph_fx;
+        if (a.ksplit > 1) {  // raw partial sum; bias / activation happen in splitk_reduce_kernel
+            float* Yp = a.Ypart + ((size_t)blockIdx.z * a.N + n) * a.M * YhYw + oy * a.Yw + ox;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (m < a.M) Yp[(size_t)m * YhYw] = acc[i][j][r];
+                }
+            }
+            continue;
+        }
         float* Yp = a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -686,6 +713,34 @@ __global__ void __launch_bounds__(256) smallm_wgrad_kernel(WgradArgs a) {
         const int m = tid >> 4, j = tid & 15;
         if (m < a.M && kb + j < a.Kp)
             a.Wp[((size_t)blockIdx.y * a.M + m) * a.Kp + kb + j] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
+// y = act( sum_s part[s] + bias[channel] ) over the split-K partial sums
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ y, const float* __restrict__ bias,
+                                     int ks, size_t n, int M, int HW, int act, float slope) {
+    const size_t n4 = (n & 3) ? 0 : (n >> 2);  // 16-byte path only when every split's base stays aligned
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 acc = reinterpret_cast<const float4*>(part)[i];
+        for (int s = 1; s < ks; ++s) {
+            const float4 v = reinterpret_cast<const float4*>(part + (size_t)s * n)[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t e = i * 4 + u;
+            if (bias) o[u] += bias[(e / HW) % M];
+            o[u] = act_apply(o[u], act, slope);
+        }
+        reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    for (size_t e = (n4 << 2) + blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += stride) {
+        float acc = 0.f;
+        for (int s = 0; s < ks; ++s) acc += part[(size_t)s * n + e];
+        if (bias) acc += bias[(e / HW) % M];
+        y[e] = act_apply(acc, act, slope);
     }
 }
 
@@ -1010,13 +1065,34 @@ static int check_desc(const pcgan_conv_desc* d) {
     return 0;
 }
 
-// tile choice: the largest tile that still gives the 256 CUs >= ~1.5 workgroups each
-static void choose_tile(int M, int ptot_max, int nphase, int* bm, int* bp) {
+// tile choice: the largest tile that still gives the 256 CUs >= ~1.5 workgroups each; problems with few
+// pixels but a long K loop (the encoder's 7x7 / 14x14 stages, the PatchGAN's 16x16 stage) keep the big tile
+// and are cut along K instead (split-K, partial sums reduced by splitk_reduce_kernel)
+static inline long tile_blocks(int M, int ptot_max, int nphase, int mm, int pp) {
+    return (long)((M + mm - 1) / mm) * ((ptot_max + pp - 1) / pp) * nphase;
+}
+static inline bool may_split(int M, int ptot_max, int nphase) {
+    const int m = M > 64 ? 128 : (M > 32 ? 64 : 32);
+    return M > 4 && tile_blocks(M, ptot_max, nphase, m, 128) < 192;
+}
+static void choose_tile(int M, int ptot_max, int nphase, int nst, bool allow_split, int* bm, int* bp, int* ks) {
     int m = M > 64 ? 128 : (M > 32 ? 64 : 32);
     int p = 128;
-    auto blocks = [&](int mm, int pp) { return (long)((M + mm - 1) / mm) * ((ptot_max + pp - 1) / pp) * nphase; };
-    if (m >= 64 && blocks(m, p) < 384) p = 64;
-    if (m == 128 && blocks(m, p) < 384) m = 64;
+    *ks = 1;
+    if (allow_split && may_split(M, ptot_max, nphase) && nst >= 32) {
+        const long b = tile_blocks(M, ptot_max, nphase, m, 128);
+        int k = (int)(512 / b);
+        if (k > 8) k = 8;
+        if (k > nst / 8) k = nst / 8;
+        if (k >= 2) {
+            *bm = m;
+            *bp = 128;
+            *ks = k;
+            return;
+        }
+    }
+    if (m >= 64 && tile_blocks(M, ptot_max, nphase, m, p) < 384) p = 64;
+    if (m == 128 && tile_blocks(M, ptot_max, nphase, m, p) < 384) m = 64;
     const char* env = getenv("PCGAN_TILE");  // experiments: "BM,BP"
     if (env) {
         int em = 0, ep = 0;
@@ -1031,7 +1107,7 @@ static void choose_tile(int M, int ptot_max, int nphase, int* bm, int* bp) {
 }
 
 template <int MODE>
-static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
+static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, size_t part_bytes = 0) {
     int pmax = 0;
     for (int i = 0; i < a.nphase; ++i) pmax = a.ph[i].Ptot > pmax ? a.ph[i].Ptot : pmax;
     if (pmax <= 0 || a.nphase <= 0) return 0;
@@ -1052,13 +1128,19 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
         PCGAN_LAUNCH_CHECK();
         return 0;
     }
-    int bm, bp;
-    choose_tile(a.M, pmax, a.nphase, &bm, &bp);
+    int bm, bp, ks;
+    int nst_min = 1 << 30;
+    for (int i = 0; i < a.nphase; ++i) nst_min = (a.ph[i].Kp + 15) / 16 < nst_min ? (a.ph[i].Kp + 15) / 16 : nst_min;
+    const size_t out_elems = (size_t)a.N * a.M * a.Yh * a.Yw;
+    choose_tile(a.M, pmax, a.nphase, nst_min, part_ws != nullptr, &bm, &bp, &ks);
+    if (ks > 1 && (size_t)ks * out_elems * 4 > part_bytes) ks = 1;
+    a.ksplit = ks;
+    a.Ypart = part_ws;
     {
         const char* env = getenv("PCGAN_STAGGER");
-        const_cast<IgemmArgs&>(a).stagger = env ? atoi(env) : 0;
+        a.stagger = env ? atoi(env) : 0;
     }
-    const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((pmax + bp - 1) / bp)), (unsigned)a.nphase);
+    const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((pmax + bp - 1) / bp)), (unsigned)a.nphase, (unsigned)ks);
     const bool cg16 = (a.Cgp % 16) == 0;
     PCGAN_CHECK(cg16 || MODE != MODE_BWD_REFLECT, "igemm: fused reflect data-gradient needs K %% 16 == 0");
 #define LI(BMV, BPV)                                                                                   \
@@ -1075,6 +1157,14 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
     else LI(32, 128);
 #undef LI
     PCGAN_LAUNCH_CHECK();
+    if (ks > 1) {
+        size_t b = (out_elems / 4 + 255) / 256;
+        if (b > 4096) b = 4096;
+        if (b < 1) b = 1;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, (const float*)part_ws, a.Y, a.bias, ks,
+                           out_elems, a.M, a.Yh * a.Yw, a.act, a.slope);
+        PCGAN_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -1096,7 +1186,9 @@ static int wgrad_splits(const pcgan_conv_desc* d, int* chunks_per_split) {
     const int tiles = ((d->K + bm - 1) / bm) * ((Kp + 127) / 128);
     const int Ptot = d->N * d->P * d->Q;
     const int chunks = (Ptot + 31) / 32;
-    int splits = (1024 + tiles - 1) / tiles;
+    int target = 1024;
+    if (const char* env = getenv("PCGAN_WGRAD_BLOCKS")) target = atoi(env) > 0 ? atoi(env) : target;
+    int splits = (target + tiles - 1) / tiles;
     if (splits > chunks / 8) splits = chunks / 8;  // at least 8 stages of work per block
     if (splits < 1) splits = 1;
     if (splits > 512) splits = 512;
@@ -1110,13 +1202,30 @@ static int wgrad_splits(const pcgan_conv_desc* d, int* chunks_per_split) {
 
 using namespace pcgan;
 
+// room for split-K partial sums (upper bound: 8 splits), 0 when the problem never splits
+static size_t fwd_part_bytes(const pcgan_conv_desc* d) {
+    const int ptot = d->N * d->P * d->Q;
+    return may_split(d->K, ptot, 1) ? align_up((size_t)8 * d->N * d->K * d->P * d->Q * 4, 256) : 0;
+}
+static size_t bwd_part_bytes(const pcgan_conv_desc* d) {
+    const int s = d->stride;
+    const int pmax = d->N * ((d->H + s - 1) / s) * ((d->W + s - 1) / s);
+    return may_split(d->C, pmax, s * s) ? align_up((size_t)8 * d->N * d->C * d->H * d->W * 4, 256) : 0;
+}
+static size_t fwd_base_bytes(const pcgan_conv_desc* d) {
+    // A matrix (+ RS*C*16 bytes: room for the [k][4] transposed weights of the small-M path)
+    return align_up((size_t)d->K * d->R * d->S * round4(d->C) * 4 + (size_t)d->R * d->S * round4(d->C) * 16, 256);
+}
+static size_t bwd_base_bytes(const pcgan_conv_desc* d) {
+    return align_up((size_t)d->C * d->R * d->S * round4(d->K) * 4 + (size_t)d->R * d->S * round4(d->K) * 16, 256);
+}
+
 extern "C" size_t pcgan_conv2d_workspace_bytes(const pcgan_conv_desc* d, int pass) {
     if (!d) return 0;
     const size_t RS = (size_t)d->R * d->S;
-    // (+ RS*C*16 bytes: room for the [k][4] transposed weights of the small-M path)
-    if (pass == PCGAN_PASS_FWD) return align_up((size_t)d->K * RS * round4(d->C) * 4 + RS * round4(d->C) * 16, 256);
+    if (pass == PCGAN_PASS_FWD) return fwd_base_bytes(d) + fwd_part_bytes(d);
     if (pass == PCGAN_PASS_BWD_DATA) {
-        size_t b = align_up((size_t)d->C * RS * round4(d->K) * 4 + RS * round4(d->K) * 16, 256);
+        size_t b = bwd_base_bytes(d) + bwd_part_bytes(d);
         if (d->pad_mode == 1)
             b += align_up((size_t)d->N * d->C * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * 4, 256);
         return b;
@@ -1160,7 +1269,9 @@ extern "C" int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const 
         p.A = At;
     }
     p.r0 = 0; p.s0 = 0; p.nR = d->R; p.nS = d->S; p.Ptot = d->N * d->P * d->Q;
-    return d->pad_mode == 1 ? launch_igemm<MODE_FWD_REFLECT>(a, st) : launch_igemm<MODE_FWD_ZERO>(a, st);
+    float* part = fwd_part_bytes(d) ? (float*)((char*)ws + fwd_base_bytes(d)) : nullptr;
+    return d->pad_mode == 1 ? launch_igemm<MODE_FWD_REFLECT>(a, st, part, fwd_part_bytes(d))
+                            : launch_igemm<MODE_FWD_ZERO>(a, st, part, fwd_part_bytes(d));
 }
 
 extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, const float* w,
@@ -1174,7 +1285,7 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
     hipStream_t st = (hipStream_t)s;
     const int Kgp = round4(d->K), RS = d->R * d->S;
     float* Abase = (float*)ws;
-    const size_t a_bytes = align_up((size_t)d->C * RS * Kgp * 4 + (size_t)RS * Kgp * 16, 256);
+    const size_t a_bytes = bwd_base_bytes(d);
     const bool smallm = d->C <= 4;
     size_t at_off = (size_t)d->C * RS * Kgp;  // transposed copies for the small-M path live behind the A's
     // reflection: gather the mirror images directly (fused, needs K % 16 == 0 and H,W >= 2 pad + 2); otherwise
@@ -1237,7 +1348,10 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
         hipError_t e = hipMemsetAsync(out, 0, (size_t)d->N * d->C * H * W * 4, st);
         PCGAN_CHECK(e == hipSuccess, "memset failed: %s", hipGetErrorString(e));
     }
-    if (fused ? launch_igemm<MODE_BWD_REFLECT>(a, st) : launch_igemm<MODE_BWD>(a, st)) return 2;
+    // split-K partials live behind the A matrices (not with the padded-grid fallback or uncovered phases)
+    float* part = (bwd_part_bytes(d) && !reflect && !need_zero) ? (float*)((char*)ws + a_bytes) : nullptr;
+    if (fused ? launch_igemm<MODE_BWD_REFLECT>(a, st, part, bwd_part_bytes(d)) : launch_igemm<MODE_BWD>(a, st, part, bwd_part_bytes(d)))
+        return 2;
     if (reflect) {
         const size_t total = (size_t)d->N * d->C * d->H * d->W;
         const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
