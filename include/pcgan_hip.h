@@ -128,6 +128,16 @@ int pcgan_norm_bwd_apply(const float* dy, const float* x, const float* y, const 
                          int act, float slope, pcgan_stream_t s);
 int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, float* s2_c, int N, int C,
                         pcgan_stream_t s);
+/* Fused instance norm (the generator's 23 norm sites per pass, models/networks.py:580-601,633,646): the
+ * (n,c) plane stays in registers, so forward = one read + one write (statistics + normalise + residual +
+ * activation; mean / M2 are also returned for the backward and the running-stat update) and backward = one
+ * read of dy, x (and y for the activation mask) + one write.  Planes that do not fit (HW % 4 != 0 or
+ * HW > 65536) fall back to the two-pass kernels above; ws_s1s2 (2*N*C floats) is only used then. */
+int pcgan_instnorm_fwd(const float* x, const float* residual, float* y, float* mean_nc, float* m2_nc, int N, int C,
+                       int HW, float eps, int act, float slope, pcgan_stream_t s);
+int pcgan_instnorm_bwd(const float* dy, const float* x, const float* y, const float* mean_nc, const float* m2_nc,
+                       float* dx, float* ws_s1s2, int N, int C, int HW, float eps, int act, float slope,
+                       pcgan_stream_t s);
 
 /* ---- pooling / resize ------------------------------------------------------------
  * MaxPool2d(k, stride, pad)   models/resnet.py:138 ; models/networks.py:1225-1235

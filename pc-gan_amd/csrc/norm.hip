@@ -50,19 +50,24 @@ __global__ void __launch_bounds__(256) plane_stats_kernel(const float* __restric
     }
 }
 
+// one wave per channel: lanes stride over the N plane statistics, shuffle-reduce (was one thread per channel
+// walking N entries serially: 18 us of pure latency per call)
 __global__ void bn_merge_kernel(const float* __restrict__ mean_nc, const float* __restrict__ m2_nc,
                                 float* __restrict__ mean_c, float* __restrict__ var_c, float* running_mean,
                                 float* running_var, int N, int C, int HW, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
+    const int lane = threadIdx.x & 63;
     float msum = 0.f;
-    for (int n = 0; n < N; ++n) msum += mean_nc[n * C + c];
-    const float mean = msum / (float)N;
+    for (int n = lane; n < N; n += 64) msum += mean_nc[n * C + c];
+    const float mean = wave_sum(msum) / (float)N;
     float m2 = 0.f;
-    for (int n = 0; n < N; ++n) {
+    for (int n = lane; n < N; n += 64) {
         const float d = mean_nc[n * C + c] - mean;
         m2 += m2_nc[n * C + c] + d * d * (float)HW;
     }
+    m2 = wave_sum(m2);
+    if (lane != 0) return;
     const float cnt = (float)N * (float)HW;
     if (mean_c) mean_c[c] = mean;
     if (var_c) var_c[c] = m2 / cnt;
@@ -73,16 +78,22 @@ __global__ void bn_merge_kernel(const float* __restrict__ mean_nc, const float* 
 __global__ void in_running_kernel(const float* __restrict__ mean_nc, const float* __restrict__ m2_nc,
                                   float* running_mean, float* running_var, int N, int C, int HW,
                                   float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
+    const int lane = threadIdx.x & 63;
+    const float rm = running_mean[c], rv = running_var[c];
     float ms = 0.f, vs = 0.f;
-    for (int n = 0; n < N; ++n) {
+    for (int n = lane; n < N; n += 64) {
         // each of the N copies is updated, then averaged (torch instance_norm semantics)
-        ms += (1.f - momentum) * running_mean[c] + momentum * mean_nc[n * C + c];
-        vs += (1.f - momentum) * running_var[c] + momentum * (m2_nc[n * C + c] / (float)(HW - 1));
+        ms += (1.f - momentum) * rm + momentum * mean_nc[n * C + c];
+        vs += (1.f - momentum) * rv + momentum * (m2_nc[n * C + c] / (float)(HW - 1));
     }
-    running_mean[c] = ms / (float)N;
-    running_var[c] = vs / (float)N;
+    ms = wave_sum(ms);
+    vs = wave_sum(vs);
+    if (lane == 0) {
+        running_mean[c] = ms / (float)N;
+        running_var[c] = vs / (float)N;
+    }
 }
 
 struct NormArgs {
@@ -168,15 +179,20 @@ __global__ void __launch_bounds__(256) norm_bwd_stats_kernel(NormArgs a) {
 
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ s1_nc, const float* __restrict__ s2_nc,
                                      float* __restrict__ s1_c, float* __restrict__ s2_c, int N, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
+    const int lane = threadIdx.x & 63;
     float a = 0.f, b = 0.f;
-    for (int n = 0; n < N; ++n) {
+    for (int n = lane; n < N; n += 64) {
         a += s1_nc[n * C + c];
         b += s2_nc[n * C + c];
     }
-    s1_c[c] = a;
-    s2_c[c] = b;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+        s1_c[c] = a;
+        s2_c[c] = b;
+    }
 }
 
 __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(NormArgs a) {
@@ -201,6 +217,121 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(NormArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused instance norm: the whole (n,c) plane lives in the workgroup's registers, so forward is ONE read
+// + ONE write (statistics, normalise, residual, activation) and backward ONE read of dy/x(/y) + ONE write.
+// T threads x E float4 per thread cover planes up to T*E*4 elements (HW % 4 == 0).
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__global__ void __launch_bounds__(1024) instnorm_fwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                   float* __restrict__ y, float* __restrict__ mean_nc,
+                                                                   float* __restrict__ m2_nc, int HW, float eps, int act,
+                                                                   float slope) {
+    __shared__ float scratch[16];
+    const size_t plane = blockIdx.x;
+    const int T = blockDim.x, n4 = HW >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + plane * (size_t)HW);
+    float4 v[E];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = threadIdx.x + k * T;
+        v[k] = i < n4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mean = block_sum(s, scratch) / (float)HW;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        if (threadIdx.x + k * T < n4) {
+            const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float m2 = block_sum(q, scratch);
+    const float rstd = rsqrtf(m2 / (float)HW + eps);
+    const float sh = -mean * rstd;
+    const float4* r4 = res ? reinterpret_cast<const float4*>(res + plane * (size_t)HW) : nullptr;
+    float4* y4 = reinterpret_cast<float4*>(y + plane * (size_t)HW);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = threadIdx.x + k * T;
+        if (i < n4) {
+            float4 o = make_float4(v[k].x * rstd + sh, v[k].y * rstd + sh, v[k].z * rstd + sh, v[k].w * rstd + sh);
+            if (r4) {
+                const float4 r = r4[i];
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            o.x = act_apply(o.x, act, slope); o.y = act_apply(o.y, act, slope);
+            o.z = act_apply(o.z, act, slope); o.w = act_apply(o.w, act, slope);
+            y4[i] = o;
+        }
+    }
+    if (threadIdx.x == 0) {
+        mean_nc[plane] = mean;
+        m2_nc[plane] = m2;
+    }
+}
+
+template <int E>
+__global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   const float* __restrict__ y, const float* __restrict__ mean_nc,
+                                                                   const float* __restrict__ m2_nc, float* __restrict__ dx, int HW,
+                                                                   float eps, int act, float slope) {
+    __shared__ float scratch[16];
+    const size_t plane = blockIdx.x;
+    const int T = blockDim.x, n4 = HW >> 2;
+    const float mean = mean_nc[plane];
+    const float rstd = rsqrtf(m2_nc[plane] / (float)HW + eps);
+    const float4* d4 = reinterpret_cast<const float4*>(dy + plane * (size_t)HW);
+    const float4* x4 = reinterpret_cast<const float4*>(x + plane * (size_t)HW);
+    const float4* y4 = (act != PCGAN_ACT_NONE) ? reinterpret_cast<const float4*>(y + plane * (size_t)HW) : nullptr;
+    float4 g[E], xh[E];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = threadIdx.x + k * T;
+        if (i < n4) {
+            g[k] = d4[i];
+            const float4 xv = x4[i];
+            if (y4) {
+                const float4 yv = y4[i];
+                g[k].x *= act_grad_from_out(yv.x, act, slope); g[k].y *= act_grad_from_out(yv.y, act, slope);
+                g[k].z *= act_grad_from_out(yv.z, act, slope); g[k].w *= act_grad_from_out(yv.w, act, slope);
+            }
+            xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            s1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+            s2 += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+        } else {
+            g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[k] = g[k];
+        }
+    }
+    s1 = block_sum(s1, scratch);
+    s2 = block_sum(s2, scratch);
+    const float m1 = s1 / (float)HW, mm2 = s2 / (float)HW;
+    float4* o4 = reinterpret_cast<float4*>(dx + plane * (size_t)HW);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = threadIdx.x + k * T;
+        if (i < n4)
+            o4[i] = make_float4(rstd * (g[k].x - m1 - xh[k].x * mm2), rstd * (g[k].y - m1 - xh[k].y * mm2),
+                                rstd * (g[k].z - m1 - xh[k].z * mm2), rstd * (g[k].w - m1 - xh[k].w * mm2));
+    }
+}
+
+// (threads, float4-per-thread) for a plane of HW elements; E == 0: plane too large / not a multiple of 4
+static inline void fused_plan(int HW, int* T, int* E) {
+    *T = 0;
+    *E = 0;
+    if (HW & 3) return;
+    const int n4 = HW >> 2;
+    if (n4 <= 256) { *T = n4 <= 64 ? 64 : (n4 <= 128 ? 128 : 256); *E = 1; }
+    else if (n4 <= 1024) { *T = 256; *E = 4; }
+    else if (n4 <= 4096) { *T = 1024; *E = 4; }
+    else if (n4 <= 16384) { *T = 1024; *E = 16; }
+}
+
 static inline int plane_threads(int HW) { return HW >= 1024 ? 256 : (HW >= 256 ? 128 : 64); }
 
 }  // namespace pcgan
@@ -219,7 +350,7 @@ extern "C" int pcgan_bn_merge(const float* mean_nc, const float* m2_nc, float* m
                               float* running_mean, float* running_var, int N, int C, int HW, float momentum,
                               pcgan_stream_t s) {
     PCGAN_CHECK(mean_nc && m2_nc && N > 0 && C > 0 && HW > 0, "bn_merge: bad arguments");
-    hipLaunchKernelGGL(bn_merge_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, mean_nc, m2_nc, mean_c,
+    hipLaunchKernelGGL(bn_merge_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)s, mean_nc, m2_nc, mean_c,
                        var_c, running_mean, running_var, N, C, HW, momentum);
     PCGAN_LAUNCH_CHECK();
     return 0;
@@ -230,7 +361,7 @@ extern "C" int pcgan_in_running_update(const float* mean_nc, const float* m2_nc,
                                        pcgan_stream_t s) {
     PCGAN_CHECK(mean_nc && m2_nc && running_mean && running_var && N > 0 && C > 0 && HW > 1,
                 "in_running_update: bad arguments");
-    hipLaunchKernelGGL(in_running_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, mean_nc, m2_nc,
+    hipLaunchKernelGGL(in_running_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)s, mean_nc, m2_nc,
                        running_mean, running_var, N, C, HW, momentum);
     PCGAN_LAUNCH_CHECK();
     return 0;
@@ -266,7 +397,7 @@ extern "C" int pcgan_norm_bwd_stats(const float* dy, const float* x, const float
 extern "C" int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, float* s2_c, int N, int C,
                                    pcgan_stream_t s) {
     PCGAN_CHECK(s1_nc && s2_nc && s1_c && s2_c, "bn_bwd_reduce: null pointer");
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, s1_nc, s2_nc, s1_c,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)s, s1_nc, s2_nc, s1_c,
                        s2_c, N, C);
     PCGAN_LAUNCH_CHECK();
     return 0;
@@ -285,6 +416,45 @@ extern "C" int pcgan_norm_bwd_apply(const float* dy, const float* x, const float
     a.N = N; a.C = C; a.HW = HW; a.per_plane = per_plane; a.eps = eps; a.act = act; a.slope = slope;
     a.inv_cnt = 1.f / (per_plane ? (float)HW : (float)N * (float)HW);
     hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s, a);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_instnorm_fwd(const float* x, const float* residual, float* y, float* mean_nc, float* m2_nc, int N,
+                                  int C, int HW, float eps, int act, float slope, pcgan_stream_t s) {
+    PCGAN_CHECK(x && y && mean_nc && m2_nc && N > 0 && C > 0 && HW > 0, "instnorm_fwd: bad arguments");
+    int T, E;
+    fused_plan(HW, &T, &E);
+    hipStream_t st = (hipStream_t)s;
+    if (E == 0) {  // plane does not fit the register-resident kernel: statistics pass + apply pass
+        if (pcgan_plane_stats(x, mean_nc, m2_nc, N * C, HW, s)) return 1;
+        return pcgan_norm_act_fwd(x, mean_nc, m2_nc, nullptr, nullptr, residual, y, N, C, HW, 1, eps, act, slope, s);
+    }
+    if (E == 1) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<1>), dim3(N * C), dim3(T), 0, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope);
+    else if (E == 4) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<4>), dim3(N * C), dim3(T), 0, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope);
+    else hipLaunchKernelGGL((instnorm_fwd_fused_kernel<16>), dim3(N * C), dim3(T), 0, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_instnorm_bwd(const float* dy, const float* x, const float* y, const float* mean_nc,
+                                  const float* m2_nc, float* dx, float* ws_s1s2, int N, int C, int HW, float eps, int act,
+                                  float slope, pcgan_stream_t s) {
+    PCGAN_CHECK(dy && x && mean_nc && m2_nc && dx, "instnorm_bwd: null pointer");
+    PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "instnorm_bwd: activation mask needs y");
+    int T, E;
+    fused_plan(HW, &T, &E);
+    hipStream_t st = (hipStream_t)s;
+    if (E == 0) {
+        PCGAN_CHECK(ws_s1s2, "instnorm_bwd: the two-pass fallback needs 2*N*C floats of workspace");
+        if (pcgan_norm_bwd_stats(dy, x, y, mean_nc, m2_nc, ws_s1s2, ws_s1s2 + (size_t)N * C, N, C, HW, 1, eps, act, slope, s))
+            return 1;
+        return pcgan_norm_bwd_apply(dy, x, y, mean_nc, m2_nc, nullptr, ws_s1s2, ws_s1s2 + (size_t)N * C, dx, nullptr, N, C,
+                                    HW, 1, eps, act, slope, s);
+    }
+    if (E == 1) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1>), dim3(N * C), dim3(T), 0, st, dy, x, y, mean_nc, m2_nc, dx, HW, eps, act, slope);
+    else if (E == 4) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<4>), dim3(N * C), dim3(T), 0, st, dy, x, y, mean_nc, m2_nc, dx, HW, eps, act, slope);
+    else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<16>), dim3(N * C), dim3(T), 0, st, dy, x, y, mean_nc, m2_nc, dx, HW, eps, act, slope);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

@@ -89,11 +89,13 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 __global__ void sum_over_n_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per channel
     if (c >= C) return;
+    const int lane = threadIdx.x & 63;
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s += part[n * C + c];
-    out[c] = s;
+    for (int n = lane; n < N; n += 64) s += part[n * C + c];
+    s = wave_sum(s);
+    if (lane == 0) out[c] = s;
 }
 
 __global__ void channel_scale_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y,
@@ -159,7 +161,7 @@ extern "C" int pcgan_channel_sum(const float* x, float* out, float* scratch_nc, 
     hipLaunchKernelGGL(plane_sum_kernel, dim3(N * C), dim3(HW >= 1024 ? 256 : 64), 0, (hipStream_t)s, x, scratch_nc,
                        HW);
     PCGAN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_over_n_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, scratch_nc, out, N, C);
+    hipLaunchKernelGGL(sum_over_n_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)s, scratch_nc, out, N, C);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

@@ -92,13 +92,13 @@ class _InstanceNormActFn(torch.autograd.Function):
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         if training or running_mean is None:
-            mean, var = ops.plane_stats(x)          # var holds the plane M2
+            y, mean, var = ops.instnorm_fwd(x, residual, eps, act, slope)    # var holds the plane M2
             per_plane = True
             if training and running_mean is not None:
                 ops.in_running_update(mean, var, running_mean, running_var, N, C, HW, momentum)
         else:
             mean, var, per_plane = running_mean, running_var, False
-        y = ops.norm_act_fwd(x, mean, var, None, None, residual, per_plane, eps, act, slope)
+            y = ops.norm_act_fwd(x, mean, var, None, None, residual, per_plane, eps, act, slope)
         ctx.cfg = (eps, act, slope, per_plane, residual is not None)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, var)
         return y
@@ -111,12 +111,9 @@ class _InstanceNormActFn(torch.autograd.Function):
             raise NotImplementedError('pcgan_amd: backward through eval-mode InstanceNorm is not on the hot path')
         dy = _c(dy)
         dx = dres = None
-        want_res = has_res and ctx.needs_input_grad[1]
         if ctx.needs_input_grad[0]:
-            s1, s2 = ops.norm_bwd_stats(dy, x, y, mean, var, True, eps, act, slope)
-            dx, dres = ops.norm_bwd_apply(dy, x, y, mean, var, None, s1, s2, True, eps, act, slope,
-                                          want_res and act != ACT_NONE)
-        if want_res and dres is None:
+            dx = ops.instnorm_bwd(dy, x, y, mean, var, eps, act, slope)
+        if has_res and ctx.needs_input_grad[1]:
             dres = dy if act == ACT_NONE else ops.act_bwd(dy, y, act, slope)
         return dx, dres, None, None, None, None, None, None, None
 

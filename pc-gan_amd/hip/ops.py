@@ -222,6 +222,30 @@ def norm_bwd_apply(dy, x, y, mean, var, gamma, s1, s2, per_plane, eps, act, slop
     return dx, dres
 
 
+def instnorm_fwd(x, residual, eps, act, slope):
+    """fused instance norm forward: returns y, mean[N*C], m2[N*C]"""
+    _chk(x, residual)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    y = torch.empty_like(x)
+    mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    m2 = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().pcgan_instnorm_fwd(_p(x), _p(residual), _p(y), _p(mean), _p(m2), N, C, HW, float(eps), act,
+                                          float(slope), _stream()), 'instnorm_fwd')
+    return y, mean, m2
+
+
+def instnorm_bwd(dy, x, y, mean, m2, eps, act, slope):
+    _chk(dy, x, y, mean, m2)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    dx = torch.empty_like(x)
+    ws = torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().pcgan_instnorm_bwd(_p(dy), _p(x), _p(y), _p(mean), _p(m2), _p(dx), _p(ws), N, C, HW, float(eps),
+                                          act, float(slope), _stream()), 'instnorm_bwd')
+    return dx
+
+
 # ---------------------------------------------------------------- pooling / resize
 def maxpool_fwd(x, k, stride, pad):
     _chk(x)

@@ -160,7 +160,33 @@ def test_instance_norm(shape, act, slope, res, dev):
         assert_close(dres, r64.grad, 1e-6, 'instnorm residual grad')
 
 
-@pytest.mark.parametrize('shape', [(4, 8, 16, 16), (3, 5, 7, 7), (2, 16, 64, 64)])
+@pytest.mark.parametrize('shape', [(2, 8, 32, 32), (3, 5, 7, 7), (2, 4, 128, 128), (1, 2, 256, 256), (2, 6, 15, 15),
+                                   (2, 3, 64, 64), (2, 3, 8, 8)])
+@pytest.mark.parametrize('act,res', [(0, False), (1, False), (0, True)])
+def test_instance_norm_fused(shape, act, res, dev):
+    """register-resident single-pass kernels (and their two-pass fallback for planes that are not a multiple of 4)"""
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(shape, generator=g) * 1.5 + 0.3
+    r = torch.randn(shape, generator=g) if res else None
+    x64 = x.double().requires_grad_(True)
+    y64 = R.instance_norm(x64)
+    if res:
+        y64 = y64 + r.double()
+    y64 = R.activation(y64, act)
+    dy = torch.randn(shape, generator=g)
+    y64.backward(dy.double())
+    xd = x.to(dev)
+    y, mean, m2 = ops.instnorm_fwd(xd, r.to(dev) if res else None, 1e-5, act, 0.0)
+    assert_close(y, y64, 2e-5, 'fused instnorm fwd')
+    mean_ref, m2_ref = ops.plane_stats(xd)
+    assert_close(mean, mean_ref, 1e-5, 'fused mean', atol=1e-6)
+    assert_close(m2, m2_ref, 1e-5, 'fused M2')
+    dx = ops.instnorm_bwd(dy.to(dev), xd, y, mean, m2, 1e-5, act, 0.0)
+    assert_close(dx, x64.grad, 5e-5, 'fused instnorm bwd')
+
+
+@pytest.mark.parametrize('shape', [(4, 8, 16, 16), (3, 5, 7, 7), (2, 16, 64, 64), (40, 3, 4, 4), (70, 5, 2, 2)])
 @pytest.mark.parametrize('act,slope,res', [(2, 0.2, False), (1, 0.0, True), (2, 0.7, False), (0, 0.0, False)])
 def test_batch_norm_train(shape, act, slope, res, dev):
     from pcgan_amd.hip import ops
