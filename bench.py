@@ -128,11 +128,12 @@ def main():
     world, rank, local = parallel.init_process_group()
     assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
+    dev_index = local % torch.cuda.device_count()   # (one GPU per rank on a real node; a 1-GPU box can only rehearse)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
 
     tmpdir = tempfile.mkdtemp(prefix='pcgan_bench_')
-    model, opt = build_model(local, PER_GPU_BATCH, SIZE, tmpdir)
+    model, opt = build_model(dev_index, PER_GPU_BATCH, SIZE, tmpdir)
     batches = [synthetic_batch(PER_GPU_BATCH, SIZE, rank, it) for it in range(2)]
     # inputs resident in HBM before the timed region (set_input's .to(device) is then a no-op copy)
     batches = [{k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in b.items()} for b in batches]

@@ -28,11 +28,11 @@ def init_process_group(backend=None):
         return world, rank, local
     if not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('PCGAN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local
 
@@ -56,10 +56,10 @@ def allreduce_mean_(flat):
     if not is_distributed():
         return flat
     world = dist.get_world_size()
-    if flat.is_cuda:
+    if dist.get_backend() == 'nccl':
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)      # RCCL computes the average in the ring
     else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)      # gloo (CPU tests): no AVG
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)      # gloo (CPU tests / single-GPU rehearsal): no AVG
         flat.mul_(1.0 / world)
     return flat
 

@@ -120,8 +120,8 @@ class BaseOptions():
 
         ids = [int(s) for s in opt.gpu_ids.split(',')]
         opt.gpu_ids = [i for i in ids if i >= 0]
-        if 'LOCAL_RANK' in os.environ and len(opt.gpu_ids) > 0:
-            opt.gpu_ids = [int(os.environ['LOCAL_RANK'])]      # one process <-> one GPU
+        if 'LOCAL_RANK' in os.environ and len(opt.gpu_ids) > 0 and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            opt.gpu_ids = [int(os.environ['LOCAL_RANK']) % max(1, torch.cuda.device_count())]   # one process <-> one GPU
         if len(opt.gpu_ids) > 1:
             raise RuntimeError('pcgan_amd runs one process per GPU: launch with torchrun --nproc-per-node %d '
                                'instead of --gpu_ids %s' % (len(opt.gpu_ids), ','.join(map(str, opt.gpu_ids))))
