@@ -67,13 +67,15 @@ int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const float* w, c
  * forward of nn.ConvTranspose2d, models/networks.py:597-600). */
 int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, const float* w, const float* bias,
                           float* dx, void* ws, size_t ws_bytes, pcgan_stream_t s);
-/* dw[K][C][R][S] = sum_{n,p,q} dy * gather(x). */
-int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw,
+/* dw[K][C][R][S] (+)= sum_{n,p,q} dy * gather(x).  accumulate != 0 adds into dw -- used with dw = the
+ * parameter's slice of the optimizer's flat gradient buffer, which fuses autograd's "grad += dw" pass. */
+int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
                             void* ws, size_t ws_bytes, pcgan_stream_t s);
 
 /* ---- per-channel reductions / pointwise ---------------------------------------- */
-/* out[c] = sum over n,h,w of x[n][c][h][w]  (bias gradients); scratch_nc: N*C floats. */
-int pcgan_channel_sum(const float* x, float* out, float* scratch_nc, int N, int C, int HW, pcgan_stream_t s);
+/* out[c] (+)= sum over n,h,w of x[n][c][h][w]  (bias gradients); scratch_nc: N*C floats. */
+int pcgan_channel_sum(const float* x, float* out, float* scratch_nc, int N, int C, int HW, int accumulate,
+                      pcgan_stream_t s);
 /* dx = dy * act'(y)  where y is the activation OUTPUT (relu/lrelu/tanh/sigmoid). */
 int pcgan_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float slope, pcgan_stream_t s);
 /* y = act(x) standalone (nn.ReLU in AlexNetFeature, models/networks.py:1224-1234). */

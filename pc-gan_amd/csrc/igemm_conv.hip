@@ -1024,7 +1024,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 
 // dw[k][c][r][s] = sum_split Wp[split][k][tap*Cgp + c]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ Wp, float* __restrict__ dw, int splits, int K,
-                                    int C, int Cgp, int RS) {
+                                    int C, int Cgp, int RS, int accumulate) {
     const int Kp = RS * Cgp;
     const size_t total = (size_t)K * Kp;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -1034,7 +1034,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ Wp, float* __restr
         if (c >= C) continue;
         float acc = 0.f;
         for (int s = 0; s < splits; ++s) acc += Wp[(size_t)s * total + i];
-        dw[((size_t)k * C + c) * RS + tap] = acc;
+        float* o = dw + ((size_t)k * C + c) * RS + tap;
+        *o = accumulate ? *o + acc : acc;   // accumulate: dw is the parameter's .grad buffer (fused "grad +=")
     }
 }
 
@@ -1363,7 +1364,7 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
 }
 
 extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw,
-                                       void* ws, size_t ws_bytes, pcgan_stream_t s) {
+                                       int accumulate, void* ws, size_t ws_bytes, pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(x && dy && dw, "conv2d_bwd_weight: null pointer");
     PCGAN_CHECK(ws && ws_bytes >= pcgan_conv2d_workspace_bytes(d, PCGAN_PASS_BWD_WEIGHT),
@@ -1389,7 +1390,7 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
         const size_t total = (size_t)d->K * RS * Cgp;
         const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, d->K, d->C,
-                           Cgp, RS);
+                           Cgp, RS, accumulate);
         PCGAN_LAUNCH_CHECK();
         return 0;
     }
@@ -1413,7 +1414,7 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
         const size_t total = (size_t)d->K * RS * Cgp;
         const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits,
-                           d->K, d->C, Cgp, RS);
+                           d->K, d->C, Cgp, RS, accumulate);
         PCGAN_LAUNCH_CHECK();
     }
     return 0;

@@ -88,14 +88,14 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
     s = block_sum(s, scratch);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
-__global__ void sum_over_n_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int C) {
+__global__ void sum_over_n_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int C, int accumulate) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per channel
     if (c >= C) return;
     const int lane = threadIdx.x & 63;
     float s = 0.f;
     for (int n = lane; n < N; n += 64) s += part[n * C + c];
     s = wave_sum(s);
-    if (lane == 0) out[c] = s;
+    if (lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 __global__ void channel_scale_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y,
@@ -155,13 +155,13 @@ extern "C" int pcgan_concat_z(const float* img, const float* z, float* out, int 
     return 0;
 }
 
-extern "C" int pcgan_channel_sum(const float* x, float* out, float* scratch_nc, int N, int C, int HW,
-                                    pcgan_stream_t s) {
+extern "C" int pcgan_channel_sum(const float* x, float* out, float* scratch_nc, int N, int C, int HW, int accumulate,
+                                 pcgan_stream_t s) {
     PCGAN_CHECK(x && out && scratch_nc && N > 0 && C > 0 && HW > 0, "channel_sum: bad arguments");
     hipLaunchKernelGGL(plane_sum_kernel, dim3(N * C), dim3(HW >= 1024 ? 256 : 64), 0, (hipStream_t)s, x, scratch_nc,
                        HW);
     PCGAN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_over_n_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)s, scratch_nc, out, N, C);
+    hipLaunchKernelGGL(sum_over_n_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)s, scratch_nc, out, N, C, accumulate);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

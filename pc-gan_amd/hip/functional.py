@@ -15,6 +15,15 @@ def _c(t):
     return t if (t is None or t.is_contiguous()) else t.contiguous()
 
 
+def _fused_grad_target(p):
+    """The parameter's slice of a FusedAdam flat gradient buffer, if it has one: the weight-/bias-gradient
+    kernels then add into it directly and autograd receives None (no separate `grad += dw` pass, no dw
+    allocation).  FusedAdam marks its parameters with `_pcgan_fused_grad`."""
+    if p is not None and getattr(p, '_pcgan_fused_grad', False) and p.grad is not None and p.grad.is_contiguous():
+        return p.grad
+    return None
+
+
 # ---------------------------------------------------------------------------- conv
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
@@ -23,6 +32,7 @@ class _Conv2dFn(torch.autograd.Function):
         y = ops.conv2d_fwd(x, w, b, stride, pad, pad_mode, act, slope)
         ctx.cfg = (stride, pad, pad_mode, act, slope)
         ctx.has_bias = b is not None
+        ctx.params = (w, b)          # the Parameter objects (for their fused gradient buffers)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
 
@@ -37,9 +47,15 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_bwd_data(dy, w, (x.shape[2], x.shape[3]), stride, pad, pad_mode)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv2d_bwd_weight(x, dy, tuple(w.shape), stride, pad, pad_mode)
+            tgt = _fused_grad_target(ctx.params[0])
+            dw = ops.conv2d_bwd_weight(x, dy, tuple(w.shape), stride, pad, pad_mode, accumulate_into=tgt)
+            if tgt is not None:
+                dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.channel_sum(dy)
+            tgt = _fused_grad_target(ctx.params[1])
+            db = ops.channel_sum(dy, accumulate_into=tgt)
+            if tgt is not None:
+                db = None
         return dx, dw, db, None, None, None, None, None
 
 
@@ -62,6 +78,7 @@ class _ConvTranspose2dFn(torch.autograd.Function):
         y = ops.conv2d_bwd_data(x, w, (Ho, Wo), stride, pad, 0, bias=b)
         ctx.cfg = (stride, pad)
         ctx.has_bias = b is not None
+        ctx.params = (w, b)
         ctx.save_for_backward(x, w)
         return y
 
@@ -74,9 +91,15 @@ class _ConvTranspose2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_fwd(dy, w, None, stride, pad, 0)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv2d_bwd_weight(dy, x, tuple(w.shape), stride, pad, 0)
+            tgt = _fused_grad_target(ctx.params[0])
+            dw = ops.conv2d_bwd_weight(dy, x, tuple(w.shape), stride, pad, 0, accumulate_into=tgt)
+            if tgt is not None:
+                dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.channel_sum(dy)
+            tgt = _fused_grad_target(ctx.params[1])
+            db = ops.channel_sum(dy, accumulate_into=tgt)
+            if tgt is not None:
+                db = None
         return dx, dw, db, None, None, None
 
 

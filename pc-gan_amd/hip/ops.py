@@ -79,30 +79,36 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None):
     return dx
 
 
-def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0):
-    _chk(x, dy)
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=None):
+    """dw, or -- with accumulate_into = the parameter's gradient buffer -- `accumulate_into += dw` in place."""
+    _chk(x, dy, accumulate_into)
     lib = _L.load()
     N, C, H, W = x.shape
     K, C2, R, S = w_shape
     assert C == C2 and dy.shape[1] == K
     d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode)
     assert (d.P, d.Q) == tuple(dy.shape[2:]), 'conv2d_bwd_weight: geometry mismatch'
-    dw = torch.empty((K, C, R, S), dtype=torch.float32, device=x.device)
+    if accumulate_into is not None:
+        assert tuple(accumulate_into.shape) == (K, C, R, S)
+        dw = accumulate_into
+    else:
+        dw = torch.empty((K, C, R, S), dtype=torch.float32, device=x.device)
     nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_BWD_WEIGHT)
     ws = _ws(nb, x.device)
-    _L.check(lib.pcgan_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), _stream()),
-             'conv2d_bwd_weight')
+    _L.check(lib.pcgan_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), int(accumulate_into is not None),
+                                         _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight')
     return dw
 
 
 # ---------------------------------------------------------------- pointwise
-def channel_sum(x):
-    _chk(x)
+def channel_sum(x, accumulate_into=None):
+    _chk(x, accumulate_into)
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
-    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    out = accumulate_into if accumulate_into is not None else torch.empty(C, dtype=torch.float32, device=x.device)
     scratch = torch.empty(N * C, dtype=torch.float32, device=x.device)
-    _L.check(_L.load().pcgan_channel_sum(_p(x), _p(out), _p(scratch), N, C, HW, _stream()), 'channel_sum')
+    _L.check(_L.load().pcgan_channel_sum(_p(x), _p(out), _p(scratch), N, C, HW, int(accumulate_into is not None),
+                                         _stream()), 'channel_sum')
     return out
 
 

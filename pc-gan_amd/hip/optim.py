@@ -45,6 +45,7 @@ class FusedAdam(torch.optim.Optimizer):
                 p.data = self.flat[o:o + n].view(p.shape)
                 gv = self.gflat[o:o + n].view(p.shape)
                 p.grad = gv
+                p._pcgan_fused_grad = True     # conv backward accumulates straight into this view
                 self._views.append((p, gv))
         self.numel = sum(p.numel() for p in ps)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
