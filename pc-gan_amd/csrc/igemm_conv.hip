@@ -196,9 +196,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     const int st_end = st_begin + nst_per < nst_all ? st_begin + nst_per : nst_all;
 
     KIter it{0, 0, 0};
-    if (CG16) {
-        const int tap0 = (st_begin * 16) / a.Cgp;
-        it.c = st_begin * 16 - tap0 * a.Cgp;
+    if (CG16) {  // chunked K order: stage st = (channel chunk st / T, tap st % T)
+        const int T = ph_nR * ph_nS;
+        const int cc0 = st_begin / T, tap0 = st_begin - cc0 * T;
+        it.c = cc0 * 16;
         it.ri = tap0 / ph_nS;
         it.sj = tap0 - it.ri * ph_nS;
     } else {
@@ -251,13 +252,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
                     bmir[2][i] = ld_b32(rX, v11, so);
                 }
             }
-            const int c1 = it.c + 16;
-            const bool wc = c1 == a.Cgp;
-            it.c = wc ? 0 : c1;
-            const int s1 = it.sj + (wc ? 1 : 0);
+            // next stage: next tap of the same channel chunk; after the last tap, the next chunk
+            const int s1 = it.sj + 1;
             const bool ws = s1 == ph_nS;
             it.sj = ws ? 0 : s1;
-            it.ri += ws ? 1 : 0;
+            const int r1 = it.ri + (ws ? 1 : 0);
+            const bool wr = r1 == ph_nR;
+            it.ri = wr ? 0 : r1;
+            it.c += wr ? 16 : 0;
             return;
         }
         if (CG16) {
@@ -271,13 +273,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i)
                 breg[i] = ld_b32(rX, (c0 + i < a.Cg) ? voff : OOB, (unsigned)((c0 + i) * HgWg) * 4u);
-            const int c1 = it.c + 16;
-            const bool wc = c1 == a.Cgp;
-            it.c = wc ? 0 : c1;
-            const int s1 = it.sj + (wc ? 1 : 0);
+            // next stage: next tap of the same channel chunk; after the last tap, the next chunk
+            const int s1 = it.sj + 1;
             const bool ws = s1 == ph_nS;
             it.sj = ws ? 0 : s1;
-            it.ri += ws ? 1 : 0;
+            const int r1 = it.ri + (ws ? 1 : 0);
+            const bool wr = r1 == ph_nR;
+            it.ri = wr ? 0 : r1;
+            it.c += wr ? 16 : 0;
             return;
         }
         KIter e = it;
@@ -748,26 +751,47 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
 // weight re-layout kernels
 // ------------------------------------------------------------------------------------
 // forward: A[k][tap][c] (Cgp-padded) from w[K][C][R][S]
+// chunked != 0 (CG16 kernels): K order (16-channel chunk, tap, channel-in-chunk), so the 9..49 taps of one
+// channel chunk are consecutive K stages and re-read the same small input tile from L1/L2 instead of
+// streaming the whole input once per tap from beyond L2
 __global__ void repack_fwd_kernel(const float* __restrict__ w, float* __restrict__ A, int K, int C, int Cgp,
-                                  int RS) {
+                                  int RS, int chunked) {
     const int Kp = RS * Cgp;
     const size_t total = (size_t)K * Kp;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i / Kp);
         const int j = (int)(i - (size_t)k * Kp);
-        const int tap = j / Cgp, c = j - tap * Cgp;
+        int tap, c;
+        if (chunked) {
+            const int t2 = j >> 4;
+            const int cc = t2 / RS;
+            tap = t2 - cc * RS;
+            c = cc * 16 + (j & 15);
+        } else {
+            tap = j / Cgp;
+            c = j - tap * Cgp;
+        }
         A[i] = (c < C) ? w[((size_t)k * C + c) * RS + tap] : 0.f;
     }
 }
 // backward-data, one stride phase: A[c][(ri,sj)][k] (Kgp-padded) from w[K][C][R][S]
 __global__ void repack_bwd_kernel(const float* __restrict__ w, float* __restrict__ A, int K, int C, int Kgp,
-                                  int R, int S, int r0, int s0, int tstep, int nR, int nS) {
+                                  int R, int S, int r0, int s0, int tstep, int nR, int nS, int chunked) {
     const int Kp = nR * nS * Kgp;
     const size_t total = (size_t)C * Kp;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i / Kp);
         const int j = (int)(i - (size_t)c * Kp);
-        const int t = j / Kgp, k = j - t * Kgp;
+        int t, k;
+        if (chunked) {
+            const int t2 = j >> 4;
+            const int kc = t2 / (nR * nS);
+            t = t2 - kc * (nR * nS);
+            k = kc * 16 + (j & 15);
+        } else {
+            t = j / Kgp;
+            k = j - t * Kgp;
+        }
         const int ri = t / nS, sj = t - ri * nS;
         const int r = r0 + ri * tstep, s = s0 + sj * tstep;
         A[i] = (k < K) ? w[(((size_t)k * C + c) * R + r) * S + s] : 0.f;
@@ -1248,7 +1272,8 @@ extern "C" int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const 
     {
         const size_t total = (size_t)d->K * RS * Cgp;
         const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-        hipLaunchKernelGGL(repack_fwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Cgp, RS);
+        hipLaunchKernelGGL(repack_fwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Cgp, RS,
+                           (int)((Cgp % 16) == 0 && d->K > 4));
         PCGAN_LAUNCH_CHECK();
     }
     IgemmArgs a;
@@ -1328,7 +1353,7 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
             a_off += total;
             const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
             hipLaunchKernelGGL(repack_bwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Kgp, d->R,
-                               d->S, r0, s0, stv, nR, nS);
+                               d->S, r0, s0, stv, nR, nS, (int)((Kgp % 16) == 0 && !smallm));
             PCGAN_LAUNCH_CHECK();
             PhaseArgs& p = a.ph[a.nphase++];
             p.A = A; p.Kp = nR * nS * Kgp; p.Hs = Hs; p.Ws = Ws; p.fy = fy; p.fx = fx;
