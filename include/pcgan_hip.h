@@ -67,6 +67,18 @@ int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const float* w, c
  * forward of nn.ConvTranspose2d, models/networks.py:597-600). */
 int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, const float* w, const float* bias,
                           float* dx, void* ws, size_t ws_bytes, pcgan_stream_t s);
+/* Weight packing split out of the two calls above.  fwd/bwd_data re-tile w into the implicit-GEMM A
+ * operand on every call (a few us, ~2 % of a step); weights only change once per optimizer step while the
+ * reference's step runs each net 2-4 times (models/wsgan_emb_model.py:277-330), so the host can pack once
+ * per (weight version, pass) and call the *_packed variants.  `packed` holds pcgan_conv2d_packed_bytes(d,
+ * pass) bytes (0 for PCGAN_PASS_BWD_WEIGHT) and is valid for any desc that differs only in N (batch). */
+size_t pcgan_conv2d_packed_bytes(const pcgan_conv_desc* d, int pass);
+int pcgan_conv2d_pack_weights(const pcgan_conv_desc* d, int pass, const float* w, float* packed,
+                              pcgan_stream_t s);
+int pcgan_conv2d_fwd_packed(const pcgan_conv_desc* d, const float* x, const float* packed, const float* bias,
+                            float* y, int act, float slope, void* ws, size_t ws_bytes, pcgan_stream_t s);
+int pcgan_conv2d_bwd_data_packed(const pcgan_conv_desc* d, const float* dy, const float* packed,
+                                 const float* bias, float* dx, void* ws, size_t ws_bytes, pcgan_stream_t s);
 /* dw[K][C][R][S] (+)= sum_{n,p,q} dy * gather(x).  accumulate != 0 adds into dw -- used with dw = the
  * parameter's slice of the optimizer's flat gradient buffer, which fuses autograd's "grad += dw" pass. */
 int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,

@@ -308,10 +308,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             const int row = q >> 2, kc = (q & 3) * 4;
             if (BM * 4 >= 256 || row < BM) *reinterpret_cast<float4*>(&As[buf][row * AP + kc]) = areg[j];
         }
-        if (NM == 1) {
+        if constexpr (NM == 1) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) breg[i] += bmir[0][i];
-        } else if (NM == 3) {
+        } else if constexpr (NM == 3) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) breg[i] += (bmir[0][i] + bmir[1][i]) + bmir[2][i];
         }
@@ -1260,22 +1260,33 @@ extern "C" size_t pcgan_conv2d_workspace_bytes(const pcgan_conv_desc* d, int pas
     return align_up((size_t)splits * d->K * RS * round4(d->C) * 4, 256);
 }
 
-extern "C" int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const float* w, const float* bias,
-                                float* y, int act, float slope, void* ws, size_t ws_bytes, pcgan_stream_t s) {
+// forward weight pack: A[K][Kp] (+ its [Kp][4] transpose behind it for the small-M path)
+static int pack_fwd(const pcgan_conv_desc* d, const float* w, float* A, hipStream_t st) {
+    const int Cgp = round4(d->C), RS = d->R * d->S;
+    const size_t total = (size_t)d->K * RS * Cgp;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(repack_fwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Cgp, RS,
+                       (int)((Cgp % 16) == 0 && d->K > 4));
+    PCGAN_LAUNCH_CHECK();
+    if (d->K <= 4) {
+        hipLaunchKernelGGL(transpose4_kernel, dim3((RS * Cgp * 4 + 255) / 256), dim3(256), 0, st, (const float*)A,
+                           A + total, d->K, RS * Cgp);
+        PCGAN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+static int conv2d_fwd_impl(const pcgan_conv_desc* d, const float* x, const float* w, const float* packed,
+                           const float* bias, float* y, int act, float slope, void* ws, size_t ws_bytes,
+                           pcgan_stream_t s) {
     if (check_desc(d)) return 1;
-    PCGAN_CHECK(x && w && y, "conv2d_fwd: null pointer");
+    PCGAN_CHECK(x && (w || packed) && y, "conv2d_fwd: null pointer");
     PCGAN_CHECK(ws && ws_bytes >= pcgan_conv2d_workspace_bytes(d, PCGAN_PASS_FWD),
                 "conv2d_fwd: workspace too small (%zu)", ws_bytes);
     hipStream_t st = (hipStream_t)s;
     const int Cgp = round4(d->C), RS = d->R * d->S;
-    float* A = (float*)ws;
-    {
-        const size_t total = (size_t)d->K * RS * Cgp;
-        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-        hipLaunchKernelGGL(repack_fwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Cgp, RS,
-                           (int)((Cgp % 16) == 0 && d->K > 4));
-        PCGAN_LAUNCH_CHECK();
-    }
+    float* A = packed ? const_cast<float*>(packed) : (float*)ws;
+    if (!packed && pack_fwd(d, w, A, st)) return 2;
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.X = x; a.Y = y; a.bias = bias;
@@ -1287,30 +1298,39 @@ extern "C" int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const 
     a.nphase = 1;
     PhaseArgs& p = a.ph[0];
     p.A = A; p.Kp = RS * Cgp; p.Hs = d->P; p.Ws = d->Q; p.fy = 0; p.fx = 0;
-    if (d->K <= 4) {  // small-M path reads the weights as [k][4]
-        float* At = A + (size_t)d->K * RS * Cgp;
-        hipLaunchKernelGGL(transpose4_kernel, dim3((RS * Cgp * 4 + 255) / 256), dim3(256), 0, st, (const float*)A, At,
-                           d->K, RS * Cgp);
-        PCGAN_LAUNCH_CHECK();
-        p.A = At;
-    }
+    if (d->K <= 4) p.A = A + (size_t)d->K * RS * Cgp;  // small-M path reads the weights as [k][4]
     p.r0 = 0; p.s0 = 0; p.nR = d->R; p.nS = d->S; p.Ptot = d->N * d->P * d->Q;
     float* part = fwd_part_bytes(d) ? (float*)((char*)ws + fwd_base_bytes(d)) : nullptr;
     return d->pad_mode == 1 ? launch_igemm<MODE_FWD_REFLECT>(a, st, part, fwd_part_bytes(d))
                             : launch_igemm<MODE_FWD_ZERO>(a, st, part, fwd_part_bytes(d));
 }
 
-extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, const float* w,
-                                     const float* bias, float* dx, void* ws, size_t ws_bytes,
-                                     pcgan_stream_t s) {
+extern "C" int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const float* w, const float* bias,
+                                float* y, int act, float slope, void* ws, size_t ws_bytes, pcgan_stream_t s) {
     if (check_desc(d)) return 1;
-    PCGAN_CHECK(dy && w && dx, "conv2d_bwd_data: null pointer");
-    PCGAN_CHECK(ws && ws_bytes >= pcgan_conv2d_workspace_bytes(d, PCGAN_PASS_BWD_DATA),
+    PCGAN_CHECK(w, "conv2d_fwd: null weight pointer");
+    return conv2d_fwd_impl(d, x, w, nullptr, bias, y, act, slope, ws, ws_bytes, s);
+}
+extern "C" int pcgan_conv2d_fwd_packed(const pcgan_conv_desc* d, const float* x, const float* packed,
+                                       const float* bias, float* y, int act, float slope, void* ws, size_t ws_bytes,
+                                       pcgan_stream_t s) {
+    if (check_desc(d)) return 1;
+    PCGAN_CHECK(packed, "conv2d_fwd_packed: null packed-weight pointer");
+    return conv2d_fwd_impl(d, x, nullptr, packed, bias, y, act, slope, ws, ws_bytes, s);
+}
+
+static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const float* w, const float* packed,
+                                const float* bias, float* dx, void* ws, size_t ws_bytes, pcgan_stream_t s) {
+    if (check_desc(d)) return 1;
+    const bool pack_only = dx == nullptr;   // pcgan_conv2d_pack_weights: run the repack launches into `packed` only
+    PCGAN_CHECK(pack_only ? (w && packed) : (dy && (w || packed)), "conv2d_bwd_data: null pointer");
+    PCGAN_CHECK(pack_only || (ws && ws_bytes >= pcgan_conv2d_workspace_bytes(d, PCGAN_PASS_BWD_DATA)),
                 "conv2d_bwd_data: workspace too small (%zu)", ws_bytes);
     PCGAN_CHECK(d->pad_mode == 0 || d->stride == 1, "conv2d_bwd_data: reflection padding needs stride 1");
     hipStream_t st = (hipStream_t)s;
     const int Kgp = round4(d->K), RS = d->R * d->S;
-    float* Abase = (float*)ws;
+    float* Abase = packed ? const_cast<float*>(packed) : (float*)ws;
+    const bool do_pack = pack_only || !packed;
     const size_t a_bytes = bwd_base_bytes(d);
     const bool smallm = d->C <= 4;
     size_t at_off = (size_t)d->C * RS * Kgp;  // transposed copies for the small-M path live behind the A's
@@ -1352,22 +1372,27 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
             const size_t total = (size_t)d->C * nR * nS * Kgp;
             a_off += total;
             const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-            hipLaunchKernelGGL(repack_bwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Kgp, d->R,
-                               d->S, r0, s0, stv, nR, nS, (int)((Kgp % 16) == 0 && !smallm));
-            PCGAN_LAUNCH_CHECK();
+            if (do_pack) {
+                hipLaunchKernelGGL(repack_bwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Kgp, d->R,
+                                   d->S, r0, s0, stv, nR, nS, (int)((Kgp % 16) == 0 && !smallm));
+                PCGAN_LAUNCH_CHECK();
+            }
             PhaseArgs& p = a.ph[a.nphase++];
             p.A = A; p.Kp = nR * nS * Kgp; p.Hs = Hs; p.Ws = Ws; p.fy = fy; p.fx = fx;
             if (smallm) {
                 float* At = Abase + at_off;
                 at_off += (size_t)nR * nS * Kgp * 4;
-                hipLaunchKernelGGL(transpose4_kernel, dim3((nR * nS * Kgp * 4 + 255) / 256), dim3(256), 0, st,
-                                   (const float*)A, At, d->C, nR * nS * Kgp);
-                PCGAN_LAUNCH_CHECK();
+                if (do_pack) {
+                    hipLaunchKernelGGL(transpose4_kernel, dim3((nR * nS * Kgp * 4 + 255) / 256), dim3(256), 0, st,
+                                       (const float*)A, At, d->C, nR * nS * Kgp);
+                    PCGAN_LAUNCH_CHECK();
+                }
                 p.A = At;
             }
             p.r0 = r0; p.s0 = s0; p.nR = nR; p.nS = nS; p.Ptot = d->N * Hs * Ws;
         }
     }
+    if (pack_only) return 0;
     if (need_zero) {
         // pixels that no phase writes would also miss the bias; never happens for the nets on the hot path
         PCGAN_CHECK(!bias, "conv2d_bwd_data: bias with uncovered phases is unsupported");
@@ -1386,6 +1411,36 @@ extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, 
         PCGAN_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, const float* w,
+                                     const float* bias, float* dx, void* ws, size_t ws_bytes,
+                                     pcgan_stream_t s) {
+    if (check_desc(d)) return 1;
+    PCGAN_CHECK(w && dx, "conv2d_bwd_data: null pointer");
+    return conv2d_bwd_data_impl(d, dy, w, nullptr, bias, dx, ws, ws_bytes, s);
+}
+extern "C" int pcgan_conv2d_bwd_data_packed(const pcgan_conv_desc* d, const float* dy, const float* packed,
+                                            const float* bias, float* dx, void* ws, size_t ws_bytes,
+                                            pcgan_stream_t s) {
+    if (check_desc(d)) return 1;
+    PCGAN_CHECK(packed && dx, "conv2d_bwd_data_packed: null pointer");
+    return conv2d_bwd_data_impl(d, dy, nullptr, packed, bias, dx, ws, ws_bytes, s);
+}
+
+extern "C" size_t pcgan_conv2d_packed_bytes(const pcgan_conv_desc* d, int pass) {
+    if (!d) return 0;
+    if (pass == PCGAN_PASS_FWD) return fwd_base_bytes(d);
+    if (pass == PCGAN_PASS_BWD_DATA) return bwd_base_bytes(d);
+    return 0;
+}
+extern "C" int pcgan_conv2d_pack_weights(const pcgan_conv_desc* d, int pass, const float* w, float* packed,
+                                         pcgan_stream_t s) {
+    if (check_desc(d)) return 1;
+    PCGAN_CHECK(w && packed, "conv2d_pack_weights: null pointer");
+    if (pass == PCGAN_PASS_FWD) return pack_fwd(d, w, packed, (hipStream_t)s);
+    PCGAN_CHECK(pass == PCGAN_PASS_BWD_DATA, "conv2d_pack_weights: pass %d has no packed weights", pass);
+    return conv2d_bwd_data_impl(d, nullptr, w, packed, nullptr, nullptr, nullptr, 0, s);
 }
 
 extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw,

@@ -24,12 +24,23 @@ def _fused_grad_target(p):
     return None
 
 
+def _pack_cache(p):
+    """Per-parameter dict holding the packed copies of a conv weight (see ops._packed_weights)."""
+    if p is None or not isinstance(p, torch.nn.Parameter):
+        return None
+    c = p.__dict__.get('_pcgan_pack')
+    if c is None:
+        c = p.__dict__['_pcgan_pack'] = {}
+    return c
+
+
 # ---------------------------------------------------------------------------- conv
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, pad_mode, act, slope):
         x, w, b = _c(x), _c(w), _c(b)
-        y = ops.conv2d_fwd(x, w, b, stride, pad, pad_mode, act, slope)
+        ctx.pack = _pack_cache(w)
+        y = ops.conv2d_fwd(x, w, b, stride, pad, pad_mode, act, slope, pack_cache=ctx.pack)
         ctx.cfg = (stride, pad, pad_mode, act, slope)
         ctx.has_bias = b is not None
         ctx.params = (w, b)          # the Parameter objects (for their fused gradient buffers)
@@ -45,7 +56,7 @@ class _Conv2dFn(torch.autograd.Function):
             dy = ops.act_bwd(dy, y, act, slope)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_bwd_data(dy, w, (x.shape[2], x.shape[3]), stride, pad, pad_mode)
+            dx = ops.conv2d_bwd_data(dy, w, (x.shape[2], x.shape[3]), stride, pad, pad_mode, pack_cache=ctx.pack)
         if ctx.needs_input_grad[1]:
             tgt = _fused_grad_target(ctx.params[0])
             dw = ops.conv2d_bwd_weight(x, dy, tuple(w.shape), stride, pad, pad_mode, accumulate_into=tgt)
@@ -75,7 +86,8 @@ class _ConvTranspose2dFn(torch.autograd.Function):
         R, S = w.shape[2], w.shape[3]
         Ho = (x.shape[2] - 1) * stride - 2 * pad + R + out_pad
         Wo = (x.shape[3] - 1) * stride - 2 * pad + S + out_pad
-        y = ops.conv2d_bwd_data(x, w, (Ho, Wo), stride, pad, 0, bias=b)
+        ctx.pack = _pack_cache(w)
+        y = ops.conv2d_bwd_data(x, w, (Ho, Wo), stride, pad, 0, bias=b, pack_cache=ctx.pack)
         ctx.cfg = (stride, pad)
         ctx.has_bias = b is not None
         ctx.params = (w, b)
@@ -89,7 +101,7 @@ class _ConvTranspose2dFn(torch.autograd.Function):
         dy = _c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_fwd(dy, w, None, stride, pad, 0)
+            dx = ops.conv2d_fwd(dy, w, None, stride, pad, 0, pack_cache=ctx.pack)
         if ctx.needs_input_grad[1]:
             tgt = _fused_grad_target(ctx.params[0])
             dw = ops.conv2d_bwd_weight(dy, x, tuple(w.shape), stride, pad, 0, accumulate_into=tgt)

@@ -32,6 +32,10 @@ SIGNATURES = {
     'pcgan_conv2d_workspace_bytes': (_sz, [_dp, _i]),
     'pcgan_conv2d_fwd': (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
     'pcgan_conv2d_bwd_data': (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'pcgan_conv2d_packed_bytes': (_sz, [_dp, _i]),
+    'pcgan_conv2d_pack_weights': (_i, [_dp, _i, _vp, _vp, _vp]),
+    'pcgan_conv2d_fwd_packed': (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
+    'pcgan_conv2d_bwd_data_packed': (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pcgan_conv2d_bwd_weight': (_i, [_dp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     'pcgan_channel_sum': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pcgan_act_bwd': (_i, [_vp, _vp, _vp, _sz, _i, _f, _vp]),

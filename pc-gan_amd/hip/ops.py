@@ -46,7 +46,34 @@ def make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode):
 
 
 # ---------------------------------------------------------------- convolution family
-def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0):
+# Packed-weight cache.  The implicit-GEMM kernels read the weights re-tiled ("packed"); a step runs every
+# net several times between two optimizer updates, so the packed copy is kept per (weight tensor, pass) and
+# re-made when the weights may have changed: the stamp is (global epoch, tensor version, storage address).
+# The epoch is bumped by everything that writes parameters behind autograd's back (the Adam kernels, which
+# update the flat buffer through raw pointers; model.set_input / load_networks / broadcast as a backstop).
+_PACK_EPOCH = [0]
+
+
+def invalidate_packed_weights():
+    _PACK_EPOCH[0] += 1
+
+
+def _packed_weights(lib, d, pass_, w, cache):
+    key = (pass_, d.stride, d.pad, d.pad_mode)
+    stamp = (_PACK_EPOCH[0], w._version, w.data_ptr(), tuple(w.shape))
+    ent = cache.get(key)
+    if ent is not None and ent[0] == stamp:
+        return ent[1]
+    nb = max(int(lib.pcgan_conv2d_packed_bytes(ctypes.byref(d), pass_)), 256)
+    buf = ent[1] if (ent is not None and ent[1].numel() == nb and ent[1].device == w.device) else _ws(nb, w.device)
+    _L.check(lib.pcgan_conv2d_pack_weights(ctypes.byref(d), pass_, _p(w), _p(buf), _stream()), 'conv2d_pack_weights')
+    cache[key] = (stamp, buf)
+    return buf
+
+
+def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pack_cache=None):
+    """pack_cache: a dict owned by the caller (one per weight tensor) that keeps the packed weights between
+    calls; None packs inside the call."""
     _chk(x, w, bias)
     lib = _L.load()
     N, C, H, W = x.shape
@@ -56,12 +83,17 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0):
     y = torch.empty((N, K, d.P, d.Q), dtype=torch.float32, device=x.device)
     nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_FWD)
     ws = _ws(nb, x.device)
+    if pack_cache is not None:
+        pk = _packed_weights(lib, d, _L.PASS_FWD, w, pack_cache)
+        _L.check(lib.pcgan_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(pk), _p(bias), _p(y), act, float(slope),
+                                             _p(ws), ws.numel(), _stream()), 'conv2d_fwd_packed')
+        return y
     _L.check(lib.pcgan_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), act, float(slope),
                                   _p(ws), ws.numel(), _stream()), 'conv2d_fwd')
     return y
 
 
-def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None):
+def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache=None):
     """dx[N][C][H][W] for a conv with weight w[K][C][R][S]; in_hw = (H, W) of the conv input."""
     _chk(dy, w, bias)
     lib = _L.load()
@@ -74,6 +106,11 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None):
     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
     nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_BWD_DATA)
     ws = _ws(nb, dy.device)
+    if pack_cache is not None:
+        pk = _packed_weights(lib, d, _L.PASS_BWD_DATA, w, pack_cache)
+        _L.check(lib.pcgan_conv2d_bwd_data_packed(ctypes.byref(d), _p(dy), _p(pk), _p(bias), _p(dx), _p(ws),
+                                                  ws.numel(), _stream()), 'conv2d_bwd_data_packed')
+        return dx
     _L.check(lib.pcgan_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(w), _p(bias), _p(dx), _p(ws), ws.numel(),
                                        _stream()), 'conv2d_bwd_data')
     return dx
@@ -349,12 +386,14 @@ def mse_loss(a, b, want_grad=True):
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     _chk(param, grad, exp_avg, exp_avg_sq)
+    invalidate_packed_weights()
     _L.check(_L.load().pcgan_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr),
                                        float(beta1), float(beta2), float(eps), int(step), _stream()), 'adam_step')
 
 
 def adam_step_dev(param, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1, beta2, eps):
     _chk(param, grad, exp_avg, exp_avg_sq, lr_dev)
+    invalidate_packed_weights()
     _L.check(_L.load().pcgan_adam_step_dev(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(),
                                            _p(lr_dev), _vp(step_dev.data_ptr()), float(beta1), float(beta2),
                                            float(eps), _stream()), 'adam_step_dev')

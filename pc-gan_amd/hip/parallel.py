@@ -90,3 +90,5 @@ def broadcast_parameters(net, src=0):
         return
     for t in list(net.parameters()) + list(net.buffers()):
         dist.broadcast(t.data, src)
+    from . import ops
+    ops.invalidate_packed_weights()

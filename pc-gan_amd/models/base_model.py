@@ -120,6 +120,8 @@ class BaseModel():
                                                                  'num_batches_tracked'):
                     state_dict.pop(key)
             net.load_state_dict(state_dict)
+        from ..hip import ops
+        ops.invalidate_packed_weights()
 
     def print_networks(self, verbose):
         print('---------- Networks initialized -------------')

@@ -82,6 +82,8 @@ def init_weights(net, init_type='normal', gain=0.02):
 
     print('initialize network with %s' % init_type)
     net.apply(init_func)
+    from ..hip import ops            # .data writes do not bump tensor versions: drop packed-weight copies
+    ops.invalidate_packed_weights()
 
 
 def init_net(net, init_type='normal', gpu_ids=[]):

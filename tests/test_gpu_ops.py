@@ -82,6 +82,41 @@ def test_conv2d_fwd_bwd(case, dev):
     assert_close(dw, dw_ref, 1e-4, name + ' bwd_weight')
     db = ops.channel_sum(dyd)
     assert_close(db, db_ref, 1e-4, name + ' bias grad')
+    # prepacked-weight entry points: same kernels on the same operand -> bit-identical; a second batch size
+    # reuses the packed copy (it does not depend on N)
+    cache = {}
+    assert torch.equal(ops.conv2d_fwd(xd, wd, bd, stride, pad, pm, pack_cache=cache), y), name + ' fwd_packed'
+    assert torch.equal(ops.conv2d_bwd_data(dyd, wd, (H, W), stride, pad, pm, pack_cache=cache), dx), name + ' bwd_packed'
+    assert len(cache) == 2
+    stamps = {k: v[0] for k, v in cache.items()}
+    assert torch.equal(ops.conv2d_fwd(xd[:1].contiguous(), wd, bd, stride, pad, pm, pack_cache=cache), y[:1])
+    assert torch.equal(ops.conv2d_bwd_data(dyd[:1].contiguous(), wd, (H, W), stride, pad, pm, pack_cache=cache), dx[:1])
+    assert {k: v[0] for k, v in cache.items()} == stamps
+
+
+def test_packed_weight_cache_invalidation(dev):
+    """The packed copy must follow the weights: torch in-place writes (version counter), the raw-pointer Adam
+    kernels (global epoch) and storage moves all re-pack."""
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(2, 32, 12, 12, generator=g) * 2 - 1).to(dev)
+    w = (torch.randn(32, 32, 3, 3, generator=g) * 0.1).to(dev)
+    cache = {}
+    y0 = ops.conv2d_fwd(x, w, None, 1, 1, 1, pack_cache=cache)
+    w.mul_(2.0)                                              # version bump
+    assert_close(ops.conv2d_fwd(x, w, None, 1, 1, 1, pack_cache=cache), 2 * y0.double().cpu(), 2e-5, 'after mul_')
+    grad = torch.ones_like(w)
+    m, v = torch.zeros_like(w), torch.zeros_like(w)
+    w_before = w.clone()
+    ops.adam_step(w, grad, m, v, 0.05, 0.5, 0.999, 1e-8, 1)  # raw-pointer update, no version bump
+    assert not torch.equal(w, w_before)
+    y_new = ops.conv2d_fwd(x, w, None, 1, 1, 1, pack_cache=cache)
+    assert torch.equal(y_new, ops.conv2d_fwd(x, w, None, 1, 1, 1)), 'stale packed weights after adam_step'
+    dx_new = ops.conv2d_bwd_data(y0, w, (12, 12), 1, 1, 1, pack_cache=cache)
+    ops.adam_step(w, grad, m, v, 0.05, 0.5, 0.999, 1e-8, 2)
+    assert torch.equal(ops.conv2d_bwd_data(y0, w, (12, 12), 1, 1, 1, pack_cache=cache),
+                       ops.conv2d_bwd_data(y0, w, (12, 12), 1, 1, 1)), 'stale packed weights (bwd) after adam_step'
+    assert not torch.equal(dx_new, ops.conv2d_bwd_data(y0, w, (12, 12), 1, 1, 1))
 
 
 @pytest.mark.parametrize('act,slope', [(1, 0.0), (2, 0.2), (3, 0.0), (4, 0.0)])
