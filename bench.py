@@ -69,7 +69,7 @@ def synthetic_batch(batch, size, rank, it=0):
     return {'A': A, 'B': B, 'label': label, 'A_paths': [''] * batch, 'B_paths': [''] * batch}
 
 
-def time_resblock_conv(device, n=PER_GPU_BATCH, iters=30):
+def time_resblock_conv(device, n=PER_GPU_BATCH, iters=50):
     """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of the
     dominant kernel: 256->256 3x3 reflect-padded conv on (n,256,32,32)."""
     from pcgan_amd.hip import ops
@@ -78,7 +78,7 @@ def time_resblock_conv(device, n=PER_GPU_BATCH, iters=30):
     w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(device)
     b = torch.zeros(256, device=device)
     cache = {}                                   # weights packed once, as in the step (ops._packed_weights)
-    for _ in range(5):
+    for _ in range(60):                          # ~20 ms of back-to-back launches: clocks at their sustained level
         ops.conv2d_fwd(x, w, b, 1, 1, 1, pack_cache=cache)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -176,7 +176,7 @@ def main():
                                'PatchGAN + ResNet-18 Elo encoder@224 + AlexNet IP@224, full optimize_parameters()',
                    'global_batch': PER_GPU_BATCH * world, 'parallelism': 'dp%d' % world},
         'step_flop_fraction': round(GFLOP_PER_IMG_FULL * 1e9 * value / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4),
-        'roofline': {'bound': 'mfma', 'kernel': 'igemm_kernel<1,128,128,true> (FWD_REFLECT, 128x128 tile) 256->256 3x3 reflect @32x32, bs32',
+        'roofline': {'bound': 'mfma', 'kernel': 'igemm2_kernel<1,128,128> (FWD_REFLECT, 128x128 tile) 256->256 3x3 reflect @32x32, bs32',
                      'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'ms_per_launch': round(conv_ms, 4),
                      'flop_per_launch': conv_flop, 'traffic': None},

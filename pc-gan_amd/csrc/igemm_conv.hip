@@ -65,6 +65,7 @@ struct IgemmArgs {
     unsigned x_bytes;
     int nphase;
     int stagger;  // > 0: waves in odd hardware slots sleep this many 64-cycle units before starting
+    int chunked;  // K order of ph[].A: 1 = (16-channel chunk, tap, channel) -> igemm2_kernel, 0 = (tap, channel)
     int ksplit;   // > 1: blockIdx.z takes a contiguous range of K stages and stores a raw partial sum
     float* Ypart; // [ksplit][N][M][Yh][Yw] partial sums (then reduced + bias + activation by splitk_reduce)
     PhaseArgs ph[16];
@@ -464,6 +465,415 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
                     if (a.bias) v += a.bias[m];
                     v = act_apply(v, a.act, a.slope);
                     Yp[(size_t)m * YhYw] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Chunked-K kernel (C % 16 == 0, <= 25 filter taps): the hot kernel of the step.
+//
+// K order (16-channel chunk, tap, channel-in-chunk): one K stage = 16 channels of ONE filter tap, consecutive
+// stages walk the taps of the same 16 channel planes (L2-resident).
+//
+// What bounds this kernel (measured, scripts/micro/mfma_mix.hip): on one SIMD every vector-ALU, LDS and
+// vector-memory instruction issued between two v_mfma costs the matrix pipe ~4-6 cycles -- they do not hide
+// under the 64 cycles of a 32x32x2 fp32 MFMA; only scalar instructions are free.  So the loop is written to
+// need as few non-scalar instructions per stage as possible:
+//   * the gather offset of (pixel, tap) -- padding / reflection / stride arithmetic, validity in bit 31 -- is
+//     tabulated once per workgroup in LDS: a stage needs ONE 4-byte LDS read (+1 VALU for its address);
+//   * channel and K offsets go through the scalar offset operand of the buffer loads;
+//   * the LDS buffer index is a compile-time constant (loop unrolled by two), so every LDS address is a
+//     per-thread base register + immediate;
+//   * the K iterator lives in SGPRs.
+// Per wave and stage (128x128 tile): 32 MFMA, 9 LDS reads, 4 LDS writes, 10 global loads, ~2 VALU.
+//
+// Pipeline (a wave issues in order and stops at every wait, so each wait must come long after its request):
+//     first half of the MFMA chain (operands av0/bv0, already in registers)
+//         + LDS reads of this stage's second-half operands av1/bv1
+//         + LDS write of stage t+1 (its global loads were issued one stage ago)
+//         + global gathers of stage t+2
+//     barrier  (stage t+1 is now visible; nobody still reads the buffer written next)
+//     second half of the chain (av1/bv1)
+//         + LDS reads of stage t+1's first-half operands av0/bv0
+//         + offset-table read for the gathers of stage t+3
+// so the LDS write -> barrier -> LDS read latency chain of a hand-over sits under matrix instructions instead
+// of between two stages.  Two LDS buffers suffice (the buffer written in stage t was last read before the
+// barrier of stage t-1).  Stages past the end of the K range are gathered as all-out-of-range (zeros) and
+// written to LDS but never consumed.  Source order in the loop IS the issue order (sched_barrier(0) per slot).
+static constexpr int NTAP_FWD = 25;   // filter taps the offset table holds (5x5)
+static constexpr int NTAP_MIR = 9;    // ... for the fused reflect data gradient (4 source combinations)
+
+#ifdef EXP_NORD
+#define EXP_RD(x)
+#else
+#define EXP_RD(x) x
+#endif
+#ifdef EXP_NOWR
+#define EXP_WR(x)
+#else
+#define EXP_WR(x) x
+#endif
+
+// index along one axis of the gathered tensor for filter tap `tap`, or 0xffffffff if the tap falls outside.
+// Forward modes: p = output coordinate.  Backward modes: base = p + pad (or the padded-grid index of the mirror
+// image of p for the fused reflect gradient; base_ok = false if there is none).
+template <int MODE>
+__device__ __forceinline__ unsigned axis_entry(int p, int base, bool base_ok, int tap, int n, int sl, int pad) {
+    int i;
+    bool ok;
+    if (MODE == MODE_BWD || MODE == MODE_BWD_REFLECT) {
+        const int t = base - tap;
+        i = t >> sl;  // divisible by construction of the phase
+        ok = base_ok & (t >= 0) & (i < n);
+    } else {
+        i = (p << sl) - pad + tap;
+        if (MODE == MODE_FWD_REFLECT) {
+            i = i < 0 ? -i : i;
+            i = i >= n ? 2 * (n - 1) - i : i;
+            ok = true;
+        } else {
+            ok = (unsigned)i < (unsigned)n;
+        }
+    }
+    return ok ? (unsigned)i : 0xffffffffu;
+}
+
+__device__ __forceinline__ float4 ld_b128s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// Pixel enumeration of a phase: index -> (image, y, x) on the output grid.
+// MODE_BWD_REFLECT enumerates the pixels that receive no mirror image first (all images), then the others (rows /
+// columns 1..pad and H-1-pad..H-2), so that the tiles which need the extra mirror gathers are few and separate:
+// the bulk of the workgroups runs the plain one-source loop.
+__device__ __forceinline__ int refl_inner(int i, int n, int p) { return i == 0 ? 0 : (i == n - 2 * p - 1 ? n - 1 : i + p); }
+__device__ __forceinline__ int refl_border(int j, int n, int p) { return j < p ? 1 + j : n - 1 - 2 * p + j; }
+template <int MODE>
+__device__ __forceinline__ void pix_coord(const IgemmArgs& a, int HsWs, int Ws, int fy, int fx, int pg, int& n, int& py, int& px) {
+    if (MODE == MODE_BWD_REFLECT) {
+        const int H = a.Yh, W = a.Yw, p = a.pad;
+        const int hi = H - 2 * p, wi = W - 2 * p, nint = hi * wi, nbor = H * W - nint;
+        if (pg < a.N * nint) {
+            n = pg / nint;
+            const int rem = pg - n * nint;
+            const int iy = rem / wi;
+            py = refl_inner(iy, H, p);
+            px = refl_inner(rem - iy * wi, W, p);
+        } else {
+            const int q = pg - a.N * nint;
+            n = q / nbor;
+            const int rem = q - n * nbor;
+            if (rem < 2 * p * W) {
+                const int rb = rem / W;
+                py = refl_border(rb, H, p);
+                px = rem - rb * W;
+            } else {
+                const int j = rem - 2 * p * W;
+                const int iy = j / (2 * p);
+                py = refl_inner(iy, H, p);
+                px = refl_border(j - iy * 2 * p, W, p);
+            }
+        }
+    } else {
+        n = pg / HsWs;
+        const int rem = pg - n * HsWs;
+        const int sy = rem / Ws;
+        py = sy * a.ostep + fy;
+        px = (rem - sy * Ws) * a.ostep + fx;
+    }
+}
+
+template <int MODE, int BM, int BP>
+__global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
+    constexpr int WM = (BM == 128 || (BM == 64 && BP == 64)) ? 2 : 1;
+    constexpr int WP = 4 / WM;
+    constexpr int WMT = BM / WM, WPT = BP / WP;
+    constexpr int MI = WMT / 32, PJ = WPT / 32;
+    constexpr int AP = 20;
+    constexpr int KPT = BP / 16;
+    constexpr int ACH = (BM * 4 + 255) / 256;
+    constexpr bool MIR = MODE == MODE_BWD_REFLECT;
+    constexpr int TROWS = (MIR ? NTAP_MIR : NTAP_FWD) + 1;   // + one all-out-of-range row for dead stages
+    constexpr int NCOMB = MIR ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * AP];
+    __shared__ __attribute__((aligned(16))) float Bs[2][4 * BP * 4];
+    __shared__ unsigned offT[NCOMB][TROWS][BP];
+    __shared__ __attribute__((aligned(16))) float biasS[BM];
+
+    const PhaseArgs& P = a.ph[blockIdx.y];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WP, wp = wave % WP;
+    const int nMt = (a.M + BM - 1) / BM;
+    const int Ptot = P.Ptot, Kp = P.Kp;
+    const int ntiles = (Ptot + BP - 1) / BP;
+    const int mt = blockIdx.x % nMt;
+    int pt = blockIdx.x / nMt;
+    if (pt >= ntiles) return;
+#ifndef EXP_NOREV
+    if (MIR) pt = ntiles - 1 - pt;   // the (slower) tiles with mirror gathers are dispatched first
+#endif
+    const int m0 = mt * BM, p0 = pt * BP;
+    const int ph_nS = P.nS, ph_Ws = P.Ws, ph_fy = P.fy, ph_fx = P.fx;
+    const int T = P.nR * ph_nS;
+    const int HsWs = P.Hs * ph_Ws;
+    const int HgWg4 = a.Hg * a.Wg * 4;
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(P.A, (unsigned)a.M * (unsigned)Kp * 4u);
+
+    // --- gather-offset table of this workgroup's BP pixels ------------------------------
+    const int pl = tid % BP;
+    int myr = -1, mxr = -1;
+    {
+        const int pg = p0 + pl;
+        const bool pvalid = pg < Ptot;
+        int gn = 0, py = 0, px = 0;
+        if (pvalid) pix_coord<MODE>(a, HsWs, ph_Ws, ph_fy, ph_fx, pg, gn, py, px);
+        const unsigned vbase = (unsigned)gn * (unsigned)a.Cg * (unsigned)(a.Hg * a.Wg);
+        if (MIR && pvalid) {  // padded row j holds input row reflect(j - pad): row py also appears at these padded rows
+            if (py >= 1 && py <= a.pad) myr = a.pad - py;
+            else if (py >= a.Yh - 1 - a.pad && py <= a.Yh - 2) myr = a.pad + 2 * (a.Yh - 1) - py;
+            if (px >= 1 && px <= a.pad) mxr = a.pad - px;
+            else if (px >= a.Yw - 1 - a.pad && px <= a.Yw - 2) mxr = a.pad + 2 * (a.Yw - 1) - px;
+        }
+        for (int t = tid / BP; t <= T; t += 256 / BP) {
+            const int ri = t / ph_nS, sj = t - ri * ph_nS;
+            const int r = P.r0 + ri * a.tstep, sx = P.s0 + sj * a.tstep;
+            const bool live = pvalid && t < T;
+            const unsigned y = axis_entry<MODE>(py, py + a.pad, true, r, a.Hg, a.sl, a.pad);
+            const unsigned x = axis_entry<MODE>(px, px + a.pad, true, sx, a.Wg, a.sl, a.pad);
+            offT[0][t][pl] = (live && y != 0xffffffffu && x != 0xffffffffu) ? (vbase + y * (unsigned)a.Wg + x) * 4u : OOB;
+            if (MIR) {
+                const unsigned yb = axis_entry<MODE>(py, myr, myr >= 0, r, a.Hg, a.sl, a.pad);
+                const unsigned xb = axis_entry<MODE>(px, mxr, mxr >= 0, sx, a.Wg, a.sl, a.pad);
+                offT[NCOMB > 1 ? 1 : 0][t][pl] = (live && y != 0xffffffffu && xb != 0xffffffffu) ? (vbase + y * (unsigned)a.Wg + xb) * 4u : OOB;
+                offT[NCOMB > 1 ? 2 : 0][t][pl] = (live && yb != 0xffffffffu && x != 0xffffffffu) ? (vbase + yb * (unsigned)a.Wg + x) * 4u : OOB;
+                offT[NCOMB > 1 ? 3 : 0][t][pl] = (live && yb != 0xffffffffu && xb != 0xffffffffu) ? (vbase + yb * (unsigned)a.Wg + xb) * 4u : OOB;
+            }
+        }
+        if (tid < BM) biasS[tid] = (a.bias != nullptr && m0 + tid < a.M) ? a.bias[m0 + tid] : 0.f;
+    }
+    const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);
+
+    const int nst_all = Kp >> 4;
+    const int nst_per = a.ksplit > 1 ? (nst_all + a.ksplit - 1) / a.ksplit : nst_all;
+    const int st_begin = a.ksplit > 1 ? (int)blockIdx.z * nst_per : 0;
+    const int st_end = st_begin + nst_per < nst_all ? st_begin + nst_per : nst_all;
+
+    // load-side iterator (scalar; runs two stages ahead of the MFMA chain)
+    int it_c, it_tap, it_k0;
+    {
+        const int cc0 = st_begin / T;
+        it_tap = st_begin - cc0 * T;
+        it_c = cc0 * 16;
+        it_k0 = st_begin * 16;
+    }
+    unsigned a_base[ACH];
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) {
+        const int q = tid + 256 * j;
+        const int row = q >> 2, kc = (q & 3) * 4;
+        a_base[j] = ((row < BM) & (m0 + row < a.M)) ? (unsigned)((m0 + row) * Kp + kc) * 4u : OOB;
+    }
+
+    float4 areg[ACH];
+    float breg[KPT];
+    float bmir[MIR ? 3 : 1][MIR ? KPT : 1];
+    unsigned vo[NCOMB];          // gather offsets of the next load (bit 31 = out of range)
+    int vo_c = 0, vo_k0 = 0;     // channel chunk / A column of the stage `vo` belongs to
+
+    // offset-table read for the stage the iterator points at + iterator advance
+    auto next_offsets = [&](auto nm_tag) {
+        constexpr int NM = decltype(nm_tag)::value;
+        const int row = it_c >= a.Cg ? T : it_tap;     // stage past the end of K: the all-out-of-range row
+        const unsigned* tp = &offT[0][0][pl] + row * BP;
+        vo[0] = tp[0];
+        if constexpr (NM >= 1) vo[NCOMB > 1 ? 1 : 0] = tp[(NCOMB > 1 ? 1 : 0) * TROWS * BP];
+        if constexpr (NM >= 3) {
+            vo[NCOMB > 1 ? 2 : 0] = tp[(NCOMB > 1 ? 2 : 0) * TROWS * BP];
+            vo[NCOMB > 1 ? 3 : 0] = tp[(NCOMB > 1 ? 3 : 0) * TROWS * BP];
+        }
+        vo_c = it_c;
+        vo_k0 = it_k0;
+        const int t1 = it_tap + 1;
+        const bool wr = t1 == T;
+        it_tap = wr ? 0 : t1;
+        it_c += wr ? 16 : 0;
+        it_k0 += 16;
+    };
+    auto load_a = [&](int j) { areg[j] = ld_b128s(rA, a_base[j], (unsigned)vo_k0 * 4u); };
+    auto load_b = [&](int i, auto nm_tag) {
+        constexpr int NM = decltype(nm_tag)::value;
+        const unsigned so = (unsigned)((vo_c + ksub * KPT + i) * HgWg4);
+        breg[i] = ld_b32(rX, vo[0], so);
+        if constexpr (NM >= 1) bmir[0][i] = ld_b32(rX, vo[NCOMB > 1 ? 1 : 0], so);
+        if constexpr (NM >= 3) {
+            bmir[1][i] = ld_b32(rX, vo[NCOMB > 1 ? 2 : 0], so);
+            bmir[2][i] = ld_b32(rX, vo[NCOMB > 1 ? 3 : 0], so);
+        }
+    };
+    auto store_a = [&](int buf, int j) {
+        const int q = tid + 256 * j;
+        const int row = q >> 2, kc = (q & 3) * 4;
+        if (BM * 4 >= 256 || row < BM) *reinterpret_cast<float4*>(&As[buf][row * AP + kc]) = areg[j];
+    };
+    auto store_b = [&](int buf, int gq, auto nm_tag) {
+        constexpr int NM = decltype(nm_tag)::value;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = gq * 4 + e;
+            v[e] = breg[i];
+            if constexpr (NM == 1) v[e] += bmir[0][i];
+            if constexpr (NM == 3) v[e] += (bmir[0][i] + bmir[1][i]) + bmir[2][i];
+        }
+        *reinterpret_cast<float4*>(&Bs[buf][((ksub * (KPT / 4) + gq) * BP + pl) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+    };
+
+    f32x16 acc[MI][PJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < PJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float av0[MI][4], bv0[PJ][4], av1[MI][4], bv1[PJ][4];
+    auto read_a = [&](int buf, int q, int i, float (&av)[MI][4]) {
+        const float4 t = *reinterpret_cast<const float4*>(&As[buf][(wm * WMT + i * 32 + lo) * AP + (2 * q + hi) * 4]);
+        av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+    };
+    auto read_b = [&](int buf, int q, int j, float (&bv)[PJ][4]) {
+        const float4 t = *reinterpret_cast<const float4*>(&Bs[buf][((2 * q + hi) * BP + wp * WPT + j * 32 + lo) * 4]);
+        bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
+    };
+    // g-th matrix instruction of a half stage; consecutive ones hit different accumulators
+    auto mfma_one = [&](int g, const float (&av)[MI][4], const float (&bv)[PJ][4]) {
+        const int jj = g / (MI * PJ), i = (g / PJ) % MI, j = g % PJ;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][jj], bv[j][jj], acc[i][j], 0, 0, 0);
+    };
+
+    auto run = [&](auto nm_tag) {
+        constexpr int NH = MI * PJ * 4;                      // matrix instructions per half stage
+        // non-MFMA work of the first half, in issue order: operand reads (second half of this stage), LDS writes of
+        // stage st+1, global loads of stage st+2
+        constexpr int I_RA = 0, I_RB = I_RA + MI, I_WA = I_RB + PJ, I_WB = I_WA + ACH, I_LA = I_WB + KPT / 4,
+                      I_LB = I_LA + ACH, NI1 = I_LB + KPT;
+        // second half: operand reads of stage st+1 (first half), offset-table read for stage st+3
+        constexpr int J_RA = 0, J_RB = J_RA + MI, J_TA = J_RB + PJ, NI2 = J_TA + 1;
+        if (st_begin >= st_end) return;
+        __syncthreads();                                     // table visible
+        next_offsets(nm_tag);
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) load_a(j);             // stage 0
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) load_b(i, nm_tag);
+        next_offsets(nm_tag);
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) store_a(0, j);
+#pragma unroll
+        for (int gq = 0; gq < KPT / 4; ++gq) store_b(0, gq, nm_tag);
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) load_a(j);             // stage 1
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) load_b(i, nm_tag);
+        next_offsets(nm_tag);                                // offsets of stage 2
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) read_a(0, 0, i, av0);
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) read_b(0, 0, j, bv0);
+
+        auto stage = [&](auto buf_tag) {
+            constexpr int buf = decltype(buf_tag)::value;
+#pragma unroll
+            for (int g = 0; g < NH; ++g) {
+                mfma_one(g, av0, bv0);
+#pragma unroll
+                for (int k = 0; k < NI1; ++k) {
+                    if (k * NH / NI1 != g) continue;
+                    if (k < I_RB) { EXP_RD(read_a(buf, 1, k - I_RA, av1)); }
+                    else if (k < I_WA) { EXP_RD(read_b(buf, 1, k - I_RB, bv1)); }
+                    else if (k < I_WB) { EXP_WR(store_a(buf ^ 1, k - I_WA)); }
+                    else if (k < I_LA) { EXP_WR(store_b(buf ^ 1, k - I_WB, nm_tag)); }
+#ifndef EXP_NOLOAD
+                    else if (k < I_LB) load_a(k - I_LA);
+                    else load_b(k - I_LB, nm_tag);
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifdef EXP_NOBAR
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NH; ++g) {
+                mfma_one(g, av1, bv1);
+#pragma unroll
+                for (int k = 0; k < NI2; ++k) {
+                    if (k * NH / NI2 != g) continue;
+                    if (k < J_RB) { EXP_RD(read_a(buf ^ 1, 0, k - J_RA, av0)); }
+                    else if (k < J_TA) { EXP_RD(read_b(buf ^ 1, 0, k - J_RB, bv0)); }
+                    else next_offsets(nm_tag);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        for (int st = st_begin; st < st_end; st += 2) {
+            stage(std::integral_constant<int, 0>{});
+            if (st + 1 < st_end) stage(std::integral_constant<int, 1>{});
+        }
+    };
+    if (MIR) {  // workgroup-uniform: does any of its pixels receive a mirror image?
+#ifdef EXP_NM0
+        if (__syncthreads_or((myr >= 0) | (mxr >= 0)) && a.N < 0) run(std::integral_constant<int, 3>{});
+#else
+        if (__syncthreads_or((myr >= 0) | (mxr >= 0))) run(std::integral_constant<int, 3>{});
+#endif
+        else run(std::integral_constant<int, 0>{});
+    } else {
+        run(std::integral_constant<int, 0>{});
+    }
+
+    // --- epilogue: bias (from LDS) + activation, NCHW store (pixel on the lane -> coalesced) ------
+    const int YhYw = a.Yh * a.Yw;
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        const int pix = p0 + wp * WPT + j * 32 + lo;
+        if (pix >= Ptot) continue;
+        int n, oy, ox;
+        pix_coord<MODE>(a, HsWs, ph_Ws, ph_fy, ph_fx, pix, n, oy, ox);
+        if (a.ksplit > 1) {
+            float* Yp = a.Ypart + ((size_t)blockIdx.z * a.N + n) * a.M * YhYw + oy * a.Yw + ox;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (m < a.M) Yp[(size_t)m * YhYw] = acc[i][j][r];
+                }
+            }
+            continue;
+        }
+        float* Yp = a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int ml = wm * WMT + i * 32 + 8 * rq + 4 * hi;      // 4 consecutive output channels
+                const float4 bq = *reinterpret_cast<const float4*>(&biasS[ml]);
+                const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + ml + e;
+                    if (m < a.M) Yp[(size_t)m * YhYw] = act_apply(acc[i][j][rq * 4 + e] + bb[e], a.act, a.slope);
                 }
             }
         }
@@ -1093,6 +1503,8 @@ static int check_desc(const pcgan_conv_desc* d) {
 // tile choice: the largest tile that still gives the 256 CUs >= ~1.5 workgroups each; problems with few
 // pixels but a long K loop (the encoder's 7x7 / 14x14 stages, the PatchGAN's 16x16 stage) keep the big tile
 // and are cut along K instead (split-K, partial sums reduced by splitk_reduce_kernel)
+// chunked K order / igemm2_kernel: gathered channel count a multiple of 16, taps fit the LDS tables, MFMA path
+static inline bool chunked_k(int Cg, int M, int R, int S) { return (Cg % 16) == 0 && M > 4 && R * S <= NTAP_FWD; }
 static inline long tile_blocks(int M, int ptot_max, int nphase, int mm, int pp) {
     return (long)((M + mm - 1) / mm) * ((ptot_max + pp - 1) / pp) * nphase;
 }
@@ -1166,11 +1578,19 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
         a.stagger = env ? atoi(env) : 0;
     }
     const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((pmax + bp - 1) / bp)), (unsigned)a.nphase, (unsigned)ks);
-    const bool cg16 = (a.Cgp % 16) == 0;
+    const bool cg16 = a.chunked != 0;
     PCGAN_CHECK(cg16 || MODE != MODE_BWD_REFLECT, "igemm: fused reflect data-gradient needs K %% 16 == 0");
+    if (cg16) {
+        PCGAN_CHECK((a.Cg % 16) == 0, "igemm: chunked K order needs a multiple of 16 channels");
+        for (int i = 0; i < a.nphase; ++i)
+            PCGAN_CHECK(a.ph[i].nR * a.ph[i].nS <= (MODE == MODE_BWD_REFLECT ? NTAP_MIR : NTAP_FWD) && (a.ph[i].Kp % 16) == 0,
+                        "igemm: chunked K order: bad phase");
+    }
+    static const bool old_kernel = getenv("PCGAN_OLD_IGEMM") != nullptr;   // A/B experiments
 #define LI(BMV, BPV)                                                                                   \
     do {                                                                                               \
-        if (cg16) hipLaunchKernelGGL((igemm_kernel<MODE, BMV, BPV, true>), grid, dim3(256), 0, st, a); \
+        if (cg16 && !old_kernel) hipLaunchKernelGGL((igemm2_kernel<MODE, BMV, BPV>), grid, dim3(256), 0, st, a); \
+        else if (cg16) hipLaunchKernelGGL((igemm_kernel<MODE, BMV, BPV, true>), grid, dim3(256), 0, st, a); \
         else if (MODE != MODE_BWD_REFLECT)                                                             \
             hipLaunchKernelGGL((igemm_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV, false>), grid, \
                                dim3(256), 0, st, a);                                                   \
@@ -1266,7 +1686,7 @@ static int pack_fwd(const pcgan_conv_desc* d, const float* w, float* A, hipStrea
     const size_t total = (size_t)d->K * RS * Cgp;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(repack_fwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Cgp, RS,
-                       (int)((Cgp % 16) == 0 && d->K > 4));
+                       (int)chunked_k(d->C, d->K, d->R, d->S));
     PCGAN_LAUNCH_CHECK();
     if (d->K <= 4) {
         hipLaunchKernelGGL(transpose4_kernel, dim3((RS * Cgp * 4 + 255) / 256), dim3(256), 0, st, (const float*)A,
@@ -1296,6 +1716,7 @@ static int conv2d_fwd_impl(const pcgan_conv_desc* d, const float* x, const float
     a.act = act; a.slope = slope;
     a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
     a.nphase = 1;
+    a.chunked = chunked_k(d->C, d->K, d->R, d->S);
     PhaseArgs& p = a.ph[0];
     p.A = A; p.Kp = RS * Cgp; p.Hs = d->P; p.Ws = d->Q; p.fy = 0; p.fx = 0;
     if (d->K <= 4) p.A = A + (size_t)d->K * RS * Cgp;  // small-M path reads the weights as [k][4]
@@ -1336,7 +1757,8 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     size_t at_off = (size_t)d->C * RS * Kgp;  // transposed copies for the small-M path live behind the A's
     // reflection: gather the mirror images directly (fused, needs K % 16 == 0 and H,W >= 2 pad + 2); otherwise
     // compute the gradient of the PADDED input (pad 0 on a larger grid) and fold it back
-    const bool fused = d->pad_mode == 1 && !smallm && (Kgp % 16) == 0 && d->H >= 2 * d->pad + 2 && d->W >= 2 * d->pad + 2;
+    const bool chunked = chunked_k(d->K, d->C, d->R, d->S);
+    const bool fused = d->pad_mode == 1 && chunked && d->R * d->S <= NTAP_MIR && d->H >= 2 * d->pad + 2 && d->W >= 2 * d->pad + 2;
     const bool reflect = d->pad_mode == 1 && !fused;
     const int H = reflect ? d->H + 2 * d->pad : d->H;
     const int W = reflect ? d->W + 2 * d->pad : d->W;
@@ -1351,6 +1773,7 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     a.Yh = H; a.Yw = W;
     a.ostep = stv; a.sl = ilog2_exact(stv); a.pad = pad; a.tstep = stv;
     a.act = PCGAN_ACT_NONE; a.slope = 0.f;
+    a.chunked = chunked;
     a.x_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * 4);
 
     // one phase per (iy % stride, ix % stride): only the taps that are structurally non-zero for it
@@ -1374,7 +1797,7 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
             const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
             if (do_pack) {
                 hipLaunchKernelGGL(repack_bwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Kgp, d->R,
-                                   d->S, r0, s0, stv, nR, nS, (int)((Kgp % 16) == 0 && !smallm));
+                                   d->S, r0, s0, stv, nR, nS, (int)chunked);
                 PCGAN_LAUNCH_CHECK();
             }
             PhaseArgs& p = a.ph[a.nphase++];

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libpcgan_hip.so')
+LIB_PATH = os.environ.get('PCGAN_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libpcgan_hip.so')
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PASS_FWD, PASS_BWD_DATA, PASS_BWD_WEIGHT = 0, 1, 2
