@@ -1456,6 +1456,250 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Weight gradient, pipelined version for tap-aligned K tiles (padded channel count a multiple of 128, or 64):
+// same recipe as igemm2_kernel -- few non-scalar instructions per matrix instruction, every wait long after its
+// request, source order = issue order.
+//   tile  : BM output channels x 128 K-columns (one filter tap x 128 channels, or two taps x 64), reduction over
+//           pixels in stages of 32, split over pixel ranges (blockIdx.y) with a deterministic second-pass sum
+//   offsets: the per-pixel gather offsets (padding / reflection / stride arithmetic, two integer divisions) are
+//           computed by all 256 threads for 8 stages at a time into a 16-slot LDS ring; a stage then needs
+//           NT + 1 four-byte LDS reads
+//   stage t: group 0/1 of the MFMA chain + LDS writes of stage t+1 (loaded one stage ago)
+//            group 2/3 + global loads of stage t+2; the barrier sits between group 2 and 3, the operands of
+//            stage t+1's first group are read under group 3
+template <int MODE, int BM, bool VECA, int NT>
+__global__ void __launch_bounds__(256) wgrad2_kernel(WgradArgs a) {
+    constexpr int BN = 128;
+    constexpr int WM = (BM == 128) ? 2 : 1;
+    constexpr int WN = 4 / WM;
+    constexpr int WMT = BM / WM, WNT = BN / WN;
+    constexpr int MI = WMT / 32, NJ = WNT / 32;
+    constexpr int PT = 36;
+    constexpr int AR = BM / 8, BR = BN / 8;
+    constexpr int AV = BM / 32;
+    constexpr int NA = VECA ? AV : AR;          // dY loads / LDS writes per thread and stage
+    constexpr int RING = 16;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * PT];
+    __shared__ __attribute__((aligned(16))) float Gs[2][BN * PT];
+    __shared__ unsigned xoffT[RING][NT][32];
+    __shared__ unsigned yoffT[RING][32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int pl = tid & 31, rg = tid >> 5;
+
+    const int nKt = (a.Kp + BN - 1) / BN;
+    const int kt = blockIdx.x % nKt, mt = blockIdx.x / nKt;
+    const int m0 = mt * BM, kb = kt * BN;
+    const int split = blockIdx.y;
+    const int HoWo = a.Ho * a.Wo, HgWg = a.Hg * a.Wg;
+    const int HoWo4 = HoWo * 4, HgWg4 = HgWg * 4;
+    const Geom g{a.Hg, a.Wg, a.sl, a.pad};
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.dY, a.dy_bytes);
+    const int tap_b = kb / a.Cgp, c_b = kb - tap_b * a.Cgp;
+    const int ntaps = a.Kp / a.Cgp;
+
+    const int nchunks = (a.Ptot + 31) / 32;
+    const int c_begin = split * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    if (c_end > nchunks) c_end = nchunks;
+    const int nst = c_end - c_begin;
+
+    // offsets of 8 stages (relative chunks tb .. tb+7) -> ring slots
+    auto refill = [&](int tb) {
+        const int rel = tb + (tid >> 5);
+        const int slot = rel & (RING - 1);
+        const int pg = (c_begin + rel) * 32 + pl;
+        const bool valid = (pg < a.Ptot) & (c_begin + rel < c_end);
+        const int n = pg / HoWo;
+        const int rem = pg - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        yoffT[slot][pl] = valid ? (unsigned)((n * a.M + m0) * HoWo + rem) * 4u : OOB;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int tap = tap_b + ti;
+            const int r = tap / a.S, sx = tap - r * a.S;
+            int off;
+            const bool ok = tap_offset<MODE>(g, oy, ox, r, sx, off) & valid & (tap < ntaps);
+            xoffT[slot][ti][pl] = ok ? (unsigned)(n * a.Cg * HgWg + off) * 4u : OOB;
+        }
+    };
+
+    // per-thread constant parts of the load offsets (bit 31 = row out of range)
+    const int pc = (tid & 7) * 4;
+    const unsigned yrow = VECA ? (unsigned)((tid >> 3) * HoWo4) : (unsigned)(rg * HoWo4);
+    unsigned yflag[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int row = VECA ? (tid >> 3) + 32 * j : rg + 8 * j;
+        yflag[j] = (m0 + row < a.M) ? 0u : OOB;
+    }
+    const unsigned xrow = (unsigned)(rg * HgWg4);
+
+    float areg[VECA ? 4 * AV : AR], breg[BR];
+    unsigned yo = OOB, xo[NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) xo[ti] = OOB;
+    unsigned yraw = OOB, xraw[NT];
+    auto read_offsets = [&](int rel) {   // ring-table entries of relative chunk `rel` (raw: used one group later)
+        const int slot = rel & (RING - 1);
+        yraw = yoffT[slot][VECA ? pc : pl];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) xraw[ti] = xoffT[slot][ti][pl];
+    };
+    auto combine_offsets = [&]() {
+        yo = yraw + yrow;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) xo[ti] = xraw[ti] + xrow;
+    };
+    auto load_a = [&](int j) {
+        if (VECA) {
+            const float4 v = ld_b128s(rY, yo | yflag[j], (unsigned)(32 * j * HoWo4));
+            areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
+        } else {
+            areg[j] = ld_b32(rY, yo | yflag[j], (unsigned)(8 * j * HoWo4));
+        }
+    };
+    auto load_b = [&](int i) {
+        constexpr int PER = BR / NT;   // K-columns (i) per tap
+        breg[i] = ld_b32(rX, xo[i / PER], (unsigned)((c_b + 8 * (i % PER)) * HgWg4));
+    };
+    auto store_a = [&](int buf, int j) {
+        if (VECA) {
+            *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * j) * PT + pc]) =
+                make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
+        } else {
+            As[buf][(rg + 8 * j) * PT + pl] = areg[j];
+        }
+    };
+    auto store_b = [&](int buf, int i) { Gs[buf][(rg + 8 * i) * PT + pl] = breg[i]; };
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float av[2][MI][4], bv[2][NJ][4];   // operand sets of two consecutive MFMA groups
+    auto read_op = [&](int buf, int q, int k, int set) {   // k-th operand read of group q: A rows first, then B
+        if (k < MI) {
+            const float4 t = *reinterpret_cast<const float4*>(&As[buf][(wm * WMT + k * 32 + lo) * PT + (2 * q + hi) * 4]);
+            av[set][k][0] = t.x; av[set][k][1] = t.y; av[set][k][2] = t.z; av[set][k][3] = t.w;
+        } else {
+            const int j = k - MI;
+            const float4 t = *reinterpret_cast<const float4*>(&Gs[buf][(wn * WNT + j * 32 + lo) * PT + (2 * q + hi) * 4]);
+            bv[set][j][0] = t.x; bv[set][j][1] = t.y; bv[set][j][2] = t.z; bv[set][j][3] = t.w;
+        }
+    };
+    auto mfma_one = [&](int gidx, int set) {
+        const int jj = gidx / (MI * NJ), i = (gidx / NJ) % MI, j = gidx % NJ;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][i][jj], bv[set][j][jj], acc[i][j], 0, 0, 0);
+    };
+
+    if (nst > 0) {
+        refill(0);
+        refill(8);
+        __syncthreads();
+        read_offsets(0);
+        combine_offsets();
+#pragma unroll
+        for (int j = 0; j < NA; ++j) load_a(j);
+#pragma unroll
+        for (int i = 0; i < BR; ++i) load_b(i);
+        read_offsets(1);
+        combine_offsets();
+#pragma unroll
+        for (int j = 0; j < NA; ++j) store_a(0, j);
+#pragma unroll
+        for (int i = 0; i < BR; ++i) store_b(0, i);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) load_a(j);
+#pragma unroll
+        for (int i = 0; i < BR; ++i) load_b(i);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MI + NJ; ++k) read_op(0, 0, k, 0);
+
+        constexpr int NG = MI * NJ * 4;            // matrix instructions per group
+        constexpr int NOP = MI + NJ;               // operand reads per group
+        constexpr int NWR = NA + BR, NLD = NA + BR;
+        constexpr int NW0 = NWR / 2, NL0 = NLD / 2;
+        auto stage = [&](int t, auto buf_tag) {
+            constexpr int buf = decltype(buf_tag)::value;
+            // group q computes with operand set q & 1 and issues: the reads of group q+1's operands, plus its share of
+            // LDS writes (groups 0, 1) / global loads (groups 2, 3)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n_extra = q == 0 ? NW0 + 1 : (q == 1 ? NWR - NW0 : (q == 2 ? NL0 + 1 : NLD - NL0));
+                const int n_items = NOP + n_extra;
+                if (q == 3) {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int gI = 0; gI < NG; ++gI) {
+                    mfma_one(gI, q & 1);
+#pragma unroll
+                    for (int k = 0; k < n_items; ++k) {
+                        if (k * NG / n_items != gI) continue;
+                        if (k < NOP) {
+                            if (q < 3) read_op(buf, q + 1, k, (q + 1) & 1);
+                            else read_op(buf ^ 1, 0, k, 0);
+                        } else {
+                            const int e = k - NOP;
+                            if (q == 0) {
+                                if (e == 0) read_offsets(t + 2);
+                                else if (e - 1 < NA) store_a(buf ^ 1, e - 1);
+                                else store_b(buf ^ 1, e - 1 - NA);
+                            } else if (q == 1) {
+                                const int w = NW0 + e;
+                                if (w < NA) store_a(buf ^ 1, w);
+                                else store_b(buf ^ 1, w - NA);
+                            } else if (q == 2) {
+                                if (e == 0) combine_offsets();
+                                else if (e - 1 < NA) load_a(e - 1);
+                                else load_b(e - 1 - NA);
+                            } else {
+                                const int l = NL0 + e;
+                                if (l < NA) load_a(l);
+                                else load_b(l - NA);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        for (int t = 0; t < nst; t += 2) {
+            if ((t & 7) == 0 && t > 0) refill(t + 8);
+            stage(t, std::integral_constant<int, 0>{});
+            if (t + 1 < nst) stage(t + 1, std::integral_constant<int, 1>{});
+        }
+    }
+    // partial tile store: row = m, column = k (lane) -> coalesced
+    float* Wp = a.Wp + (size_t)split * a.M * a.Kp;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int kcol = kb + wn * WNT + j * 32 + lo;
+        if (kcol >= a.Kp) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < a.M) Wp[(size_t)m * a.Kp + kcol] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 // dw[k][c][r][s] = sum_split Wp[split][k][tap*Cgp + c]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ Wp, float* __restrict__ dw, int splits, int K,
                                     int C, int Cgp, int RS, int accumulate) {
@@ -1903,6 +2147,18 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
     const bool reflect = d->pad_mode == 1;
     const bool veca = ((d->P * d->Q) % 4) == 0;
     const int kmode = smallc ? 1 : ((Cgp % 128) == 0 ? 2 : 0);
+    static const bool old_wgrad = getenv("PCGAN_OLD_WGRAD") != nullptr;   // A/B experiments
+    const bool w2 = !old_wgrad && (d->C % 64) == 0 && ((Cgp % 128) == 0 || Cgp == 64);
+    if (w2) {
+#define LW2(MODE, BMV, VA) do { if (Cgp == 64) hipLaunchKernelGGL((wgrad2_kernel<MODE, BMV, VA, 2>), grid, dim3(256), 0, st, a); \
+                                else hipLaunchKernelGGL((wgrad2_kernel<MODE, BMV, VA, 1>), grid, dim3(256), 0, st, a); } while (0)
+#define LW2_VA(MODE, BMV) do { if (veca) LW2(MODE, BMV, true); else LW2(MODE, BMV, false); } while (0)
+#define LW2_BM(MODE) do { if (bm == 128) LW2_VA(MODE, 128); else if (bm == 64) LW2_VA(MODE, 64); else LW2_VA(MODE, 32); } while (0)
+        if (reflect) LW2_BM(MODE_FWD_REFLECT); else LW2_BM(MODE_FWD_ZERO);
+#undef LW2_BM
+#undef LW2_VA
+#undef LW2
+    } else {
 #define LW(MODE, BMV, KM, VA) hipLaunchKernelGGL((wgrad_kernel<MODE, BMV, KM, VA>), grid, dim3(256), 0, st, a)
 #define LW_VA(MODE, BMV, KM) do { if (veca) LW(MODE, BMV, KM, true); else LW(MODE, BMV, KM, false); } while (0)
 #define LW_SC(MODE, BMV) do { if (kmode == 1) LW_VA(MODE, BMV, 1); else if (kmode == 2) LW_VA(MODE, BMV, 2); else LW_VA(MODE, BMV, 0); } while (0)
@@ -1912,6 +2168,7 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
 #undef LW_SC
 #undef LW_VA
 #undef LW
+    }
     PCGAN_LAUNCH_CHECK();
     {
         const size_t total = (size_t)d->K * RS * Cgp;
