@@ -57,15 +57,25 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_bwd_data(dy, w, (x.shape[2], x.shape[3]), stride, pad, pad_mode, pack_cache=ctx.pack)
-        if ctx.needs_input_grad[1]:
-            tgt = _fused_grad_target(ctx.params[0])
-            dw = ops.conv2d_bwd_weight(x, dy, tuple(w.shape), stride, pad, pad_mode, accumulate_into=tgt)
-            if tgt is not None:
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        wt = _fused_grad_target(ctx.params[0]) if want_w else None
+        bt = _fused_grad_target(ctx.params[1]) if want_b else None
+        if ops.SIDE_STREAM and (not want_w or wt is not None) and (not want_b or bt is not None) and (want_w or want_b):
+            # both go straight into the optimizer's gradient buffer: nobody in this backward pass reads them
+            with ops.fork_side(x, dy):
+                if want_w:
+                    ops.conv2d_bwd_weight(x, dy, tuple(w.shape), stride, pad, pad_mode, accumulate_into=wt)
+                if want_b:
+                    ops.channel_sum(dy, accumulate_into=bt)
+            return dx, None, None, None, None, None, None, None
+        if want_w:
+            dw = ops.conv2d_bwd_weight(x, dy, tuple(w.shape), stride, pad, pad_mode, accumulate_into=wt)
+            if wt is not None:
                 dw = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            tgt = _fused_grad_target(ctx.params[1])
-            db = ops.channel_sum(dy, accumulate_into=tgt)
-            if tgt is not None:
+        if want_b:
+            db = ops.channel_sum(dy, accumulate_into=bt)
+            if bt is not None:
                 db = None
         return dx, dw, db, None, None, None, None, None
 

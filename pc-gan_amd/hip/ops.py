@@ -3,6 +3,7 @@ torch's caching allocator (device memory plumbing only) and launch on torch's cu
 stream.  No arithmetic happens in Python or in torch here.
 """
 import ctypes
+import os
 
 import torch
 
@@ -43,6 +44,57 @@ def conv_out_size(H, k, stride, pad):
 def make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode):
     return ConvDesc(N, C, H, W, K, R, S, stride, pad, pad_mode,
                     conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad))
+
+
+# ---------------------------------------------------------------- side stream for parameter gradients
+# In a backward pass the data gradient of a layer feeds the next layer while its weight / bias gradients feed
+# nobody until the optimizer runs.  They are launched on a second HIP stream, so the hardware overlaps them
+# with the data-gradient chain (fills each kernel's ramp-up / tail and the small launches in between).  The
+# main stream joins at the end of the backward pass (autograd callback) -- results and summation order are
+# unchanged (all parameter-gradient kernels run in issue order on the one side stream).
+SIDE_STREAM = os.environ.get('PCGAN_SIDE_STREAM', '1') != '0'
+_side = {}
+_side_state = {'dirty': False, 'queued': False}
+
+
+class fork_side(object):
+    """with fork_side(t1, t2, ...): launches inside go to the side stream, after everything already queued on
+    the current stream; the tensors are kept alive until the side stream is done with them."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        cur = torch.cuda.current_stream()
+        dev = cur.device
+        st = _side.get(dev)
+        if st is None:
+            st = _side[dev] = torch.cuda.Stream(device=dev)
+        st.wait_stream(cur)
+        for t in self.tensors:
+            t.record_stream(st)
+        self.ctx = torch.cuda.stream(st)
+        self.ctx.__enter__()
+        _side_state['dirty'] = True
+        if not _side_state['queued']:
+            try:    # join automatically when the running backward pass ends
+                torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+                _side_state['queued'] = True
+            except RuntimeError:
+                pass
+        return st
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def join_side_stream():
+    """Make the current stream wait for everything launched on the side stream."""
+    _side_state['queued'] = False
+    if _side_state['dirty']:
+        for st in _side.values():
+            torch.cuda.current_stream(st.device).wait_stream(st)
+        _side_state['dirty'] = False
 
 
 # ---------------------------------------------------------------- convolution family

@@ -56,6 +56,7 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         """Zero the flat gradient buffer (one memset) and keep every .grad a view into it so that
         autograd accumulates in place."""
+        ops.join_side_stream()
         self.gflat.zero_()
         for p, gv in self._views:
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
@@ -75,6 +76,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        ops.join_side_stream()            # parameter-gradient kernels run on a side stream
         g = self.param_groups[0]
         lr = float(g['lr'])
         if lr != self._lr_host:           # scheduler changed it (once per epoch)

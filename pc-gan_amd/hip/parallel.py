@@ -69,6 +69,8 @@ def sync_gradients(optimizer):
     (flat buffer), otherwise one flattened collective over its parameter grads."""
     if not is_distributed():
         return
+    from . import ops
+    ops.join_side_stream()
     gflat = getattr(optimizer, 'gflat', None)
     if gflat is not None:
         allreduce_mean_(gflat)
