@@ -51,6 +51,7 @@ struct PhaseArgs {
     int fy, fx;      // output coordinate = sub * ostep + f
     int r0, s0, nR, nS;  // taps: r = r0 + i*tstep (i < nR), s = s0 + j*tstep (j < nS)
     int Ptot;        // N * Hs * Ws
+    int ymap;        // 1: sub-grid row sy is output row {0, pad+1 .. H-2-pad, H-1}[sy] (rows without a mirror image)
 };
 
 struct IgemmArgs {
@@ -65,9 +66,11 @@ struct IgemmArgs {
     unsigned x_bytes;
     int nphase;
     int stagger;  // > 0: waves in odd hardware slots sleep this many 64-cycle units before starting
+    int rowfold;  // MODE_BWD_REFLECT: the row mirrors are folded into per-phase weights, only column mirrors are gathered
     int chunked;  // K order of ph[].A: 1 = (16-channel chunk, tap, channel) -> igemm2_kernel, 0 = (tap, channel)
     int ksplit;   // > 1: blockIdx.z takes a contiguous range of K stages and stores a raw partial sum
     float* Ypart; // [ksplit][N][M][Yh][Yw] partial sums (then reduced + bias + activation by splitk_reduce)
+    int tstart[17];  // igemm2_kernel: first pixel tile of each phase in the linearised grid (no empty workgroups)
     PhaseArgs ph[16];
 };
 
@@ -545,45 +548,15 @@ __device__ __forceinline__ float4 ld_b128s(__amdgpu_buffer_rsrc_t r, unsigned vo
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// Pixel enumeration of a phase: index -> (image, y, x) on the output grid.
-// MODE_BWD_REFLECT enumerates the pixels that receive no mirror image first (all images), then the others (rows /
-// columns 1..pad and H-1-pad..H-2), so that the tiles which need the extra mirror gathers are few and separate:
-// the bulk of the workgroups runs the plain one-source loop.
+// Pixel enumeration of a phase: index -> (image, y, x) on the output grid (row-major, lanes stay coalesced).
 __device__ __forceinline__ int refl_inner(int i, int n, int p) { return i == 0 ? 0 : (i == n - 2 * p - 1 ? n - 1 : i + p); }
-__device__ __forceinline__ int refl_border(int j, int n, int p) { return j < p ? 1 + j : n - 1 - 2 * p + j; }
-template <int MODE>
-__device__ __forceinline__ void pix_coord(const IgemmArgs& a, int HsWs, int Ws, int fy, int fx, int pg, int& n, int& py, int& px) {
-    if (MODE == MODE_BWD_REFLECT) {
-        const int H = a.Yh, W = a.Yw, p = a.pad;
-        const int hi = H - 2 * p, wi = W - 2 * p, nint = hi * wi, nbor = H * W - nint;
-        if (pg < a.N * nint) {
-            n = pg / nint;
-            const int rem = pg - n * nint;
-            const int iy = rem / wi;
-            py = refl_inner(iy, H, p);
-            px = refl_inner(rem - iy * wi, W, p);
-        } else {
-            const int q = pg - a.N * nint;
-            n = q / nbor;
-            const int rem = q - n * nbor;
-            if (rem < 2 * p * W) {
-                const int rb = rem / W;
-                py = refl_border(rb, H, p);
-                px = rem - rb * W;
-            } else {
-                const int j = rem - 2 * p * W;
-                const int iy = j / (2 * p);
-                py = refl_inner(iy, H, p);
-                px = refl_border(j - iy * 2 * p, W, p);
-            }
-        }
-    } else {
-        n = pg / HsWs;
-        const int rem = pg - n * HsWs;
-        const int sy = rem / Ws;
-        py = sy * a.ostep + fy;
-        px = (rem - sy * Ws) * a.ostep + fx;
-    }
+__device__ __forceinline__ void pix_coord(const IgemmArgs& a, const PhaseArgs& P, int pg, int& n, int& py, int& px) {
+    const int HsWs = P.Hs * P.Ws;
+    n = pg / HsWs;
+    const int rem = pg - n * HsWs;
+    const int sy = rem / P.Ws;
+    py = P.ymap ? refl_inner(sy, a.Yh, a.pad) : sy * a.ostep + P.fy;
+    px = (rem - sy * P.Ws) * a.ostep + P.fx;
 }
 
 template <int MODE, int BM, int BP>
@@ -603,20 +576,18 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
     __shared__ unsigned offT[NCOMB][TROWS][BP];
     __shared__ __attribute__((aligned(16))) float biasS[BM];
 
-    const PhaseArgs& P = a.ph[blockIdx.y];
+    const int nMt = (a.M + BM - 1) / BM;
+    const int mt = blockIdx.x % nMt;
+    int pt = blockIdx.x / nMt;
+    int phase = 0;
+    while (phase + 1 < a.nphase && pt >= a.tstart[phase + 1]) ++phase;   // grid.x = all phases' tiles back to back
+    pt -= a.tstart[phase];
+    const PhaseArgs& P = a.ph[phase];
     const int tid = threadIdx.x;
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WP, wp = wave % WP;
-    const int nMt = (a.M + BM - 1) / BM;
     const int Ptot = P.Ptot, Kp = P.Kp;
-    const int ntiles = (Ptot + BP - 1) / BP;
-    const int mt = blockIdx.x % nMt;
-    int pt = blockIdx.x / nMt;
-    if (pt >= ntiles) return;
-#ifndef EXP_NOREV
-    if (MIR) pt = ntiles - 1 - pt;   // the (slower) tiles with mirror gathers are dispatched first
-#endif
     const int m0 = mt * BM, p0 = pt * BP;
     const int ph_nS = P.nS, ph_Ws = P.Ws, ph_fy = P.fy, ph_fx = P.fx;
     const int T = P.nR * ph_nS;
@@ -632,13 +603,14 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
         const int pg = p0 + pl;
         const bool pvalid = pg < Ptot;
         int gn = 0, py = 0, px = 0;
-        if (pvalid) pix_coord<MODE>(a, HsWs, ph_Ws, ph_fy, ph_fx, pg, gn, py, px);
+        if (pvalid) pix_coord(a, P, pg, gn, py, px);
         const unsigned vbase = (unsigned)gn * (unsigned)a.Cg * (unsigned)(a.Hg * a.Wg);
         if (MIR && pvalid) {  // padded row j holds input row reflect(j - pad): row py also appears at these padded rows
             if (py >= 1 && py <= a.pad) myr = a.pad - py;
             else if (py >= a.Yh - 1 - a.pad && py <= a.Yh - 2) myr = a.pad + 2 * (a.Yh - 1) - py;
             if (px >= 1 && px <= a.pad) mxr = a.pad - px;
             else if (px >= a.Yw - 1 - a.pad && px <= a.Yw - 2) mxr = a.pad + 2 * (a.Yw - 1) - px;
+            if (a.rowfold) myr = -1;   // this phase's weights already carry the row mirror
         }
         for (int t = tid / BP; t <= T; t += 256 / BP) {
             const int ri = t / ph_nS, sj = t - ri * ph_nS;
@@ -831,11 +803,15 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
             if (st + 1 < st_end) stage(std::integral_constant<int, 1>{});
         }
     };
-    if (MIR) {  // workgroup-uniform: does any of its pixels receive a mirror image?
+    if (MIR) {  // workgroup-uniform: how many mirror images do its pixels receive at most?
+        const int any2 = __syncthreads_or((myr >= 0) & (mxr >= 0));
+        const int any1 = __syncthreads_or((myr >= 0) | (mxr >= 0));
 #ifdef EXP_NM0
-        if (__syncthreads_or((myr >= 0) | (mxr >= 0)) && a.N < 0) run(std::integral_constant<int, 3>{});
+        if (a.N < 0) run(std::integral_constant<int, 3>{});
+        else if (a.N < -1) run(std::integral_constant<int, 1>{});
 #else
-        if (__syncthreads_or((myr >= 0) | (mxr >= 0))) run(std::integral_constant<int, 3>{});
+        if (any2 || (any1 && !a.rowfold)) run(std::integral_constant<int, 3>{});
+        else if (any1) run(std::integral_constant<int, 1>{});      // column mirrors only (table slot 1)
 #endif
         else run(std::integral_constant<int, 0>{});
     } else {
@@ -849,7 +825,7 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
         const int pix = p0 + wp * WPT + j * 32 + lo;
         if (pix >= Ptot) continue;
         int n, oy, ox;
-        pix_coord<MODE>(a, HsWs, ph_Ws, ph_fy, ph_fx, pix, n, oy, ox);
+        pix_coord(a, P, pix, n, oy, ox);
         if (a.ksplit > 1) {
             float* Yp = a.Ypart + ((size_t)blockIdx.z * a.N + n) * a.M * YhYw + oy * a.Yw + ox;
 #pragma unroll
@@ -1186,7 +1162,7 @@ __global__ void repack_fwd_kernel(const float* __restrict__ w, float* __restrict
 }
 // backward-data, one stride phase: A[c][(ri,sj)][k] (Kgp-padded) from w[K][C][R][S]
 __global__ void repack_bwd_kernel(const float* __restrict__ w, float* __restrict__ A, int K, int C, int Kgp,
-                                  int R, int S, int r0, int s0, int tstep, int nR, int nS, int chunked) {
+                                  int R, int S, int r0, int s0, int tstep, int nR, int nS, int chunked, int fold) {
     const int Kp = nR * nS * Kgp;
     const size_t total = (size_t)C * Kp;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -1204,7 +1180,12 @@ __global__ void repack_bwd_kernel(const float* __restrict__ w, float* __restrict
         }
         const int ri = t / nS, sj = t - ri * nS;
         const int r = r0 + ri * tstep, s = s0 + sj * tstep;
-        A[i] = (k < K) ? w[(((size_t)k * C + c) * R + r) * S + s] : 0.f;
+        float v = (k < K) ? w[(((size_t)k * C + c) * R + r) * S + s] : 0.f;
+        // reflection pad 1, 3 taps: output row 1 also receives padded row 0 = input row 1 through tap 0, from the
+        // source row that its tap 2 reads (fold 1); output row H-2 the other way round (fold 2)
+        if (k < K && fold == 1 && r == R - 1) v += w[(((size_t)k * C + c) * R + 0) * S + s];
+        if (k < K && fold == 2 && r == 0) v += w[(((size_t)k * C + c) * R + (R - 1)) * S + s];
+        A[i] = v;
     }
 }
 
@@ -1822,6 +1803,9 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
         a.stagger = env ? atoi(env) : 0;
     }
     const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((pmax + bp - 1) / bp)), (unsigned)a.nphase, (unsigned)ks);
+    a.tstart[0] = 0;
+    for (int i = 0; i < a.nphase; ++i) a.tstart[i + 1] = a.tstart[i] + (a.ph[i].Ptot + bp - 1) / bp;
+    const dim3 grid2((unsigned)(((a.M + bm - 1) / bm) * a.tstart[a.nphase]), 1u, (unsigned)ks);
     const bool cg16 = a.chunked != 0;
     PCGAN_CHECK(cg16 || MODE != MODE_BWD_REFLECT, "igemm: fused reflect data-gradient needs K %% 16 == 0");
     if (cg16) {
@@ -1833,7 +1817,7 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
     static const bool old_kernel = getenv("PCGAN_OLD_IGEMM") != nullptr;   // A/B experiments
 #define LI(BMV, BPV)                                                                                   \
     do {                                                                                               \
-        if (cg16 && !old_kernel) hipLaunchKernelGGL((igemm2_kernel<MODE, BMV, BPV>), grid, dim3(256), 0, st, a); \
+        if (cg16 && !old_kernel) hipLaunchKernelGGL((igemm2_kernel<MODE, BMV, BPV>), grid2, dim3(256), 0, st, a); \
         else if (cg16) hipLaunchKernelGGL((igemm_kernel<MODE, BMV, BPV, true>), grid, dim3(256), 0, st, a); \
         else if (MODE != MODE_BWD_REFLECT)                                                             \
             hipLaunchKernelGGL((igemm_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV, false>), grid, \
@@ -1905,8 +1889,15 @@ static size_t fwd_base_bytes(const pcgan_conv_desc* d) {
     // A matrix (+ RS*C*16 bytes: room for the [k][4] transposed weights of the small-M path)
     return align_up((size_t)d->K * d->R * d->S * round4(d->C) * 4 + (size_t)d->R * d->S * round4(d->C) * 16, 256);
 }
+// fused reflect data gradient (mirror images gathered on the unpadded grid) and its row-folded form (pad 1, 3 rows)
+static bool bwd_fused_reflect(const pcgan_conv_desc* d) {
+    return d->pad_mode == 1 && chunked_k(d->K, d->C, d->R, d->S) && d->R * d->S <= NTAP_MIR && d->H >= 2 * d->pad + 2 &&
+           d->W >= 2 * d->pad + 2;
+}
+static bool bwd_rowfold(const pcgan_conv_desc* d) { return bwd_fused_reflect(d) && d->pad == 1 && d->R == 3 && d->stride == 1; }
 static size_t bwd_base_bytes(const pcgan_conv_desc* d) {
-    return align_up((size_t)d->C * d->R * d->S * round4(d->K) * 4 + (size_t)d->R * d->S * round4(d->K) * 16, 256);
+    const size_t a = (size_t)d->C * d->R * d->S * round4(d->K) * 4;
+    return align_up((bwd_rowfold(d) ? 3 * a : a) + (size_t)d->R * d->S * round4(d->K) * 16, 256);
 }
 
 extern "C" size_t pcgan_conv2d_workspace_bytes(const pcgan_conv_desc* d, int pass) {
@@ -2002,7 +1993,8 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     // reflection: gather the mirror images directly (fused, needs K % 16 == 0 and H,W >= 2 pad + 2); otherwise
     // compute the gradient of the PADDED input (pad 0 on a larger grid) and fold it back
     const bool chunked = chunked_k(d->K, d->C, d->R, d->S);
-    const bool fused = d->pad_mode == 1 && chunked && d->R * d->S <= NTAP_MIR && d->H >= 2 * d->pad + 2 && d->W >= 2 * d->pad + 2;
+    const bool fused = bwd_fused_reflect(d);
+    const bool rowfold = bwd_rowfold(d);
     const bool reflect = d->pad_mode == 1 && !fused;
     const int H = reflect ? d->H + 2 * d->pad : d->H;
     const int W = reflect ? d->W + 2 * d->pad : d->W;
@@ -2018,7 +2010,30 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     a.ostep = stv; a.sl = ilog2_exact(stv); a.pad = pad; a.tstep = stv;
     a.act = PCGAN_ACT_NONE; a.slope = 0.f;
     a.chunked = chunked;
+    a.rowfold = rowfold;
     a.x_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * 4);
+
+    if (rowfold) {
+        // three row classes with their own weights: rows without a mirror image | row 1 | row H-2
+        const size_t total = (size_t)d->C * RS * Kgp;
+        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        for (int f = 0; f < 3; ++f) {
+            float* A = Abase + (size_t)f * total;
+            if (do_pack) {
+                hipLaunchKernelGGL(repack_bwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Kgp, d->R, d->S, 0, 0,
+                                   1, d->R, d->S, 1, f);
+                PCGAN_LAUNCH_CHECK();
+            }
+            PhaseArgs& p = a.ph[a.nphase++];
+            p.A = A; p.Kp = RS * Kgp; p.Ws = W; p.fx = 0; p.r0 = 0; p.s0 = 0; p.nR = d->R; p.nS = d->S;
+            p.Hs = f == 0 ? H - 2 : 1;
+            p.fy = f == 0 ? 0 : (f == 1 ? 1 : H - 2);
+            p.ymap = f == 0 ? 1 : 0;
+            p.Ptot = d->N * p.Hs * W;
+        }
+        if (pack_only) return 0;
+        return launch_igemm<MODE_BWD_REFLECT>(a, st, nullptr, 0);
+    }
 
     // one phase per (iy % stride, ix % stride): only the taps that are structurally non-zero for it
     bool need_zero = false;
@@ -2041,7 +2056,7 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
             const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
             if (do_pack) {
                 hipLaunchKernelGGL(repack_bwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Kgp, d->R,
-                                   d->S, r0, s0, stv, nR, nS, (int)chunked);
+                                   d->S, r0, s0, stv, nR, nS, (int)chunked, 0);
                 PCGAN_LAUNCH_CHECK();
             }
             PhaseArgs& p = a.ph[a.nphase++];
