@@ -51,6 +51,7 @@ struct PhaseArgs {
     int fy, fx;      // output coordinate = sub * ostep + f
     int r0, s0, nR, nS;  // taps: r = r0 + i*tstep (i < nR), s = s0 + j*tstep (j < nS)
     int Ptot;        // N * Hs * Ws
+    const float* As; // small-M strip kernel: weights as [c][sj][8][4] (row taps and outputs zero-padded)
     int ymap;        // 1: sub-grid row sy is output row {0, pad+1 .. H-2-pad, H-1}[sy] (rows without a mirror image)
 };
 
@@ -882,6 +883,17 @@ __global__ void transpose4_kernel(const float* __restrict__ A, float* __restrict
     }
 }
 
+// strip-kernel weights: Ws[c][sj][8][4] from A[m][(ri*nS + sj)*Cgp + c] (zero for ri >= nR, m >= M)
+__global__ void pack_strip_kernel(const float* __restrict__ A, float* __restrict__ Ws, int M, int Cg, int Cgp, int nR, int nS) {
+    const int total = Cg * nS * 32;
+    const int Kp = nR * nS * Cgp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int m = i & 3, ri = (i >> 2) & 7, cs = i >> 5;
+        const int c = cs / nS, sj = cs - c * nS;
+        Ws[i] = (m < M && ri < nR) ? A[(size_t)m * Kp + (ri * nS + sj) * Cgp + c] : 0.f;
+    }
+}
+
 static constexpr unsigned SM_INV = 0x40000000u;  // row/column marker: any sum with it is >= 1 GiB => out of range
 
 // 64 pixels per workgroup; the 4 waves split the channels of the gathered tensor and are summed through
@@ -984,6 +996,160 @@ __global__ void __launch_bounds__(256) smallm_conv_kernel(IgemmArgs a) {
             float v = out[m];
             if (a.bias) v += a.bias[m];
             Yp[(size_t)m * YhYw] = act_apply(v, a.act, a.slope);
+        }
+    }
+}
+
+// Strip variant: one thread = PX vertically consecutive pixels of one column x MO outputs; lanes run along the row, so
+// every gather instruction reads consecutive addresses.  For a fixed (channel, filter column) the PX + NR - 1 input
+// values above/below the strip are loaded ONCE into registers and reused by all NR row taps of all PX pixels (sliding
+// window): MO * NR * PX fused multiply-adds per PX + NR - 1 gathers instead of MO per gather, which moves the kernel
+// from the L1/TA bound of smallm_conv_kernel towards the vector-ALU bound.  Weights come in through the scalar cache
+// ([c][sj][8][4], wave-uniform addresses, no branches).  The 4 waves split the channels and are summed through LDS.
+// Needs unit pixel stride along the column in the gathered tensor: forward with stride 1, or any data-gradient phase.
+template <int MODE, int NR, int MO>
+__global__ void __launch_bounds__(256) smallm_strip_kernel(IgemmArgs a) {
+    constexpr int PX = 8, NW = PX + NR - 1;
+    constexpr bool BWD = MODE == MODE_BWD;
+    __shared__ unsigned coltab[12][64];
+    __shared__ float red[3][MO * PX][64];
+    const PhaseArgs& P = a.ph[blockIdx.y];
+    const int spc = (P.Hs + PX - 1) / PX;   // strips per column
+    const int nstrips = a.N * spc * P.Ws;
+    if ((int)(blockIdx.x * 64) >= nstrips) return;
+    const int tid = threadIdx.x;
+    const int pl = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sg = blockIdx.x * 64 + pl;
+    const bool svalid = sg < nstrips;
+    const int HgWg = a.Hg * a.Wg;
+    int n = 0, sy0 = 0, sx = 0;
+    if (svalid) {
+        n = sg / (spc * P.Ws);
+        const int rem = sg - n * spc * P.Ws;
+        const int ss = rem / P.Ws;
+        sy0 = ss * PX;
+        sx = rem - ss * P.Ws;
+    }
+    const int px = sx * a.ostep + P.fx;
+    for (int j = wave; j < P.nS; j += 4) {   // column part of the gather offset, per filter column
+        const int sc = P.s0 + j * a.tstep;
+        int ix;
+        bool ok = svalid;
+        if (BWD) {
+            const int tx = px + a.pad - sc;
+            ix = tx >> a.sl;
+            ok = ok && tx >= 0 && ix < a.Wg;
+        } else {
+            ix = px - a.pad + sc;
+            if (MODE == MODE_FWD_REFLECT) {
+                ix = ix < 0 ? -ix : ix;
+                ix = ix >= a.Wg ? 2 * (a.Wg - 1) - ix : ix;
+            } else {
+                ok = ok && (unsigned)ix < (unsigned)a.Wg;
+            }
+        }
+        coltab[j][pl] = ok ? (unsigned)ix * 4u : SM_INV;
+    }
+    // row part (+ image base): window position k holds input row y0 + k; pixel j and row tap ri meet at k = j + ri
+    // (forward) or k = j - ri + NR - 1 (data gradient: source row = sub-grid row + q0 - ri)
+    unsigned rowoff[NW];
+    {
+        const int y0 = BWD ? sy0 + ((P.fy + a.pad - P.r0) >> a.sl) - (NR - 1) : sy0 - a.pad + P.r0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            int iy = y0 + k;
+            if (MODE == MODE_FWD_REFLECT) {
+                iy = iy < 0 ? -iy : iy;
+                iy = iy >= a.Hg ? 2 * (a.Hg - 1) - iy : iy;
+            }
+            const bool ok = (unsigned)iy < (unsigned)a.Hg;   // (reflect: strips past the last row are never stored)
+            rowoff[k] = ok ? (unsigned)(n * a.Cg * HgWg + iy * a.Wg) * 4u : SM_INV;
+        }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
+    const int nS = P.nS;
+    const int cpw = (a.Cg + 3) >> 2;
+    const int c_lo = wave * cpw;
+    const int c_hi = (c_lo + cpw < a.Cg) ? c_lo + cpw : a.Cg;
+    float acc[MO][PX];
+#pragma unroll
+    for (int m = 0; m < MO; ++m)
+#pragma unroll
+        for (int j = 0; j < PX; ++j) acc[m][j] = 0.f;
+
+    const float4* __restrict__ Ws4 = reinterpret_cast<const float4*>(P.As);   // [c][sj][8] float4
+    auto issue = [&](float (&buf)[NW], float4 (&wb)[NR], int c, int sj) {
+        const unsigned co = coltab[sj][pl];
+        const unsigned so = (unsigned)(c * HgWg) * 4u;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) buf[k] = ld_b32(rX, rowoff[k] + co, so);
+        const float4* __restrict__ wr = Ws4 + (size_t)(c * nS + sj) * 8;   // wave-uniform -> scalar loads, no branches
+#pragma unroll
+        for (int ri = 0; ri < NR; ++ri) wb[ri] = wr[ri];
+    };
+    auto compute = [&](const float (&buf)[NW], const float4 (&wb)[NR]) {
+#pragma unroll
+        for (int ri = 0; ri < NR; ++ri) {
+            const float w[4] = {wb[ri].x, wb[ri].y, wb[ri].z, wb[ri].w};
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const float x = buf[BWD ? j - ri + NR - 1 : j + ri];
+#pragma unroll
+                for (int m = 0; m < MO; ++m) acc[m][j] += x * w[m];
+            }
+        }
+    };
+    const int T = (c_hi - c_lo) * nS;
+    if (T > 0) {
+        float b0[NW], b1[NW];
+        float4 w0[NR], w1[NR];
+        int c = c_lo, sj = 0;           // (c, sj) of the stage being issued
+        auto adv = [&](int& cx, int& sx_) {
+            if (++sx_ == nS) {
+                sx_ = 0;
+                ++cx;
+            }
+        };
+        issue(b0, w0, c, sj);
+        adv(c, sj);
+        for (int t = 0; t < T; t += 2) {
+            if (t + 1 < T) {
+                issue(b1, w1, c, sj);
+                adv(c, sj);
+            }
+            compute(b0, w0);
+            if (t + 1 < T) {
+                if (t + 2 < T) {
+                    issue(b0, w0, c, sj);
+                    adv(c, sj);
+                }
+                compute(b1, w1);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < MO; ++m)
+#pragma unroll
+            for (int j = 0; j < PX; ++j) red[wave - 1][m * PX + j][pl] = acc[m][j];
+    }
+    __syncthreads();
+    if (wave > 0 || !svalid) return;
+    const int YhYw = a.Yh * a.Yw;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        if (sy0 + j >= P.Hs) break;
+        const int py = (sy0 + j) * a.ostep + P.fy;
+        float* Yp = a.Y + (size_t)n * a.M * YhYw + py * a.Yw + px;
+#pragma unroll
+        for (int m = 0; m < MO; ++m) {
+            if (m < a.M) {
+                float v = acc[m][j] + (red[0][m * PX + j][pl] + red[1][m * PX + j][pl]) + red[2][m * PX + j][pl];
+                if (a.bias) v += a.bias[m];
+                Yp[(size_t)m * YhYw] = act_apply(v, a.act, a.slope);
+            }
         }
     }
 }
@@ -1777,6 +1943,27 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
         PCGAN_CHECK(a.x_bytes < SM_INV, "small-M conv: gathered tensor must be < 1 GiB");
         for (int i = 0; i < a.nphase; ++i)
             PCGAN_CHECK(a.ph[i].nR <= 12 && a.ph[i].nS <= 12, "small-M conv: more than 12 taps per axis");
+        {   // strip kernel: unit pixel stride along the column, columns long enough for 8-pixel strips, <= 7 row taps
+            int maxR = 0, minH = 1 << 30, maxstrips = 0;
+            for (int i = 0; i < a.nphase; ++i) {
+                maxR = a.ph[i].nR > maxR ? a.ph[i].nR : maxR;
+                minH = a.ph[i].Hs < minH ? a.ph[i].Hs : minH;
+                const int ns = a.N * ((a.ph[i].Hs + 7) / 8) * a.ph[i].Ws;
+                maxstrips = ns > maxstrips ? ns : maxstrips;
+            }
+            constexpr int SMODE = MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE;
+            const bool unit = SMODE == MODE_BWD || (a.sl == 0 && a.ostep == 1);
+            static const bool no_strip = getenv("PCGAN_NO_STRIP") != nullptr;   // A/B experiments
+            if (unit && maxR >= 3 && maxR <= 7 && minH >= 16 && !no_strip) {   // (1-2 row taps: nothing to reuse)
+                const dim3 gs((unsigned)((maxstrips + 63) / 64), (unsigned)a.nphase);
+#define LS(NRV) do { if (a.M <= 3) hipLaunchKernelGGL((smallm_strip_kernel<SMODE, NRV, 3>), gs, dim3(256), 0, st, a); \
+                     else hipLaunchKernelGGL((smallm_strip_kernel<SMODE, NRV, 4>), gs, dim3(256), 0, st, a); } while (0)
+                if (maxR <= 4) LS(4); else LS(7);
+#undef LS
+                PCGAN_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         int maxtaps = 0;
         for (int i = 0; i < a.nphase; ++i) maxtaps = a.ph[i].nR * a.ph[i].nS > maxtaps ? a.ph[i].nR * a.ph[i].nS : maxtaps;
         if (maxtaps <= 9) {
@@ -1886,8 +2073,9 @@ static size_t bwd_part_bytes(const pcgan_conv_desc* d) {
     return may_split(d->C, pmax, s * s) ? align_up((size_t)8 * d->N * d->C * d->H * d->W * 4, 256) : 0;
 }
 static size_t fwd_base_bytes(const pcgan_conv_desc* d) {
-    // A matrix (+ RS*C*16 bytes: room for the [k][4] transposed weights of the small-M path)
-    return align_up((size_t)d->K * d->R * d->S * round4(d->C) * 4 + (size_t)d->R * d->S * round4(d->C) * 16, 256);
+    // A matrix (+ small-M path: RS*C*16 bytes for the [k][4] transposed weights and S*C*128 for the strip layout)
+    return align_up((size_t)d->K * d->R * d->S * round4(d->C) * 4 + (size_t)d->R * d->S * round4(d->C) * 16 +
+                    (d->K <= 4 ? (size_t)d->S * d->C * 128 : 0), 256);
 }
 // fused reflect data gradient (mirror images gathered on the unpadded grid) and its row-folded form (pad 1, 3 rows)
 static bool bwd_fused_reflect(const pcgan_conv_desc* d) {
@@ -1897,7 +2085,9 @@ static bool bwd_fused_reflect(const pcgan_conv_desc* d) {
 static bool bwd_rowfold(const pcgan_conv_desc* d) { return bwd_fused_reflect(d) && d->pad == 1 && d->R == 3 && d->stride == 1; }
 static size_t bwd_base_bytes(const pcgan_conv_desc* d) {
     const size_t a = (size_t)d->C * d->R * d->S * round4(d->K) * 4;
-    return align_up((bwd_rowfold(d) ? 3 * a : a) + (size_t)d->R * d->S * round4(d->K) * 16, 256);
+    // small-M path: [k][4] transposed copies + strip layout (sum over the stride phases of nS = stride * S columns)
+    return align_up((bwd_rowfold(d) ? 3 * a : a) + (size_t)d->R * d->S * round4(d->K) * 16 +
+                    (d->C <= 4 ? (size_t)d->stride * d->S * d->K * 128 : 0), 256);
 }
 
 extern "C" size_t pcgan_conv2d_workspace_bytes(const pcgan_conv_desc* d, int pass) {
@@ -1927,6 +2117,9 @@ static int pack_fwd(const pcgan_conv_desc* d, const float* w, float* A, hipStrea
         hipLaunchKernelGGL(transpose4_kernel, dim3((RS * Cgp * 4 + 255) / 256), dim3(256), 0, st, (const float*)A,
                            A + total, d->K, RS * Cgp);
         PCGAN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(pack_strip_kernel, dim3((d->C * d->S * 32 + 255) / 256), dim3(256), 0, st, (const float*)A,
+                           A + total + (size_t)RS * Cgp * 4, d->K, d->C, Cgp, d->R, d->S);
+        PCGAN_LAUNCH_CHECK();
     }
     return 0;
 }
@@ -1954,7 +2147,10 @@ static int conv2d_fwd_impl(const pcgan_conv_desc* d, const float* x, const float
     a.chunked = chunked_k(d->C, d->K, d->R, d->S);
     PhaseArgs& p = a.ph[0];
     p.A = A; p.Kp = RS * Cgp; p.Hs = d->P; p.Ws = d->Q; p.fy = 0; p.fx = 0;
-    if (d->K <= 4) p.A = A + (size_t)d->K * RS * Cgp;  // small-M path reads the weights as [k][4]
+    if (d->K <= 4) {  // small-M path reads the weights as [k][4] / [c][ri][8][4]
+        p.A = A + (size_t)d->K * RS * Cgp;
+        p.As = p.A + (size_t)RS * Cgp * 4;
+    }
     p.r0 = 0; p.s0 = 0; p.nR = d->R; p.nS = d->S; p.Ptot = d->N * d->P * d->Q;
     float* part = fwd_part_bytes(d) ? (float*)((char*)ws + fwd_base_bytes(d)) : nullptr;
     return d->pad_mode == 1 ? launch_igemm<MODE_FWD_REFLECT>(a, st, part, fwd_part_bytes(d))
@@ -1990,6 +2186,7 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     const size_t a_bytes = bwd_base_bytes(d);
     const bool smallm = d->C <= 4;
     size_t at_off = (size_t)d->C * RS * Kgp;  // transposed copies for the small-M path live behind the A's
+    size_t as_off = at_off + (size_t)RS * Kgp * 4;   // ... and the strip layouts behind those
     // reflection: gather the mirror images directly (fused, needs K % 16 == 0 and H,W >= 2 pad + 2); otherwise
     // compute the gradient of the PADDED input (pad 0 on a larger grid) and fold it back
     const bool chunked = chunked_k(d->K, d->C, d->R, d->S);
@@ -2064,12 +2261,18 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
             if (smallm) {
                 float* At = Abase + at_off;
                 at_off += (size_t)nR * nS * Kgp * 4;
+                float* As = Abase + as_off;
+                as_off += (size_t)d->K * nS * 32;
                 if (do_pack) {
                     hipLaunchKernelGGL(transpose4_kernel, dim3((nR * nS * Kgp * 4 + 255) / 256), dim3(256), 0, st,
                                        (const float*)A, At, d->C, nR * nS * Kgp);
                     PCGAN_LAUNCH_CHECK();
+                    hipLaunchKernelGGL(pack_strip_kernel, dim3((d->K * nS * 32 + 255) / 256), dim3(256), 0, st,
+                                       (const float*)A, As, d->C, d->K, Kgp, nR, nS);
+                    PCGAN_LAUNCH_CHECK();
                 }
                 p.A = At;
+                p.As = As;
             }
             p.r0 = r0; p.s0 = s0; p.nR = nR; p.nS = nS; p.Ptot = d->N * Hs * Ws;
         }
