@@ -2046,9 +2046,34 @@ static int wgrad_splits(const pcgan_conv_desc* d, int* chunks_per_split) {
     const int tiles = ((d->K + bm - 1) / bm) * ((Kp + 127) / 128);
     const int Ptot = d->N * d->P * d->Q;
     const int chunks = (Ptot + 31) / 32;
-    int target = 1024;
-    if (const char* env = getenv("PCGAN_WGRAD_BLOCKS")) target = atoi(env) > 0 ? atoi(env) : target;
-    int splits = (target + tiles - 1) / tiles;
+    // Two workgroups fit on a CU (74-80 KB of LDS each): `slots` run at once.  The workgroup count tiles x splits is
+    // kept just BELOW a whole number of rounds of slots -- a few workgroups over and the kernel waits for a nearly empty
+    // extra round.  One round if it fills >= 90 % of the slots (fewest partial sums to write and reduce), else the
+    // round count (<= 4) with the best fill.
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        slots = 2 * cus;
+    }
+    int splits = 1;
+    if (const char* env = getenv("PCGAN_WGRAD_BLOCKS")) {   // experiments: explicit workgroup target
+        const int target = atoi(env) > 0 ? atoi(env) : 1024;
+        splits = target / tiles > 0 ? target / tiles : 1;
+    } else {
+        double best = -1.0;
+        for (int r = 1; r <= 4; ++r) {
+            const int sp = (r * slots) / tiles;
+            if (sp < 1) continue;
+            const double fill = (double)sp * tiles / ((double)r * slots);
+            if (fill > best + 1e-9) {
+                best = fill;
+                splits = sp;
+            }
+            if (fill >= 0.9) break;
+        }
+    }
     if (splits > chunks / 8) splits = chunks / 8;  // at least 8 stages of work per block
     if (splits < 1) splits = 1;
     if (splits > 512) splits = 512;
