@@ -12,7 +12,8 @@ Workload (BASELINE.json configs[1]): 9-block ResnetGenerator + 3-layer PatchGAN 
 "pretrained" E/IP weights (no checkpoints ship offline).
 
 One JSON line on rank 0: value = whole-job images/s; `roofline` = the dominant kernel (the 256->256
-3x3 residual convolution, implicit GEMM on fp32 MFMA) timed with HIP events on the launch stream;
+3x3 residual convolution, implicit GEMM on fp32 MFMA): every one of its forward launches inside the timed region
+is bracketed by HIP events on the launch stream;
 `cpu_baseline` = the oracle's PyTorch-CPU step on this host's cores, bounded sample.
 """
 import argparse
@@ -31,6 +32,7 @@ GFLOP_PER_IMG_FULL = 183.95      # 2 G + 4 D + 3 E + 2 IP fwd an
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PER_GPU_BATCH = 32
 SIZE = 128
+HBM_TRAFFIC_PER_LAUNCH = (53572 + 32768) * 1024   # FETCH_SIZE + WRITE_SIZE (KiB) of the forward kernel, profiles/README.md
 
 
 def build_model(device_index, batch, size, tmpdir, seed=0, ngf=64, ndf=64, fine_e=224, n_blocks=9):
@@ -69,27 +71,8 @@ def synthetic_batch(batch, size, rank, it=0):
     return {'A': A, 'B': B, 'label': label, 'A_paths': [''] * batch, 'B_paths': [''] * batch}
 
 
-def time_resblock_conv(device, n=PER_GPU_BATCH, iters=50):
-    """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of the
-    dominant kernel: 256->256 3x3 reflect-padded conv on (n,256,32,32)."""
-    from pcgan_amd.hip import ops
-    g = torch.Generator().manual_seed(7)
-    x = (torch.rand(n, 256, 32, 32, generator=g) * 2 - 1).to(device)
-    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(device)
-    b = torch.zeros(256, device=device)
-    cache = {}                                   # weights packed once, as in the step (ops._packed_weights)
-    for _ in range(60):                          # ~20 ms of back-to-back launches: clocks at their sustained level
-        ops.conv2d_fwd(x, w, b, 1, 1, 1, pack_cache=cache)
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        ops.conv2d_fwd(x, w, b, 1, 1, 1, pack_cache=cache)
-    e.record()
-    torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / iters
-    flop = 2.0 * n * 32 * 32 * 256 * 256 * 9
-    return ms, flop
+RES_CONV_KEY = (PER_GPU_BATCH, 256, 32, 32, 256, 3, 3, 1, 1, 1)   # the residual-block convolution: 36 forward launches per step
+RES_CONV_FLOP = 2.0 * PER_GPU_BATCH * 32 * 32 * 256 * 256 * 9
 
 
 def cpu_baseline(steps=2, batch=8):
@@ -143,11 +126,14 @@ def main():
         model.set_input(batches[i % 2])
         model.optimize_parameters()
 
+    from pcgan_amd.hip import ops
     for i in range(args.warmup):
         step(i)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    # HIP events on the launch stream around every forward launch of the dominant kernel inside the timed region
+    ops.KERNEL_TIMER = {'key': RES_CONV_KEY, 'events': []}
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -162,7 +148,10 @@ def main():
     losses = model.get_current_losses()
     assert all(v == v and abs(v) < 1e6 for v in losses.values()), 'non-finite loss: %r' % losses
 
-    conv_ms, conv_flop = time_resblock_conv(device)
+    timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    conv_launches = len(timer['events'])
+    conv_ms = sum(a.elapsed_time(b) for a, b in timer['events']) / max(conv_launches, 1)
+    conv_flop = RES_CONV_FLOP
     if rank != 0:
         return
     ms_per_step = dt / args.steps * 1e3
@@ -179,7 +168,10 @@ def main():
         'roofline': {'bound': 'mfma', 'kernel': 'igemm2_kernel<1,128,128> (FWD_REFLECT, 128x128 tile) 256->256 3x3 reflect @32x32, bs32',
                      'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'ms_per_launch': round(conv_ms, 4),
-                     'flop_per_launch': conv_flop, 'traffic': None},
+                     'launches_timed': conv_launches, 'flop_per_launch': conv_flop,
+                     # memory-side bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md: why the
+                     # gfx950 x2 FETCH_SIZE correction cannot apply to these 4-byte gathers); algorithmic bytes 69.5e6
+                     'traffic': HBM_TRAFFIC_PER_LAUNCH},
         'losses': {k: round(v, 5) for k, v in losses.items()},
     }
     if world == 1 and not args.no_cpu_baseline:

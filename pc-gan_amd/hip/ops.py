@@ -105,6 +105,10 @@ def join_side_stream():
 # update the flat buffer through raw pointers; model.set_input / load_networks / broadcast as a backstop).
 _PACK_EPOCH = [0]
 
+# bench.py: HIP events (on the launch stream) around every prepacked forward launch of one convolution shape,
+# {'key': (N, C, H, W, K, R, S, stride, pad, pad_mode), 'events': []}; None = off
+KERNEL_TIMER = None
+
 
 def invalidate_packed_weights():
     _PACK_EPOCH[0] += 1
@@ -137,8 +141,15 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
     ws = _ws(nb, x.device)
     if pack_cache is not None:
         pk = _packed_weights(lib, d, _L.PASS_FWD, w, pack_cache)
+        ev = None
+        if KERNEL_TIMER is not None and KERNEL_TIMER['key'] == (N, C, H, W, K, R, S, stride, pad, pad_mode):
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _L.check(lib.pcgan_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(pk), _p(bias), _p(y), act, float(slope),
                                              _p(ws), ws.numel(), _stream()), 'conv2d_fwd_packed')
+        if ev is not None:
+            ev[1].record()
+            KERNEL_TIMER['events'].append(ev)
         return y
     _L.check(lib.pcgan_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), act, float(slope),
                                   _p(ws), ws.numel(), _stream()), 'conv2d_fwd')
