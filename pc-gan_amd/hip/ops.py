@@ -88,6 +88,49 @@ class fork_side(object):
         return self.ctx.__exit__(*exc)
 
 
+# ---------------------------------------------------------------- branch streams (independent sub-networks)
+# In backward_G the discriminator, the AlexNet identity branch and the Elo encoder all read the same fake image and
+# meet again only in the scalar loss sum.  Each branch can run on its own stream: autograd replays every backward node
+# on the stream of its forward op and synchronises where the gradients meet, so forward AND backward of the branches
+# overlap (their mid-size kernels and launch-latency-bound BatchNorm chains fill each other's gaps).  Different nets
+# only -- two passes through ONE BatchNorm net must stay ordered (running statistics).
+BRANCH_STREAMS = os.environ.get('PCGAN_BRANCH_STREAMS', '1') != '0'
+_branch = {}
+
+
+class branch(object):
+    """with branch('E') as b: ... loss = f(...) ; b.join(loss): run the body on the named stream after everything
+    queued so far on the current stream; join() makes the current stream wait and hands the tensors over."""
+
+    def __init__(self, name):
+        self.name = name
+        self.on = BRANCH_STREAMS and torch.cuda.is_available()
+
+    def __enter__(self):
+        if self.on:
+            self.cur = torch.cuda.current_stream()
+            key = (self.cur.device, self.name)
+            st = _branch.get(key)
+            if st is None:
+                st = _branch[key] = torch.cuda.Stream(device=self.cur.device)
+            st.wait_stream(self.cur)
+            self.st = st
+            self.ctx = torch.cuda.stream(st)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            return self.ctx.__exit__(*exc)
+
+    def join(self, *tensors):
+        if self.on:
+            self.cur.wait_stream(self.st)
+            for t in tensors:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(self.cur)
+
+
 def join_side_stream():
     """Make the current stream wait for everything launched on the side stream."""
     _side_state['queued'] = False

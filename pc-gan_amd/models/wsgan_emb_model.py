@@ -19,6 +19,7 @@ import torch
 
 from . import networks
 from .base_model import BaseModel
+from ..hip import ops as hip_ops
 from ..hip import parallel
 from ..hip.optim import FusedAdam
 from ..util.util import upsample2d, str2list, str2bool, resample, compute_mu_and_var
@@ -286,56 +287,75 @@ class WSGANEmbModel(BaseModel):
 
     def _common_G_losses(self):
         o = self.opt
+        # the identity branch (AlexNet: no running statistics, order-free) runs beside the discriminator branch
+        b_ip = None
+        if o.lambda_IP > 0.0:
+            with hip_ops.branch('IP') as b_ip:
+                with torch.no_grad():
+                    feature_A = self.netIP(self.transform_IP(self.real_A_IP))
+                self.loss_G_IP = self.criterionIP(self.netIP(self.transform_IP(self.fake_B_IP)), feature_A) * o.lambda_IP
+        else:
+            self.loss_G_IP = 0.0
         self.loss_G_GAN = self.criterionGAN(self.netD(self.fake_B, self._rating_for_D()), True)
         if o.lambda_A_GAN > 0.0:
             self.loss_G_GAN_cycle = self.criterionGAN(self.netD(self.rec_A, self.embedding_A), True) * o.lambda_A_GAN
         else:
             self.loss_G_GAN_cycle = 0.0
         self.loss_G_L1 = self.criterionL1(self.fake_B, self.real_A) * o.lambda_L1 if o.lambda_L1 > 0.0 else 0.0
-        if o.lambda_IP > 0.0:
-            with torch.no_grad():
-                feature_A = self.netIP(self.transform_IP(self.real_A_IP))
-            self.loss_G_IP = self.criterionIP(self.netIP(self.transform_IP(self.fake_B_IP)), feature_A) * o.lambda_IP
-        else:
-            self.loss_G_IP = 0.0
         self.loss_G_cycle = self.criterionCycle(self.rec_A, self.real_A) * o.lambda_A if o.lambda_A > 0.0 else 0.0
+        return b_ip
 
     def backward_G(self):
         o = self.opt
-        self._common_G_losses()
+        b_e = None
         if o.lambda_z > 0.0:
-            y_var = y_logvar = None
-            if not o.bayesian and not o.noisy:
-                pred_y = self.netE(self.transform_E(self.fake_B_E))
-            elif not o.bayesian and o.noisy:
-                pred_y, y_logvar = self.netE(self.transform_E(self.fake_B_E))
-                if 'a' in o.noisy_var_type:
-                    y_var = torch.exp(y_logvar)
-            elif o.bayesian and not o.noisy:
-                pred_y, y_var = compute_mu_and_var(self.netE, self.transform_E(self.fake_B_E), o.bnn_T, False)
-                if 'e' in o.noisy_var_type:
-                    y_logvar = torch.log(y_var + MAGIC_EPS)
-            else:
-                # reference quirk kept: the prediction comes from real_A_E, so this term
-                # carries no gradient to G
-                pred_y, y_var_, y_s2_ = compute_mu_and_var(self.netE, self.transform_E(self.real_A_E), o.bnn_T, True)
-                y_var = torch.zeros_like(pred_y)
-                if 'a' in o.noisy_var_type:
-                    y_var = y_var + y_s2_
-                if 'e' in o.noisy_var_type:
-                    y_var = y_var + y_var_
-                y_logvar = torch.log(y_var + MAGIC_EPS)
-            if o.noisy_var_type and o.noisy_rec:
-                self.loss_z_rec = ((pred_y - self.y_B).pow(2) / y_var.detach() + y_logvar.detach()).sum() \
-                    / pred_y.size()[0] * 0.5 * o.lambda_z
-            else:
-                self.loss_z_rec = self.criterionRec(pred_y, self.y_B) * o.lambda_z
+            b_e = hip_ops.branch('E')     # the Elo-encoder branch, beside the discriminator / identity branches
+            b_e.__enter__()
+            try:
+                self._z_rec_loss()
+            finally:
+                b_e.__exit__(None, None, None)
         else:
             self.loss_z_rec = 0.0
+        b_ip = self._common_G_losses()
+        if b_e is not None:
+            b_e.join(self.loss_z_rec)
+        if b_ip is not None:
+            b_ip.join(self.loss_G_IP)
         self.loss_G = self.loss_G_GAN + self.loss_G_IP + self.loss_G_L1 + self.loss_G_cycle + self.loss_z_rec \
             + self.loss_G_GAN_cycle
         if isinstance(self.loss_G, torch.Tensor) and self.loss_G.requires_grad:
             self.loss_G.backward()
+
+    def _z_rec_loss(self):
+        """loss_z_rec of backward_G (reference models/wsgan_emb_model.py:400-435), its four encoder variants."""
+        o = self.opt
+        y_var = y_logvar = None
+        if not o.bayesian and not o.noisy:
+            pred_y = self.netE(self.transform_E(self.fake_B_E))
+        elif not o.bayesian and o.noisy:
+            pred_y, y_logvar = self.netE(self.transform_E(self.fake_B_E))
+            if 'a' in o.noisy_var_type:
+                y_var = torch.exp(y_logvar)
+        elif o.bayesian and not o.noisy:
+            pred_y, y_var = compute_mu_and_var(self.netE, self.transform_E(self.fake_B_E), o.bnn_T, False)
+            if 'e' in o.noisy_var_type:
+                y_logvar = torch.log(y_var + MAGIC_EPS)
+        else:
+            # reference quirk kept (SURVEY D10): the prediction comes from real_A_E, so this term
+            # carries no gradient to G
+            pred_y, y_var_, y_s2_ = compute_mu_and_var(self.netE, self.transform_E(self.real_A_E), o.bnn_T, True)
+            y_var = torch.zeros_like(pred_y)
+            if 'a' in o.noisy_var_type:
+                y_var = y_var + y_s2_
+            if 'e' in o.noisy_var_type:
+                y_var = y_var + y_var_
+            y_logvar = torch.log(y_var + MAGIC_EPS)
+        if o.noisy_var_type and o.noisy_rec:
+            self.loss_z_rec = ((pred_y - self.y_B).pow(2) / y_var.detach() + y_logvar.detach()).sum() \
+                / pred_y.size()[0] * 0.5 * o.lambda_z
+        else:
+            self.loss_z_rec = self.criterionRec(pred_y, self.y_B) * o.lambda_z
 
     def update_D(self):
         self.set_requires_grad(self.netD, True)
