@@ -49,6 +49,25 @@ CONV_CASES = [
     ('l3_3x3_256_4', 3, 256, 4, 4, 256, 3, 1, 1, 0),
     ('l4a_3x3_s2_256_512_4', 3, 256, 4, 4, 512, 3, 2, 1, 0),
     ('l4_3x3_512_2', 3, 512, 2, 2, 512, 3, 1, 1, 0),
+    # chunked-K kernels (channels % 16 == 0): reflect data gradient with row-folded weights (3x3 pad 1) at the smallest
+    # legal size, non-square, ragged pixel tiles; fused mirror gathers without the fold (5x5 pad 2); odd strided sizes
+    ('refl3x3_min_4x4', 2, 16, 4, 4, 32, 3, 1, 1, 1),
+    ('refl3x3_6x10', 3, 32, 6, 10, 16, 3, 1, 1, 1),
+    ('refl3x3_17x9_k48', 2, 48, 17, 9, 80, 3, 1, 1, 1),
+    ('refl5x5_p2_12', 2, 16, 12, 12, 32, 5, 1, 2, 1),
+    ('z3x3_s2_odd_15', 3, 32, 15, 15, 48, 3, 2, 1, 0),
+    ('z4x4_s2_odd_13', 2, 16, 13, 13, 32, 4, 2, 1, 0),
+    ('z5x5_p2_64_27', 2, 64, 27, 27, 32, 5, 1, 2, 0),
+    ('z1x1_s1_64', 2, 64, 9, 9, 128, 1, 1, 0, 0),
+    # weight-gradient tile variants: 64 channels (two taps per K tile), 128-multiple channels, pixel counts not % 4
+    ('w64_7x7map', 3, 64, 7, 7, 64, 3, 1, 1, 0),
+    ('w128_15', 2, 128, 15, 15, 32, 3, 1, 1, 0),
+    ('w384_13', 1, 384, 13, 13, 64, 3, 1, 1, 0),
+    # small-M strip kernel: heights not a multiple of the 8-pixel strip, 4 and 1 output channels, 5 row taps, stride-2 phases
+    ('strip_head_k4_19', 2, 32, 19, 19, 4, 7, 1, 3, 1),
+    ('strip_k1_5x5_21', 2, 16, 21, 21, 1, 5, 1, 2, 0),
+    ('strip_dgrad_c3_7x7s2_41', 2, 3, 41, 41, 32, 7, 2, 3, 0),
+    ('strip_dgrad_c4_3x3_18', 2, 4, 18, 18, 16, 3, 1, 1, 0),
 ]
 
 
@@ -70,7 +89,8 @@ def test_conv2d_fwd_bwd(case, dev):
     w = torch.randn(K, C, Rk, Rk, generator=g) * 0.1
     b = torch.randn(K, generator=g) * 0.1
     P = (H + 2 * pad - Rk) // stride + 1
-    dy = torch.randn(N, K, P, P, generator=g)
+    Q = (W + 2 * pad - Rk) // stride + 1
+    dy = torch.randn(N, K, P, Q, generator=g)
     y_ref, dx_ref, dw_ref, db_ref = _conv_ref(x, w, b, stride, pad, pm, dy)
 
     xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
