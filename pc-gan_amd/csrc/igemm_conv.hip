@@ -1,21 +1,21 @@
-// Implicit-GEMM convolution family for gfx950 (MI355X), fp32 in / fp32 accumulate on
-// the matrix cores (v_mfma_f32_32x32x2_f32, exact f32 fma chain).
+// Implicit-GEMM convolution family for gfx950 (MI355X), fp32 in / fp32 accumulate on the matrix cores
+// (v_mfma_f32_32x32x2_f32, exact f32 fma chain).
 //
-//   forward      Y[n][m][oy][ox] = act( sum_k A[m][k] * G(k; n,oy,ox) + bias[m] )
-//   backward-data same kernel with the transposed gather (MODE_BWD), one launch per
-//                 stride phase so no MFMA work is spent on structurally-zero taps
-//   backward-weight  Wp[m][k] = sum_pix dY[m][pix] * G(k; pix)   (split over pixels,
-//                 deterministic two-pass reduction, no atomics)
+//   forward          Y[n][m][oy][ox] = act( sum_k A[m][k] * G(k; n,oy,ox) + bias[m] )
+//   backward-data    the same kernels with the transposed gather; stride phases (only the structurally non-zero taps)
+//                    and, for reflection padding, row classes with folded weights are phases of ONE launch
+//   backward-weight  Wp[m][k] = sum_pix dY[m][pix] * G(k; pix)   (split over pixel ranges, deterministic second-pass
+//                    sum, no atomics)
 //
-// Layout: activations NCHW fp32.  The GEMM "N" dimension is the flattened pixel index
-// so consecutive lanes touch consecutive addresses of one channel plane (coalesced
-// 128/256-B segments for loads and for the epilogue stores: the 32x32 accumulator has
-// its COLUMN on the lane, so the pixel is the column and the output channel the row).
-// The K dimension is ordered (tap, channel) with the channel fastest, so a 16-deep
-// K stage stays inside one filter tap whenever C % 16 == 0 and the spatial part of the
-// gather address is recomputed only when the tap changes (a wave-uniform branch).
-// Weights are re-laid out to that order by a small repack kernel per call (they change
-// every optimizer step; 45 MB per generator pass, ~1e-2 of the conv time).
+// Layout: activations NCHW fp32.  The GEMM "N" dimension is the flattened pixel index, so consecutive lanes touch
+// consecutive addresses of one channel plane (coalesced loads and epilogue stores: the 32x32 accumulator has its COLUMN
+// on the lane, so the pixel is the column and the output channel the row).
+//
+// Kernels:  igemm2_kernel / wgrad2_kernel  -- channel counts that are multiples of 16 / 64: the step's hot kernels
+//           igemm_kernel  / wgrad_kernel   -- generic K order (3-/4-channel stems, odd channel counts, > 25 taps)
+//           smallm_*                       -- <= 4 output channels (vector ALU)
+//           repack_* / pack_strip / transpose4 -- weight packing (pcgan_conv2d_pack_weights, once per optimizer step)
+// What bounds them and why they are written the way they are: DESIGN.md section 3.
 //
 // Reference call sites replaced: see include/pcgan_hip.h.
 #include "common.h"
@@ -66,7 +66,6 @@ struct IgemmArgs {
     float slope;
     unsigned x_bytes;
     int nphase;
-    int stagger;  // > 0: waves in odd hardware slots sleep this many 64-cycle units before starting
     int rowfold;  // MODE_BWD_REFLECT: the row mirrors are folded into per-phase weights, only column mirrors are gathered
     int chunked;  // K order of ph[].A: 1 = (16-channel chunk, tap, channel) -> igemm2_kernel, 0 = (tap, channel)
     int ksplit;   // > 1: blockIdx.z takes a contiguous range of K stages and stores a raw partial sum
@@ -119,16 +118,16 @@ struct KIter {
     }
 };
 
-// Block tile BM (output channels) x BP (pixels), K stage 16, 4 waves.
-// LDS images (all accesses 128-bit):
+// Generic-K-order kernel: K ordered (tap, channel) with the channel count padded to 4, so a 16-deep K stage may
+// straddle filter taps (3-/4-channel stems, odd channel counts, > 25 taps).  Block tile BM (output channels) x BP
+// (pixels), K stage 16, 4 waves, double-buffered LDS, one barrier per stage.  LDS images (all accesses 128-bit):
 //   As[row][20]      : 16 k of one output channel per row (+4 floats pad => ds_read_b128 conflict-free)
 //   Bs[k/4][pix][4]  : 4 consecutive k of one pixel per 16-byte slot
-// The MFMA consumes K in a permuted order (half-wave h takes k = 4*(2q+h)+j in step (q,j)); A and B use the
-// same permutation so the sum is unchanged.
-// CG16: the padded channel count is a multiple of 16, so a K stage never straddles a filter tap: one
-// spatial offset per stage and a two-compare iterator (keeps the gather code short and branch-free).
-template <int MODE, int BM, int BP, bool CG16>
+// The MFMA consumes K in a permuted order (half-wave h takes k = 4*(2q+h)+j in step (q,j)); A and B use the same
+// permutation so the sum is unchanged.  The layers that matter for the step time use igemm2_kernel below.
+template <int MODE, int BM, int BP>
 __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
+    static_assert(MODE != MODE_BWD_REFLECT, "the mirror-gather data gradient exists only in the chunked-K kernel");
     constexpr int WM = (BM == 128 || (BM == 64 && BP == 64)) ? 2 : 1;  // waves along M
     constexpr int WP = 4 / WM;                                         // waves along pixels
     constexpr int WMT = BM / WM, WPT = BP / WP;
@@ -150,18 +149,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     const int m0 = mt * BM, p0 = pt * BP;
     const int Ptot = P.Ptot, Kp = P.Kp;
     if (p0 >= Ptot) return;  // phases of unequal size share one grid
-    // phase fields in registers: re-reading them from the kernel-argument segment inside the K loop costs a
-    // scalar load + lgkmcnt(0) per stage, which also drains the LDS operand reads
     const int ph_r0 = P.r0, ph_s0 = P.s0, ph_nR = P.nR, ph_nS = P.nS, ph_Ws = P.Ws, ph_fy = P.fy, ph_fx = P.fx;
-
-    // De-phase the co-resident workgroups of a CU.  Two workgroups that start together run this loop in
-    // lockstep: both gather, both sit in the LDS-read latency and both reach their barrier at the same time, so
-    // the matrix pipe idles through every stage's non-MFMA part (measured 33 % idle).  The waves in the odd
-    // hardware wave slots of each SIMD (HW_ID[3:0]) start half a stage later, so one workgroup's gather /
-    // barrier phase falls under the other's MFMA phase.  Speed only -- no effect on results.
-    if (a.stagger > 0 && (__builtin_amdgcn_s_getreg(6148) & 1)) {
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
-    }
 
     const Geom g{a.Hg, a.Wg, a.sl, a.pad};
     const int HsWs = P.Hs * ph_Ws;
@@ -180,17 +168,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         const int sy = rem / ph_Ws;
         py = sy * a.ostep + ph_fy;
         px = (rem - sy * ph_Ws) * a.ostep + ph_fx;
-        vbase = (a.stagger < 0 ? 0 : gn) * a.Cg * HgWg;  // stagger < 0: timing experiment, all images alias image 0
-    }
-    // MODE_BWD_REFLECT: padded-grid index of the mirror image of this pixel's row / column (-1: none).
-    // Padded row j holds input row reflect(j - pad); row py therefore also appears at j = pad - py when
-    // 1 <= py <= pad and at j = pad + 2(H-1) - py when H-1-pad <= py <= H-2 (H >= 2 pad + 2 checked on host).
-    int myr = -1, mxr = -1;
-    if (MODE == MODE_BWD_REFLECT) {
-        if (py >= 1 && py <= a.pad) myr = a.pad - py;
-        else if (py >= a.Yh - 1 - a.pad && py <= a.Yh - 2) myr = a.pad + 2 * (a.Yh - 1) - py;
-        if (px >= 1 && px <= a.pad) mxr = a.pad - px;
-        else if (px >= a.Yw - 1 - a.pad && px <= a.Yw - 2) mxr = a.pad + 2 * (a.Yw - 1) - px;
+        vbase = gn * a.Cg * HgWg;
     }
     const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);  // which KPT-slice of the stage this wave gathers
 
@@ -201,15 +179,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     const int st_end = st_begin + nst_per < nst_all ? st_begin + nst_per : nst_all;
 
     KIter it{0, 0, 0};
-    if (CG16) {  // chunked K order: stage st = (channel chunk st / T, tap st % T)
-        const int T = ph_nR * ph_nS;
-        const int cc0 = st_begin / T, tap0 = st_begin - cc0 * T;
-        it.c = cc0 * 16;
-        it.ri = tap0 / ph_nS;
-        it.sj = tap0 - it.ri * ph_nS;
-    } else {
-        it.advance(st_begin * 16 + ksub * KPT, a.Cgp, ph_nS);
-    }
+    it.advance(st_begin * 16 + ksub * KPT, a.Cgp, ph_nS);
 
     float4 areg[ACH];
     float breg[KPT];
@@ -222,71 +192,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         a_ok[j] = (row < BM) & (m0 + row < a.M);
         a_off[j] = (unsigned)((m0 + row) * Kp + kc) * 4u;
     }
-    float bmir[MODE == MODE_BWD_REFLECT ? 3 : 1][MODE == MODE_BWD_REFLECT ? KPT : 1];  // mirror-image gathers
 
-    auto load_stage = [&](int k0, auto nm_tag) {
-        constexpr int NM = decltype(nm_tag)::value;
+    auto load_stage = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int kc = ((tid + 256 * j) & 3) * 4;
             areg[j] = ld_b128(rA, (a_ok[j] & (k0 + kc < Kp)) ? a_off[j] + (unsigned)k0 * 4u : OOB);
-        }
-        if (CG16 && MODE == MODE_BWD_REFLECT) {
-            // Data gradient of ReflectionPad2d(pad)+conv (stride 1), gathered directly on the UNPADDED grid:
-            // input row py collects the padded rows {py+pad} U {its mirror image, if py is within pad of an
-            // edge}; same for columns => up to 2x2 sources per tap.  NM (compile time, chosen per workgroup)
-            // says which mirror sets exist: 1 = column mirrors only, 3 = row, column and corner mirrors.
-            // Straight-line code; all loads land in separate registers and are summed at the LDS write.
-            const int r = it.ri, sx = it.sj;
-            const int ya = py + a.pad - r, yb = myr - r, xa = px + a.pad - sx, xb = mxr - sx;
-            const bool base = pvalid & (it.ri < ph_nR);
-            const bool oya = base & ((unsigned)ya < (unsigned)a.Hg), oyb = base & (myr >= 0) & ((unsigned)yb < (unsigned)a.Hg);
-            const bool oxa = (unsigned)xa < (unsigned)a.Wg, oxb = (mxr >= 0) & ((unsigned)xb < (unsigned)a.Wg);
-            const unsigned v00 = (oya & oxa) ? (unsigned)(vbase + ya * a.Wg + xa) * 4u : OOB;
-            const unsigned v01 = (oya & oxb) ? (unsigned)(vbase + ya * a.Wg + xb) * 4u : OOB;
-            const unsigned v10 = (oyb & oxa) ? (unsigned)(vbase + yb * a.Wg + xa) * 4u : OOB;
-            const unsigned v11 = (oyb & oxb) ? (unsigned)(vbase + yb * a.Wg + xb) * 4u : OOB;
-            const int c0 = it.c + ksub * KPT;
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const unsigned so = (unsigned)((c0 + i) * HgWg) * 4u;
-                breg[i] = ld_b32(rX, v00, so);
-                if (NM >= 1) bmir[0][i] = ld_b32(rX, v01, so);
-                if (NM >= 3) {
-                    bmir[1][i] = ld_b32(rX, v10, so);
-                    bmir[2][i] = ld_b32(rX, v11, so);
-                }
-            }
-            // next stage: next tap of the same channel chunk; after the last tap, the next chunk
-            const int s1 = it.sj + 1;
-            const bool ws = s1 == ph_nS;
-            it.sj = ws ? 0 : s1;
-            const int r1 = it.ri + (ws ? 1 : 0);
-            const bool wr = r1 == ph_nR;
-            it.ri = wr ? 0 : r1;
-            it.c += wr ? 16 : 0;
-            return;
-        }
-        if (CG16) {
-            // whole stage inside tap (it.ri, it.sj); this wave gathers channels it.c + ksub*KPT + i.
-            // Written with selects only (no branches) so the stage body stays ONE basic block and the
-            // scheduler can spread these instructions between the MFMAs.
-            int off;
-            const bool ok = tap_offset<MODE>(g, py, px, ph_r0 + it.ri * a.tstep, ph_s0 + it.sj * a.tstep, off);
-            const unsigned voff = (ok & pvalid & (it.ri < ph_nR)) ? (unsigned)(vbase + off) * 4u : OOB;
-            const int c0 = it.c + ksub * KPT;
-#pragma unroll
-            for (int i = 0; i < KPT; ++i)
-                breg[i] = ld_b32(rX, (c0 + i < a.Cg) ? voff : OOB, (unsigned)((c0 + i) * HgWg) * 4u);
-            // next stage: next tap of the same channel chunk; after the last tap, the next chunk
-            const int s1 = it.sj + 1;
-            const bool ws = s1 == ph_nS;
-            it.sj = ws ? 0 : s1;
-            const int r1 = it.ri + (ws ? 1 : 0);
-            const bool wr = r1 == ph_nR;
-            it.ri = wr ? 0 : r1;
-            it.c += wr ? 16 : 0;
-            return;
         }
         KIter e = it;
         unsigned voff = OOB;
@@ -305,20 +216,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         }
         it.advance(16, a.Cgp, ph_nS);
     };
-    auto store_stage = [&](int buf, auto nm_tag) {
-        constexpr int NM = decltype(nm_tag)::value;
+    auto store_stage = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int q = tid + 256 * j;
             const int row = q >> 2, kc = (q & 3) * 4;
             if (BM * 4 >= 256 || row < BM) *reinterpret_cast<float4*>(&As[buf][row * AP + kc]) = areg[j];
-        }
-        if constexpr (NM == 1) {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) breg[i] += bmir[0][i];
-        } else if constexpr (NM == 3) {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) breg[i] += (bmir[0][i] + bmir[1][i]) + bmir[2][i];
         }
 #pragma unroll
         for (int gq = 0; gq < KPT / 4; ++gq)
@@ -347,92 +250,31 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
         }
     };
-    auto mfma_group = [&](const float (&av)[MI][4], const float (&bv)[PJ][4], int jj0) {
+    auto mfma_group = [&](const float (&av)[MI][4], const float (&bv)[PJ][4]) {
 #pragma unroll
-        for (int jj = jj0; jj < jj0 + 2; ++jj)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < PJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][jj], bv[j][jj], acc[i][j], 0, 0, 0);
     };
-    // Software pipeline inside ONE wave (co-resident workgroups run in lockstep, so a wave cannot count on
-    // its SIMD partner to cover its own non-MFMA work): the MFMA chain of a stage is cut into four groups and
-    // the next stage's global gathers, the second half's LDS operand reads and the address arithmetic are issued
-    // BETWEEN the groups, i.e. in the shadow of matrix instructions that are already executing.
-    // sched_barrier(0) pins that order against the compiler's own clustering.
-    auto run = [&](auto nm_tag) {
-        constexpr int NM = decltype(nm_tag)::value;
-        if (st_begin >= st_end) return;  // empty K range (split-K tail): accumulators stay zero, stored below
-        load_stage(st_begin * 16, nm_tag);
-        store_stage(0, nm_tag);
+    if (st_begin < st_end) {  // (empty K range of a split-K tail: accumulators stay zero, stored below)
+        load_stage(st_begin * 16);
+        store_stage(0);
         __syncthreads();
         read_ops(0, 0, av0, bv0);
-        if (CG16) {
-            // One basic block per stage; the directive sequence below asks the scheduler for
-            //   MFMA, then a few VALU/SALU (gather address arithmetic), gather loads, one LDS operand read
-            // per matrix instruction, so the non-MFMA work of the NEXT stage is issued while matrix
-            // instructions of THIS stage execute (a wave cannot issue past an MFMA that is waiting for the
-            // pipe: only fine-grained interleaving hides that work).
-            constexpr int NMFMA = MI * PJ * 8;
-            constexpr int NLD = ACH + KPT * (1 + NM);
-            constexpr int LGAPS = NMFMA >= 24 ? 12 : (NMFMA >= 16 ? 8 : 4);   // gaps that carry gather loads
-            for (int st = st_begin; st + 1 < st_end; ++st) {
-                const int buf = (st - st_begin) & 1;
-                read_ops(buf, 1, av1, bv1);
-                load_stage((st + 1) * 16, nm_tag);
-                mfma_group(av0, bv0, 0);
-                mfma_group(av0, bv0, 2);
-                mfma_group(av1, bv1, 0);
-                mfma_group(av1, bv1, 2);
-                // first third of the chain: LDS operand reads + all gather loads (they need >= ~1000 cycles
-                // to land before the LDS write at the end); rest: left-over bookkeeping; LDS writes last
-#pragma unroll
-                for (int gI = 0; gI < NMFMA; ++gI) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // 1 MFMA
-                    if (gI < MI + PJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // LDS read
-                    if (gI < LGAPS) {
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                          // VALU
-                        __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);                          // SALU
-                        __builtin_amdgcn_sched_group_barrier(0x020, (NLD + LGAPS - 1) / LGAPS, 0);  // gathers
-                    } else {
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);   // every MFMA of the stage is issued before the LDS hand-over
-                store_stage(buf ^ 1, nm_tag);
-                __syncthreads();
-                read_ops(buf ^ 1, 0, av0, bv0);
-            }
-            read_ops((st_end - 1 - st_begin) & 1, 1, av1, bv1);
-            mfma_group(av0, bv0, 0);
-            mfma_group(av0, bv0, 2);
-            mfma_group(av1, bv1, 0);
-            mfma_group(av1, bv1, 2);
-        } else {
-            for (int st = st_begin; st < st_end; ++st) {
-                const int buf = (st - st_begin) & 1;
-                const bool more = st + 1 < st_end;
-                read_ops(buf, 1, av1, bv1);
-                if (more) load_stage((st + 1) * 16, nm_tag);
-                mfma_group(av0, bv0, 0);
-                mfma_group(av0, bv0, 2);
-                mfma_group(av1, bv1, 0);
-                mfma_group(av1, bv1, 2);
-                if (more) store_stage(buf ^ 1, nm_tag);
-                __syncthreads();
-                if (more) read_ops(buf ^ 1, 0, av0, bv0);
-            }
+        for (int st = st_begin; st < st_end; ++st) {
+            const int buf = (st - st_begin) & 1;
+            const bool more = st + 1 < st_end;
+            read_ops(buf, 1, av1, bv1);
+            if (more) load_stage((st + 1) * 16);
+            mfma_group(av0, bv0);
+            mfma_group(av1, bv1);
+            if (more) store_stage(buf ^ 1);
+            __syncthreads();
+            if (more) read_ops(buf ^ 1, 0, av0, bv0);
         }
-    };
-    if (MODE == MODE_BWD_REFLECT && CG16) {
-        // row mirrors exist only in workgroups that touch rows 1..pad or H-1-pad..H-2 (a workgroup-uniform,
-        // loop-invariant fact): those run the 4-source loop, the others the 2-source loop
-        if (__syncthreads_or(myr >= 0)) run(std::integral_constant<int, 3>{});
-        else run(std::integral_constant<int, 1>{});
-    } else {
-        run(std::integral_constant<int, 0>{});
     }
 
     // --- epilogue: bias + activation, NCHW store (pixel on the lane -> coalesced) -----
@@ -508,17 +350,6 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
 // written to LDS but never consumed.  Source order in the loop IS the issue order (sched_barrier(0) per slot).
 static constexpr int NTAP_FWD = 25;   // filter taps the offset table holds (5x5)
 static constexpr int NTAP_MIR = 9;    // ... for the fused reflect data gradient (4 source combinations)
-
-#ifdef EXP_NORD
-#define EXP_RD(x)
-#else
-#define EXP_RD(x) x
-#endif
-#ifdef EXP_NOWR
-#define EXP_WR(x)
-#else
-#define EXP_WR(x) x
-#endif
 
 // index along one axis of the gathered tensor for filter tap `tap`, or 0xffffffff if the tap falls outside.
 // Forward modes: p = output coordinate.  Backward modes: base = p + pad (or the padded-grid index of the mirror
@@ -769,22 +600,16 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
 #pragma unroll
                 for (int k = 0; k < NI1; ++k) {
                     if (k * NH / NI1 != g) continue;
-                    if (k < I_RB) { EXP_RD(read_a(buf, 1, k - I_RA, av1)); }
-                    else if (k < I_WA) { EXP_RD(read_b(buf, 1, k - I_RB, bv1)); }
-                    else if (k < I_WB) { EXP_WR(store_a(buf ^ 1, k - I_WA)); }
-                    else if (k < I_LA) { EXP_WR(store_b(buf ^ 1, k - I_WB, nm_tag)); }
-#ifndef EXP_NOLOAD
+                    if (k < I_RB) read_a(buf, 1, k - I_RA, av1);
+                    else if (k < I_WA) read_b(buf, 1, k - I_RB, bv1);
+                    else if (k < I_WB) store_a(buf ^ 1, k - I_WA);
+                    else if (k < I_LA) store_b(buf ^ 1, k - I_WB, nm_tag);
                     else if (k < I_LB) load_a(k - I_LA);
                     else load_b(k - I_LB, nm_tag);
-#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-#ifdef EXP_NOBAR
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < NH; ++g) {
@@ -792,8 +617,8 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
 #pragma unroll
                 for (int k = 0; k < NI2; ++k) {
                     if (k * NH / NI2 != g) continue;
-                    if (k < J_RB) { EXP_RD(read_a(buf ^ 1, 0, k - J_RA, av0)); }
-                    else if (k < J_TA) { EXP_RD(read_b(buf ^ 1, 0, k - J_RB, bv0)); }
+                    if (k < J_RB) read_a(buf ^ 1, 0, k - J_RA, av0);
+                    else if (k < J_TA) read_b(buf ^ 1, 0, k - J_RB, bv0);
                     else next_offsets(nm_tag);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -807,13 +632,8 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
     if (MIR) {  // workgroup-uniform: how many mirror images do its pixels receive at most?
         const int any2 = __syncthreads_or((myr >= 0) & (mxr >= 0));
         const int any1 = __syncthreads_or((myr >= 0) | (mxr >= 0));
-#ifdef EXP_NM0
-        if (a.N < 0) run(std::integral_constant<int, 3>{});
-        else if (a.N < -1) run(std::integral_constant<int, 1>{});
-#else
         if (any2 || (any1 && !a.rowfold)) run(std::integral_constant<int, 3>{});
         else if (any1) run(std::integral_constant<int, 1>{});      // column mirrors only (table slot 1)
-#endif
         else run(std::integral_constant<int, 0>{});
     } else {
         run(std::integral_constant<int, 0>{});
@@ -1303,7 +1123,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
 // weight re-layout kernels
 // ------------------------------------------------------------------------------------
 // forward: A[k][tap][c] (Cgp-padded) from w[K][C][R][S]
-// chunked != 0 (CG16 kernels): K order (16-channel chunk, tap, channel-in-chunk), so the 9..49 taps of one
+// chunked != 0 (igemm2_kernel): K order (16-channel chunk, tap, channel-in-chunk), so the 9..49 taps of one
 // channel chunk are consecutive K stages and re-read the same small input tile from L1/L2 instead of
 // streaming the whole input once per tap from beyond L2
 __global__ void repack_fwd_kernel(const float* __restrict__ w, float* __restrict__ A, int K, int C, int Cgp,
@@ -1985,10 +1805,6 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
     if (ks > 1 && (size_t)ks * out_elems * 4 > part_bytes) ks = 1;
     a.ksplit = ks;
     a.Ypart = part_ws;
-    {
-        const char* env = getenv("PCGAN_STAGGER");
-        a.stagger = env ? atoi(env) : 0;
-    }
     const dim3 grid((unsigned)(((a.M + bm - 1) / bm) * ((pmax + bp - 1) / bp)), (unsigned)a.nphase, (unsigned)ks);
     a.tstart[0] = 0;
     for (int i = 0; i < a.nphase; ++i) a.tstart[i + 1] = a.tstart[i] + (a.ph[i].Ptot + bp - 1) / bp;
@@ -2001,14 +1817,10 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
             PCGAN_CHECK(a.ph[i].nR * a.ph[i].nS <= (MODE == MODE_BWD_REFLECT ? NTAP_MIR : NTAP_FWD) && (a.ph[i].Kp % 16) == 0,
                         "igemm: chunked K order: bad phase");
     }
-    static const bool old_kernel = getenv("PCGAN_OLD_IGEMM") != nullptr;   // A/B experiments
 #define LI(BMV, BPV)                                                                                   \
     do {                                                                                               \
-        if (cg16 && !old_kernel) hipLaunchKernelGGL((igemm2_kernel<MODE, BMV, BPV>), grid2, dim3(256), 0, st, a); \
-        else if (cg16) hipLaunchKernelGGL((igemm_kernel<MODE, BMV, BPV, true>), grid, dim3(256), 0, st, a); \
-        else if (MODE != MODE_BWD_REFLECT)                                                             \
-            hipLaunchKernelGGL((igemm_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV, false>), grid, \
-                               dim3(256), 0, st, a);                                                   \
+        if (cg16) hipLaunchKernelGGL((igemm2_kernel<MODE, BMV, BPV>), grid2, dim3(256), 0, st, a);      \
+        else hipLaunchKernelGGL((igemm_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV>), grid, dim3(256), 0, st, a); \
     } while (0)
     if (bm == 128 && bp == 128) LI(128, 128);
     else if (bm == 128) LI(128, 64);
