@@ -102,9 +102,9 @@ class branch(object):
     """with branch('E') as b: ... loss = f(...) ; b.join(loss): run the body on the named stream after everything
     queued so far on the current stream; join() makes the current stream wait and hands the tensors over."""
 
-    def __init__(self, name):
+    def __init__(self, name, enabled=True):
         self.name = name
-        self.on = BRANCH_STREAMS and torch.cuda.is_available()
+        self.on = enabled and BRANCH_STREAMS and torch.cuda.is_available()
 
     def __enter__(self):
         if self.on:
@@ -160,13 +160,24 @@ def invalidate_packed_weights():
 def _packed_weights(lib, d, pass_, w, cache):
     key = (pass_, d.stride, d.pad, d.pad_mode)
     stamp = (_PACK_EPOCH[0], w._version, w.data_ptr(), tuple(w.shape))
+    cur = torch.cuda.current_stream()
     ent = cache.get(key)
     if ent is not None and ent[0] == stamp:
+        if ent[3] != cur.cuda_stream:      # packed on another stream (branch streams): order this use after the pack
+            cur.wait_event(ent[2])
         return ent[1]
     nb = max(int(lib.pcgan_conv2d_packed_bytes(ctypes.byref(d), pass_)), 256)
-    buf = ent[1] if (ent is not None and ent[1].numel() == nb and ent[1].device == w.device) else _ws(nb, w.device)
+    if ent is not None and ent[1].numel() == nb and ent[1].device == w.device:
+        buf = ent[1]
+        if ent[3] != cur.cuda_stream:      # re-pack into a buffer another stream may still be reading
+            for st in list(_side.values()) + list(_branch.values()):
+                cur.wait_stream(st)
+    else:
+        buf = _ws(nb, w.device)
     _L.check(lib.pcgan_conv2d_pack_weights(ctypes.byref(d), pass_, _p(w), _p(buf), _stream()), 'conv2d_pack_weights')
-    cache[key] = (stamp, buf)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    cache[key] = (stamp, buf, ev, cur.cuda_stream)
     return buf
 
 

@@ -12,6 +12,7 @@ pcgan_amd.hip.  What is different by design:
   * `--lr_E > 0` (update_G_and_E) raises: the reference's own branch fails on torch >= 1.5 with
     an in-place-modification error, so there is no behaviour to reproduce.
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -23,6 +24,8 @@ from ..hip import ops as hip_ops
 from ..hip import parallel
 from ..hip.optim import FusedAdam
 from ..util.util import upsample2d, str2list, str2bool, resample, compute_mu_and_var
+
+_G2_BRANCH = os.environ.get('PCGAN_G2_BRANCH', '0') == '1'
 
 MAGIC_EPS = 1e-20
 
@@ -247,7 +250,18 @@ class WSGANEmbModel(BaseModel):
         self.fake_B = self.netG(self.real_A, self.embedding_B)
         self.fake_B_IP = upsample2d(self.fake_B, o.fineSize_IP)
         self.fake_B_E = upsample2d(self.fake_B, o.fineSize_E)
-        self.rec_A = self.netG(self.fake_B.detach() if o.detach_fake_B else self.fake_B, self.embedding_A)
+        # the second generator pass only meets the other consumers of fake_B (D / IP / E branches of backward_G) in the
+        # loss sum: it runs on its own stream beside them (forward here, its backward nodes on the same stream)
+        # (opt-in, PCGAN_G2_BRANCH=1: -1.3 % step time, but the second pass's kernels then share the GPU with the
+        # branches and per-kernel timings of the generator are no longer those of a kernel running alone)
+        with hip_ops.branch('G2', enabled=_G2_BRANCH) as self._rec_branch:
+            self.rec_A = self.netG(self.fake_B.detach() if o.detach_fake_B else self.fake_B, self.embedding_A)
+
+    def _join_rec(self):
+        b = getattr(self, '_rec_branch', None)
+        if b is not None:
+            b.join(self.rec_A)
+            self._rec_branch = None
 
     def test(self):
         if hasattr(self, 'real_B'):
@@ -297,6 +311,7 @@ class WSGANEmbModel(BaseModel):
         else:
             self.loss_G_IP = 0.0
         self.loss_G_GAN = self.criterionGAN(self.netD(self.fake_B, self._rating_for_D()), True)
+        self._join_rec()
         if o.lambda_A_GAN > 0.0:
             self.loss_G_GAN_cycle = self.criterionGAN(self.netD(self.rec_A, self.embedding_A), True) * o.lambda_A_GAN
         else:
@@ -377,6 +392,7 @@ class WSGANEmbModel(BaseModel):
         self.update_D()
 
     def get_current_visuals(self):
+        self._join_rec()
         self.set_requires_grad(self.netG, False)
         ret = OrderedDict()
         for name in self.visual_names:
