@@ -1,0 +1,111 @@
+"""Config-2 (BASELINE.json configs[1]) FULL-SIZE checks of the hot kernels and of one whole step.
+
+The oracle cannot restate a bs-32 256-channel convolution stack in seconds, so at full size the kernels are held to
+size-independent properties of the convolution (SURVEY.md 8c / tier rule 3):
+  * adjoint identities  <conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)>  (ties the three kernels together),
+  * linearity in the input,
+  * batch-slice consistency: image n of the bs-32 result equals the bs-8 result holding that image up to fp32
+    re-association (small launches are cut along K -- split-K -- so the summation order may differ; 1e-5),
+  * direct parity of ONE image against the oracle's CPU convolution (float64 twin),
+and the full optimize_parameters() at full network size (9-block G, ngf 64, 128x128) is compared with the oracle's
+CPU step on a batch of 2.
+
+Tolerances: dot products of ~3e7 fp32 terms accumulated in float64 from fp32 results: 2e-5 relative; one-image
+parity 2e-5 of the largest magnitude (forward / dgrad), 1e-4 (weight gradient, 1024-term pixel sums x 8 images).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_ref as R
+from util_cmp import assert_close
+
+pytestmark = pytest.mark.gpu
+
+# the layers that carry the step: name, C, H, K, R, stride, pad, pad_mode
+FULL = [
+    ('G.res 256->256 3x3 reflect @32', 256, 32, 256, 3, 1, 1, 1),
+    ('G.down2 128->256 3x3 s2 @64', 128, 64, 256, 3, 2, 1, 0),
+    ('D.c3 256->512 4x4 @16', 256, 16, 512, 4, 1, 1, 0),
+    ('G.head 64->3 7x7 reflect @128', 64, 128, 3, 7, 1, 3, 1),
+]
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize('case', FULL, ids=[c[0] for c in FULL])
+def test_fullsize_conv_properties(case, dev):
+    from pcgan_amd.hip import ops
+    name, C, H, K, Rk, stride, pad, pm = case
+    N = 32
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    x = (torch.rand(N, C, H, H, generator=g) * 2 - 1).to(dev)
+    x2 = (torch.rand(N, C, H, H, generator=g) * 2 - 1).to(dev)
+    w = (torch.randn(K, C, Rk, Rk, generator=g) * 0.05).to(dev)
+    P = (H + 2 * pad - Rk) // stride + 1
+    dy = torch.randn(N, K, P, P, generator=g).to(dev)
+
+    y = ops.conv2d_fwd(x, w, None, stride, pad, pm)
+    dx = ops.conv2d_bwd_data(dy, w, (H, H), stride, pad, pm)
+    dw = ops.conv2d_bwd_weight(x, dy, tuple(w.shape), stride, pad, pm)
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all() and torch.isfinite(dw).all()
+
+    # adjoint identities
+    a, b, c = _dot(y, dy), _dot(x, dx), _dot(w, dw)
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(a - b) <= 2e-5 * scale, '%s: <conv x, dy> %.9g vs <x, dgrad dy> %.9g' % (name, a, b)
+    assert abs(a - c) <= 2e-5 * scale, '%s: <conv x, dy> %.9g vs <w, wgrad> %.9g' % (name, a, c)
+
+    # linearity in x
+    y2 = ops.conv2d_fwd(x2, w, None, stride, pad, pm)
+    ylin = ops.conv2d_fwd(0.5 * x - 2.0 * x2, w, None, stride, pad, pm)
+    assert_close(ylin, (0.5 * y.double() - 2.0 * y2.double()).cpu(), 2e-5, name + ' linearity')
+
+    # batch-slice consistency (forward, data gradient)
+    y8 = ops.conv2d_fwd(x[8:16].contiguous(), w, None, stride, pad, pm)
+    assert_close(y8, y[8:16].double().cpu(), 1e-5, name + ' forward of a batch slice')
+    dx8 = ops.conv2d_bwd_data(dy[8:16].contiguous(), w, (H, H), stride, pad, pm)
+    assert_close(dx8, dx[8:16].double().cpu(), 1e-5, name + ' data gradient of a batch slice')
+
+    # one image against the oracle (float64 twin on the CPU)
+    xc = x[5:6].double().cpu().requires_grad_(True)
+    wc = w.double().cpu()
+    yr = R.conv2d(xc, wc, None, stride, pad, pm)
+    yr.backward(dy[5:6].double().cpu())
+    assert_close(y[5:6], yr.detach(), 2e-5, name + ' image 5 forward vs oracle')
+    assert_close(dx[5:6], xc.grad, 2e-5, name + ' image 5 data gradient vs oracle')
+    # weight gradient of a bs-8 slice against the oracle
+    x8 = x[:8].double().cpu()
+    w8 = w.double().cpu().requires_grad_(True)
+    R.conv2d(x8, w8, None, stride, pad, pm).backward(dy[:8].double().cpu())
+    dw8 = ops.conv2d_bwd_weight(x[:8].contiguous(), dy[:8].contiguous(), tuple(w.shape), stride, pad, pm)
+    assert_close(dw8, w8.grad, 1e-4, name + ' weight gradient (8 images) vs oracle')
+
+
+def test_fullsize_step_vs_oracle(tmp_path, dev):
+    """One optimize_parameters() with the FULL networks of config 2 (9-block G ngf 64, 3-layer D ndf 64, ResNet-18 E
+    and AlexNet IP at 224) on a batch of 2: losses and fake_B against the oracle's CPU step from the same weights."""
+    import bench
+    from oracle import networks_ref as N
+    from oracle import step_ref as S
+    torch.manual_seed(0)
+    model, opt = bench.build_model(0, 2, 128, str(tmp_path), seed=3)
+    G = N.ResnetGeneratorRef(3, 3, 1, 64, 'instance', 9)
+    D = N.NLayerDiscriminatorRef(3, 1, 64, 3, 'batch', True)
+    E = N.SiameseFeatureRef(N.ResNetFeatureRef('resnet18'), 'avg', (32, 1), 1, 0.7, False)
+    IP = N.AlexNetFeatureRef(3, 'None')
+    for ref, net in ((G, model.netG), (D, model.netD), (E, model.netE), (IP, model.netIP)):
+        ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    oracle = S.WSGANEmbStepRef(G, D, E, IP)
+    b = bench.synthetic_batch(2, 128, 0)
+    oracle.set_input(b['A'], b['B'], [int(v) for v in b['label']])
+    oracle.optimize_parameters()
+    model.set_input(b)
+    model.optimize_parameters()
+    got, want = model.get_current_losses(), oracle.losses()
+    for k, v in want.items():
+        assert abs(got[k] - v) <= 2e-4 * max(1.0, abs(v)), 'loss %s: hip %.7g oracle %.7g' % (k, got[k], v)
+    assert_close(model.fake_B, oracle.fake_B.detach(), 2e-4, 'fake_B (full-size generator)')
+    assert_close(model.rec_A, oracle.rec_A.detach(), 2e-4, 'rec_A (full-size generator)')
