@@ -202,6 +202,69 @@ def golden_steps(rn, outdir):
                      niter_decay=opt.niter_decay, epoch_count=opt.epoch_count, base_lr=opt.lr)
 
 
+def golden_cycle_step(rn, outdir):
+    """wsgan_cycle: optimize_parameters() x2 through the reference's own parser and model class:
+    unconditional D, trained ResNet-18 encoder (max pooling, cnn_dim [64, 1]), resnet generator."""
+    from options.train_options import TrainOptions
+    from models import create_model
+    tmp = tempfile.mkdtemp(prefix='pcgan_golden_cycle_')
+    base = rn.ResNetFeature(3, 'resnet18')
+    base_path = os.path.join(tmp, 'resnet18_base.pth')
+    torch.save(W.fill_state_dict(base.model.state_dict(), 31), base_path)        # plain ResNet state_dict (load_base)
+    ip = rn.AlexNetFeature(input_nc=3, pooling='None')
+    ip_path = os.path.join(tmp, 'IP.pth')
+    torch.save(W.fill_state_dict(ip.state_dict(), 40), ip_path)
+    sys.argv = ['train.py', '--dataroot', tmp, '--model', 'wsgan_cycle', '--name', 'g_cycle',
+                '--checkpoints_dir', tmp, '--gpu_ids', '-1', '--which_model_netG', 'resnet_9blocks',
+                '--which_model_netD', 'n_layers', '--n_layers_D', '3', '--ngf', '8', '--ndf', '8',
+                '--fineSize', '32', '--loadSize', '32', '--fineSize_E', '64', '--fineSize_IP', '64',
+                '--batchSize', '4', '--pretrained_model_path_E', base_path, '--pretrained_model_path_IP', ip_path,
+                '--display_id', '-1', '--attr_bins', '[10, 30, 50]', '--attr_mean', '35.0', '--attr_std', '20.0']
+    opt = TrainOptions().parse()
+    model = create_model(opt)
+    model.setup(opt)
+    model.netG.load_state_dict(W.damp_generator_head(W.fill_state_dict(model.netG.state_dict(), 19)))
+    model.netD.load_state_dict(W.fill_state_dict(model.netD.state_dict(), 20))
+    esd = model.netE.state_dict()                       # the head (cnn.*) is not covered by load_base: make it deterministic
+    filled = W.fill_state_dict(esd, 33)
+    for k in esd:
+        if k.startswith('cnn'):
+            esd[k] = filled[k]
+    model.netE.load_state_dict(esd)
+    out = {}
+    for it in range(2):
+        A = W.seeded_tensor((4, 3, 32, 32), 700 + it)
+        attr = (W.seeded_tensor((4, 1, 1, 1), 800 + it) + 1.0) * 30.0          # attributes in [0, 60)
+        torch.manual_seed(4321 + it)
+        grabbed, origs = {}, {}
+        for tag, optim, net in (('G', model.optimizer_G, model.netG), ('D', model.optimizer_D, model.netD),
+                                ('E', model.optimizer_E, model.netE)):
+            orig = origs[tag] = optim.step
+
+            def stepper(orig=orig, tag=tag, net=net):
+                grabbed[tag] = [(k, None if p.grad is None else p.grad.detach().clone()) for k, p in net.named_parameters()]
+                return orig()
+            optim.step = stepper
+        model.set_input({'A': A, 'B_attr': attr, 'A_paths': ['a'] * 4, 'B_paths': ['b'] * 4})
+        model.optimize_parameters()
+        model.optimizer_G.step, model.optimizer_D.step, model.optimizer_E.step = origs['G'], origs['D'], origs['E']
+        p = 'it%d' % it
+        losses = model.get_current_losses()
+        out[p + '/losses'] = np.array([losses[k] for k in model.loss_names], dtype=np.float64)
+        for k in ('fake_x', 'rec_x', 'fake_y', 'rec_y', 'real_y'):
+            out['%s/%s' % (p, k)] = t2n(getattr(model, k))
+        grads_summary(grabbed['G'], p + '/gradG', out, False)
+        grads_summary(grabbed['D'], p + '/gradD', out, False)
+        grads_summary(grabbed['E'], p + '/gradE', out, False)
+        for tag, net in (('G', model.netG), ('D', model.netD), ('E', model.netE)):
+            for k, v in net.state_dict().items():
+                a = t2n(v).astype(np.float64)
+                out['%s/after%s/%s' % (p, tag, k)] = np.array([a.sum(), np.abs(a).sum()])
+    out['loss_names'] = np.array(model.loss_names)
+    np.savez_compressed(os.path.join(outdir, 'cycle_step.npz'), **out)
+    print('cycle_step.npz: %d arrays, losses it0 %s' % (len(out), out['it0/losses']))
+
+
 def golden_ints(outdir):
     """Integer-exact helpers."""
     from util import util as ref_util
@@ -233,3 +296,5 @@ if __name__ == '__main__':
         golden_ints(a.out)
     if a.only in ('', 'steps'):
         golden_steps(rn, a.out)
+    if a.only in ('', 'cycle'):
+        golden_cycle_step(rn, a.out)

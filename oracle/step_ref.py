@@ -252,3 +252,90 @@ class WSGANEmbStepRef:
     def losses(self):
         """models/base_model.py:87-93"""
         return {n: float(getattr(self, 'loss_' + n)) for n in self.LOSS_NAMES}
+
+
+# ============================================================================= wsgan_cycle (SURVEY 8f rank 1)
+CYCLE_DEFAULTS = dict(fineSize_E=224, fineSize_IP=224, attr_mean=[0.0], attr_std=[100.0], lambda_x=1.0, lambda_y=1.0,
+                      lambda_IP=1.0, lr=2e-4, beta1=0.5, identity_preserving_criterion='mse')
+
+
+class WSGANCycleStepRef:
+    """CPU restatement of WSGANCycleModel's step (reference models/wsgan_cycle_model.py:148-256): unconditional D,
+    encoder E trained together with G; D is updated first, then G and E."""
+
+    LOSS_NAMES = ['G_GAN', 'G_IP', 'cycle_x', 'cycle_y', 'D_real', 'D_fake']
+
+    def __init__(self, netG, netD, netE, netIP, **opts):
+        o = dict(CYCLE_DEFAULTS)
+        o.update(opts)
+        self.opt = SimpleNamespace(**o)
+        self.netG, self.netD, self.netE, self.netIP = netG, netD, netE, netIP
+        betas = (self.opt.beta1, 0.999)                                        # :125-127
+        self.optimizer_G = torch.optim.Adam(netG.parameters(), lr=self.opt.lr, betas=betas)
+        self.optimizer_E = torch.optim.Adam(netE.parameters(), lr=self.opt.lr, betas=betas)
+        self.optimizer_D = torch.optim.Adam(netD.parameters(), lr=self.opt.lr, betas=betas)
+        self.grads = {}
+
+    def attr_normalize(self, x):
+        """:134"""
+        return (x - self.opt.attr_mean[0]) / self.opt.attr_std[0]
+
+    def set_input(self, A, B_attr):
+        """:148-163 (training branch)"""
+        self.real_x = A
+        self.real_y = self.attr_normalize(B_attr)
+        self.real_x_IP = upsample2d(self.real_x, self.opt.fineSize_IP)
+        self.real_x_E = upsample2d(self.real_x, self.opt.fineSize_E)
+
+    def forward(self):
+        """:165-171 -- the encoder input is not normalised"""
+        self.fake_x = self.netG(self.real_x, self.real_y)
+        self.fake_x_IP = upsample2d(self.fake_x, self.opt.fineSize_IP)
+        self.fake_x_E = upsample2d(self.fake_x, self.opt.fineSize_E)
+        self.fake_y = self.netE(self.real_x_E)
+        self.rec_x = self.netG(self.real_x, self.fake_y)
+        self.rec_y = self.netE(self.fake_x_E)
+
+    def backward_D(self):
+        """:187-201"""
+        self.loss_D_fake = gan_loss(self.netD(self.fake_x.detach()), False)
+        self.loss_D_real = gan_loss(self.netD(self.real_x), True)
+        self.loss_D = (self.loss_D_fake + self.loss_D_real) * 0.5
+        self.loss_D.backward()
+
+    def backward_GE(self):
+        """:203-238 (transform_IP is the identity: SURVEY D8)"""
+        o = self.opt
+        self.loss_G_GAN = gan_loss(self.netD(self.fake_x), True)
+        if o.lambda_IP > 0.0:
+            feature_A = self.netIP(self.real_x_IP).detach()
+            crit = F.mse_loss if o.identity_preserving_criterion.lower() == 'mse' else F.l1_loss
+            self.loss_G_IP = crit(self.netIP(self.fake_x_IP), feature_A) * o.lambda_IP
+        else:
+            self.loss_G_IP = 0.0
+        self.loss_cycle_x = F.l1_loss(self.rec_x, self.real_x) * o.lambda_x if o.lambda_x > 0.0 else 0.0
+        self.loss_cycle_y = F.mse_loss(self.rec_y, self.real_y) * o.lambda_y if o.lambda_y > 0.0 else 0.0
+        self.loss_G = self.loss_G_GAN + self.loss_G_IP + self.loss_cycle_x + self.loss_cycle_y
+        self.loss_G.backward()
+
+    def optimize_parameters(self):
+        """:240-256"""
+        self.forward()
+        for p in self.netD.parameters():
+            p.requires_grad = True
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        self.grads['D'] = {k: p.grad.detach().clone() for k, p in self.netD.named_parameters()}
+        self.optimizer_D.step()
+        for p in self.netD.parameters():
+            p.requires_grad = False
+        self.optimizer_G.zero_grad()
+        self.optimizer_E.zero_grad()
+        self.backward_GE()
+        self.grads['G'] = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in self.netG.named_parameters()}
+        self.grads['E'] = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in self.netE.named_parameters()}
+        self.optimizer_G.step()
+        self.optimizer_E.step()
+
+    def losses(self):
+        return {n: float(getattr(self, 'loss_' + n)) for n in self.LOSS_NAMES}

@@ -20,7 +20,7 @@ def find_dataset_using_name(dataset_name):
         if e.name != module_name:
             raise
         raise NotImplementedError('pcgan_amd: dataset mode [%s] is outside the MI355X hot path '
-                                  '(available: wsgan_emb, synthetic)' % dataset_name)
+                                  '(available: wsgan_emb, wsgan_cycle)' % dataset_name)
     target = dataset_name.replace('_', '') + 'dataset'
     found = None
     for name, cls in vars(lib).items():

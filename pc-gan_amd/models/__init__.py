@@ -12,7 +12,7 @@ def find_model_using_name(model_name):
     except ModuleNotFoundError as e:
         if e.name != module_name:
             raise
-        raise NotImplementedError('pcgan_amd: model [%s] is outside the MI355X hot path (available: wsgan_emb)'
+        raise NotImplementedError('pcgan_amd: model [%s] is outside the MI355X hot path (available: wsgan_emb, wsgan_cycle)'
                                   % model_name)
     target = model_name.replace('_', '') + 'model'
     model = None
