@@ -5,32 +5,14 @@ model's set_input reads ('A', 'B', 'label', 'A_paths', 'B_paths').
 Under torch.distributed every rank draws the same global batch order and keeps its contiguous
 slice (DataParallel's scatter), see pcgan_amd.hip.parallel.shard_batch.
 """
-import importlib
-
 import torch.utils.data
 
 from .base_dataset import BaseDataset
+from ..util.registry import find_plugin
 
 
 def find_dataset_using_name(dataset_name):
-    module_name = '%s.%s_dataset' % (__name__, dataset_name)
-    try:
-        lib = importlib.import_module(module_name)
-    except ModuleNotFoundError as e:
-        if e.name != module_name:
-            raise
-        raise NotImplementedError('pcgan_amd: dataset mode [%s] is outside the MI355X hot path '
-                                  '(available: wsgan_emb, wsgan_cycle)' % dataset_name)
-    target = dataset_name.replace('_', '') + 'dataset'
-    found = None
-    for name, cls in vars(lib).items():
-        if name.lower() == target.lower() and isinstance(cls, type) and issubclass(cls, BaseDataset):
-            found = cls
-    if found is None:
-        print('In %s.py, there should be a subclass of BaseDataset with class name that matches %s in lowercase.'
-              % (module_name, target))
-        exit(0)
-    return found
+    return find_plugin(__name__, 'dataset', dataset_name, BaseDataset)
 
 
 def get_option_setter(dataset_name):
@@ -38,22 +20,24 @@ def get_option_setter(dataset_name):
 
 
 def create_dataset(opt):
-    instance = find_dataset_using_name(opt.dataset_mode)()
-    instance.initialize(opt)
-    print('dataset [%s] was created' % instance.name())
-    return instance
+    dataset = find_dataset_using_name(opt.dataset_mode)()
+    dataset.initialize(opt)
+    print('dataset [%s] was created' % dataset.name())
+    return dataset
 
 
-class CustomDatasetDataLoader():
+class CustomDatasetDataLoader(object):
+    """Iterable over dict batches, capped at --max_dataset_size samples (reference data/__init__.py:42-69)."""
+
     def name(self):
         return 'CustomDatasetDataLoader'
 
     def initialize(self, opt):
         self.opt = opt
         self.dataset = create_dataset(opt)
-        self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=opt.batchSize,
-                                                      shuffle=not opt.serial_batches,
-                                                      num_workers=int(opt.nThreads))
+        self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=opt.batchSize, num_workers=int(opt.nThreads),
+                                                      shuffle=not opt.serial_batches)
+        return self
 
     def load_data(self):
         return self
@@ -62,13 +46,13 @@ class CustomDatasetDataLoader():
         return min(len(self.dataset), self.opt.max_dataset_size)
 
     def __iter__(self):
-        for i, batch in enumerate(self.dataloader):
-            if i * self.opt.batchSize >= self.opt.max_dataset_size:
-                break
+        seen = 0
+        for batch in self.dataloader:
+            if seen >= self.opt.max_dataset_size:
+                return
+            seen += self.opt.batchSize
             yield batch
 
 
 def CreateDataLoader(opt):
-    loader = CustomDatasetDataLoader()
-    loader.initialize(opt)
-    return loader
+    return CustomDatasetDataLoader().initialize(opt)

@@ -51,6 +51,15 @@ def shard_batch(t, rank=None, world=None):
     return t[rank * per:(rank + 1) * per]
 
 
+def shard_dict(batch, world=None, rank=None):
+    """shard_batch over every entry of a loader batch (tensors and per-sample lists alike)."""
+    if world is None:
+        world, rank = (dist.get_world_size(), dist.get_rank()) if is_distributed() else (1, 0)
+    if world == 1:
+        return batch
+    return {k: shard_batch(v, rank, world) for k, v in batch.items()}
+
+
 def allreduce_mean_(flat):
     """In-place average of a flat gradient buffer over all ranks."""
     if not is_distributed():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Training driver with the reference's command line (train.py:9-61): parse options, build the
-loader and the model, run the epoch/iteration loop with the same print/save cadence and the same
-`time` / `data` log fields, plain-text loss log instead of visdom/HTML (those deps are absent).
+"""Training driver with the reference's command line and cadence (reference train.py:9-61): same options, same
+print / save frequencies, the same `time` and `data` fields in the loss line; a plain-text loss log replaces the
+visdom / HTML visualiser (those dependencies do not exist here).
 
     python train.py --dataroot synthetic --model wsgan_emb --which_model_netG resnet_9blocks \
         --which_model_netD n_layers --n_layers_D 3 --batchSize 32 --pretrained_model_path_E E.pth ...
@@ -11,74 +11,73 @@ import math
 import os
 import time
 
-import torch
-
-from pcgan_amd.options.train_options import TrainOptions
 from pcgan_amd.data import CreateDataLoader
-from pcgan_amd.models import create_model
 from pcgan_amd.hip import parallel
+from pcgan_amd.models import create_model
+from pcgan_amd.options.train_options import TrainOptions
 
 
-def shard(data, world, rank):
-    """this rank's contiguous slice of the global batch (DataParallel's scatter)"""
-    if world == 1:
-        return data
-    out = {}
-    for k, v in data.items():
-        n = v.shape[0] if isinstance(v, torch.Tensor) else len(v)
-        per = n // world
-        out[k] = v[rank * per:(rank + 1) * per]
-    return out
+class LossLog(object):
+    """rank 0 prints the loss line and appends it to <checkpoints_dir>/<name>/loss_log.txt"""
+
+    def __init__(self, opt, rank):
+        self.path = os.path.join(opt.checkpoints_dir, opt.name, 'loss_log.txt')
+        self.active = rank == 0
+        self.write('================ Training Loss (%s) ================' % time.strftime('%c'), echo=False)
+
+    def write(self, line, echo=True):
+        if not self.active:
+            return
+        if echo:
+            print(line)
+        with open(self.path, 'a') as f:
+            f.write(line + '\n')
+
+
+def train_epoch(epoch, batches, model, opt, log, counters, world, rank):
+    t_epoch = time.time()
+    t_after_prev = time.time()
+    in_epoch = 0
+    for batch in batches:
+        t_iter = time.time()
+        t_data = t_iter - t_after_prev                    # time spent waiting for the loader
+        model.set_input(parallel.shard_dict(batch, world, rank))
+        model.optimize_parameters()
+        counters['total'] += 1
+        in_epoch += 1
+        n = counters['total']
+        if n % opt.display_freq == 0:
+            model.get_current_visuals()                   # runs G on the fixed ratings in train mode, like the reference
+        if n % opt.print_freq == 0:
+            per_image = (time.time() - t_iter) / opt.batchSize
+            fields = ' '.join('%s: %.3f' % kv for kv in model.get_current_losses().items())
+            log.write('(epoch: %d, iters: %d, time: %.3f, data: %.3f) %s' % (epoch, in_epoch, per_image, t_data, fields))
+        if n % opt.save_latest_freq == 0:
+            print('saving the latest model (epoch %d, total_iter %d)' % (epoch, n))
+            model.save_networks('latest')
+        t_after_prev = time.time()
+    if epoch % opt.save_epoch_freq == 0:
+        print('saving the model at the end of epoch %d, iters %d' % (epoch, counters['total']))
+        model.save_networks('latest')
+        model.save_networks(epoch)
+    print('End of epoch %d / %d \t Time Taken: %d sec' % (epoch, opt.niter + opt.niter_decay, time.time() - t_epoch))
+
+
+def main():
+    world, rank, _ = parallel.init_process_group()
+    opt = TrainOptions().parse()
+    loader = CreateDataLoader(opt)
+    batches = loader.load_data()
+    print('#training images = %d' % len(loader))
+    opt.num_iter_per_epoch = math.ceil(len(loader) / opt.batchSize)
+    model = create_model(opt)
+    model.setup(opt)
+    log = LossLog(opt, rank)
+    counters = {'total': 0}
+    for epoch in range(opt.epoch_count, opt.niter + opt.niter_decay + 1):
+        train_epoch(epoch, batches, model, opt, log, counters, world, rank)
+        model.update_learning_rate()
 
 
 if __name__ == '__main__':
-    world, rank, local = parallel.init_process_group()
-    opt = TrainOptions().parse()
-    data_loader = CreateDataLoader(opt)
-    dataset = data_loader.load_data()
-    dataset_size = len(data_loader)
-    print('#training images = %d' % dataset_size)
-    total_iter = 0
-    num_iter_per_epoch = math.ceil(dataset_size / opt.batchSize)
-    opt.num_iter_per_epoch = num_iter_per_epoch
-    model = create_model(opt)
-    model.setup(opt)
-    log_path = os.path.join(opt.checkpoints_dir, opt.name, 'loss_log.txt')
-    if rank == 0:
-        with open(log_path, 'a') as f:
-            f.write('================ Training Loss (%s) ================\n' % time.strftime('%c'))
-
-    for epoch in range(opt.epoch_count, opt.niter + opt.niter_decay + 1):
-        epoch_start_time = time.time()
-        iter_data_time = time.time()
-        epoch_iter = 0
-        for i, data in enumerate(dataset):
-            iter_start_time = time.time()
-            if total_iter % opt.print_freq == 0:
-                t_data = iter_start_time - iter_data_time
-            model.set_input(shard(data, world, rank))
-            model.optimize_parameters()
-            total_iter += 1
-            epoch_iter += 1
-            if total_iter % opt.display_freq == 0:
-                model.get_current_visuals()      # runs G on the fixed ratings like the reference (train mode)
-            if total_iter % opt.print_freq == 0:
-                losses = model.get_current_losses()
-                t = (time.time() - iter_start_time) / opt.batchSize
-                msg = '(epoch: %d, iters: %d, time: %.3f, data: %.3f) ' % (epoch, epoch_iter, t, t_data)
-                msg += ' '.join('%s: %.3f' % kv for kv in losses.items())
-                if rank == 0:
-                    print(msg)
-                    with open(log_path, 'a') as f:
-                        f.write(msg + '\n')
-            if total_iter % opt.save_latest_freq == 0:
-                print('saving the latest model (epoch %d, total_iter %d)' % (epoch, total_iter))
-                model.save_networks('latest')
-            iter_data_time = time.time()
-        if epoch % opt.save_epoch_freq == 0:
-            print('saving the model at the end of epoch %d, iters %d' % (epoch, total_iter))
-            model.save_networks('latest')
-            model.save_networks(epoch)
-        print('End of epoch %d / %d \t Time Taken: %d sec' % (epoch, opt.niter + opt.niter_decay,
-                                                              time.time() - epoch_start_time))
-        model.update_learning_rate()
+    main()
