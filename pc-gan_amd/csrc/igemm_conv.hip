@@ -890,9 +890,13 @@ __global__ void __launch_bounds__(256) smallm_strip_kernel(IgemmArgs a) {
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
     const int nS = P.nS;
-    const int cpw = (a.Cg + 3) >> 2;
-    const int c_lo = wave * cpw;
-    const int c_hi = (c_lo + cpw < a.Cg) ? c_lo + cpw : a.Cg;
+    // channels: split over blockIdx.z (few-strip launches, partial sums reduced by splitk_reduce_kernel), then over waves
+    const int cps = a.ksplit > 1 ? (a.Cg + a.ksplit - 1) / a.ksplit : a.Cg;
+    const int cz0 = (int)blockIdx.z * cps;
+    const int cz1 = cz0 + cps < a.Cg ? cz0 + cps : a.Cg;
+    const int cpw = (cz1 - cz0 + 3) >> 2;
+    const int c_lo = cz0 + wave * cpw;
+    const int c_hi = (c_lo + cpw < cz1) ? c_lo + cpw : cz1;
     float acc[MO][PX];
 #pragma unroll
     for (int m = 0; m < MO; ++m)
@@ -962,11 +966,15 @@ __global__ void __launch_bounds__(256) smallm_strip_kernel(IgemmArgs a) {
     for (int j = 0; j < PX; ++j) {
         if (sy0 + j >= P.Hs) break;
         const int py = (sy0 + j) * a.ostep + P.fy;
-        float* Yp = a.Y + (size_t)n * a.M * YhYw + py * a.Yw + px;
+        float* Yp = (a.ksplit > 1 ? a.Ypart + (size_t)blockIdx.z * a.N * a.M * YhYw : a.Y) + (size_t)n * a.M * YhYw + py * a.Yw + px;
 #pragma unroll
         for (int m = 0; m < MO; ++m) {
             if (m < a.M) {
                 float v = acc[m][j] + (red[0][m * PX + j][pl] + red[1][m * PX + j][pl]) + red[2][m * PX + j][pl];
+                if (a.ksplit > 1) {   // raw partial sum; bias / activation happen in splitk_reduce_kernel
+                    Yp[(size_t)m * YhYw] = v;
+                    continue;
+                }
                 if (a.bias) v += a.bias[m];
                 Yp[(size_t)m * YhYw] = act_apply(v, a.act, a.slope);
             }
@@ -1774,13 +1782,32 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
             constexpr int SMODE = MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE;
             const bool unit = SMODE == MODE_BWD || (a.sl == 0 && a.ostep == 1);
             static const bool no_strip = getenv("PCGAN_NO_STRIP") != nullptr;   // A/B experiments
-            if (unit && maxR >= 3 && maxR <= 7 && minH >= 16 && !no_strip) {   // (1-2 row taps: nothing to reuse)
-                const dim3 gs((unsigned)((maxstrips + 63) / 64), (unsigned)a.nphase);
+            if (unit && maxR >= 3 && maxR <= 7 && minH >= 8 && !no_strip) {   // (1-2 row taps: nothing to reuse)
+                // few strips but many channels (the last PatchGAN conv, 512 -> 1 on 14x14): cut the channels over blockIdx.z
+                const int wgs = ((maxstrips + 63) / 64) * a.nphase;
+                int ks = 1;
+                const size_t out_elems = (size_t)a.N * a.M * a.Yh * a.Yw;
+                if (part_ws != nullptr && a.nphase == 1 && wgs < 128 && a.Cg >= 64) {
+                    ks = 256 / wgs;
+                    if (ks > 8) ks = 8;
+                    if (ks > a.Cg / 16) ks = a.Cg / 16;
+                    if ((size_t)ks * out_elems * 4 > part_bytes) ks = 1;
+                }
+                a.ksplit = ks;
+                a.Ypart = part_ws;
+                const dim3 gs((unsigned)((maxstrips + 63) / 64), (unsigned)a.nphase, (unsigned)ks);
 #define LS(NRV) do { if (a.M <= 3) hipLaunchKernelGGL((smallm_strip_kernel<SMODE, NRV, 3>), gs, dim3(256), 0, st, a); \
                      else hipLaunchKernelGGL((smallm_strip_kernel<SMODE, NRV, 4>), gs, dim3(256), 0, st, a); } while (0)
                 if (maxR <= 4) LS(4); else LS(7);
 #undef LS
                 PCGAN_LAUNCH_CHECK();
+                if (ks > 1) {
+                    size_t b = (out_elems / 4 + 255) / 256;
+                    b = b > 4096 ? 4096 : (b < 1 ? 1 : b);
+                    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, (const float*)part_ws, a.Y, a.bias,
+                                       ks, out_elems, a.M, a.Yh * a.Yw, a.act, a.slope);
+                    PCGAN_LAUNCH_CHECK();
+                }
                 return 0;
             }
         }
@@ -1902,6 +1929,7 @@ using namespace pcgan;
 // room for split-K partial sums (upper bound: 8 splits), 0 when the problem never splits
 static size_t fwd_part_bytes(const pcgan_conv_desc* d) {
     const int ptot = d->N * d->P * d->Q;
+    if (d->K <= 4) return (ptot <= 65536 && d->C >= 64) ? align_up((size_t)8 * d->K * ptot * 4, 256) : 0;   // strip kernel, channel split
     return may_split(d->K, ptot, 1) ? align_up((size_t)8 * d->N * d->K * d->P * d->Q * 4, 256) : 0;
 }
 static size_t bwd_part_bytes(const pcgan_conv_desc* d) {
