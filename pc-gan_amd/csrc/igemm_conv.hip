@@ -1183,6 +1183,47 @@ __global__ void repack_bwd_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
+// all phases / row classes of one data-gradient weight pack in ONE launch (blockIdx.y = entry): these kernels are
+// launch-latency bound (a few microseconds each, up to 16 per layer)
+struct PackBwdArgs {
+    const float* w;
+    int K, C, Kgp, R, S, tstep, chunked, n;
+    struct Entry {
+        float* A;
+        int r0, s0, nR, nS, fold;
+    } e[16];
+};
+__global__ void repack_bwd_multi_kernel(PackBwdArgs a) {
+    const PackBwdArgs::Entry& E = a.e[blockIdx.y];
+    const int RS = E.nR * E.nS;
+    const int Kp = RS * a.Kgp;
+    const size_t total = (size_t)a.C * Kp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / Kp);
+        const int j = (int)(i - (size_t)c * Kp);
+        int t, k;
+        if (a.chunked) {
+            const int t2 = j >> 4;
+            const int kc = t2 / RS;
+            t = t2 - kc * RS;
+            k = kc * 16 + (j & 15);
+        } else {
+            t = j / a.Kgp;
+            k = j - t * a.Kgp;
+        }
+        const int ri = t / E.nS, sj = t - ri * E.nS;
+        const int r = E.r0 + ri * a.tstep, sx = E.s0 + sj * a.tstep;
+        float v = 0.f;
+        if (k < a.K) {
+            const float* wk = a.w + ((size_t)k * a.C + c) * a.R * a.S;
+            v = wk[r * a.S + sx];
+            if (E.fold == 1 && r == a.R - 1) v += wk[sx];                       // see repack_bwd_kernel
+            if (E.fold == 2 && r == 0) v += wk[(a.R - 1) * a.S + sx];
+        }
+        E.A[i] = v;
+    }
+}
+
 // fold the gradient of a reflection-padded tensor back onto the unpadded tensor
 __global__ void reflect_fold_kernel(const float* __restrict__ t, float* __restrict__ dx, int NC, int H, int W,
                                     int pad) {
@@ -2078,14 +2119,12 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     if (rowfold) {
         // three row classes with their own weights: rows without a mirror image | row 1 | row H-2
         const size_t total = (size_t)d->C * RS * Kgp;
-        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        PackBwdArgs pk;
+        memset(&pk, 0, sizeof(pk));
+        pk.w = w; pk.K = d->K; pk.C = d->C; pk.Kgp = Kgp; pk.R = d->R; pk.S = d->S; pk.tstep = 1; pk.chunked = 1; pk.n = 3;
         for (int f = 0; f < 3; ++f) {
             float* A = Abase + (size_t)f * total;
-            if (do_pack) {
-                hipLaunchKernelGGL(repack_bwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Kgp, d->R, d->S, 0, 0,
-                                   1, d->R, d->S, 1, f);
-                PCGAN_LAUNCH_CHECK();
-            }
+            pk.e[f].A = A; pk.e[f].r0 = 0; pk.e[f].s0 = 0; pk.e[f].nR = d->R; pk.e[f].nS = d->S; pk.e[f].fold = f;
             PhaseArgs& p = a.ph[a.nphase++];
             p.A = A; p.Kp = RS * Kgp; p.Ws = W; p.fx = 0; p.r0 = 0; p.s0 = 0; p.nR = d->R; p.nS = d->S;
             p.Hs = f == 0 ? H - 2 : 1;
@@ -2093,13 +2132,21 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
             p.ymap = f == 0 ? 1 : 0;
             p.Ptot = d->N * p.Hs * W;
         }
+        if (do_pack) {
+            const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+            hipLaunchKernelGGL(repack_bwd_multi_kernel, dim3(blocks, 3), dim3(256), 0, st, pk);
+            PCGAN_LAUNCH_CHECK();
+        }
         if (pack_only) return 0;
         return launch_igemm<MODE_BWD_REFLECT>(a, st, nullptr, 0);
     }
 
     // one phase per (iy % stride, ix % stride): only the taps that are structurally non-zero for it
     bool need_zero = false;
-    size_t a_off = 0;
+    size_t a_off = 0, max_total = 0;
+    PackBwdArgs pk;
+    memset(&pk, 0, sizeof(pk));
+    pk.w = w; pk.K = d->K; pk.C = d->C; pk.Kgp = Kgp; pk.R = d->R; pk.S = d->S; pk.tstep = stv; pk.chunked = (int)chunked;
     for (int fy = 0; fy < stv; ++fy) {
         for (int fx = 0; fx < stv; ++fx) {
             const int r0 = (fy + pad) % stv, s0 = (fx + pad) % stv;
@@ -2115,8 +2162,12 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
             float* A = Abase + a_off;
             const size_t total = (size_t)d->C * nR * nS * Kgp;
             a_off += total;
-            const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-            if (do_pack) {
+            if (!smallm) {   // packed together after the loop; the small-M layouts below are derived from A right away
+                max_total = total > max_total ? total : max_total;
+                PackBwdArgs::Entry& pe = pk.e[pk.n++];
+                pe.A = A; pe.r0 = r0; pe.s0 = s0; pe.nR = nR; pe.nS = nS; pe.fold = 0;
+            } else if (do_pack) {
+                const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
                 hipLaunchKernelGGL(repack_bwd_kernel, dim3(blocks), dim3(256), 0, st, w, A, d->K, d->C, Kgp, d->R,
                                    d->S, r0, s0, stv, nR, nS, (int)chunked, 0);
                 PCGAN_LAUNCH_CHECK();
@@ -2141,6 +2192,11 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
             }
             p.r0 = r0; p.s0 = s0; p.nR = nR; p.nS = nS; p.Ptot = d->N * Hs * Ws;
         }
+    }
+    if (do_pack && pk.n > 0) {
+        const int blocks = (int)((max_total + 255) / 256 > 2048 ? 2048 : (max_total + 255) / 256);
+        hipLaunchKernelGGL(repack_bwd_multi_kernel, dim3(blocks, pk.n), dim3(256), 0, st, pk);
+        PCGAN_LAUNCH_CHECK();
     }
     if (pack_only) return 0;
     if (need_zero) {
