@@ -1472,6 +1472,114 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Weight gradient for <= 3 output channels, stride 1, <= NT x NT taps (the generator head 64 -> 3, 7x7): sliding-window
+// strips like smallm_strip_kernel.  One workgroup = one input channel c and a range of strips; one thread = 8 vertically
+// consecutive output pixels of one column (lanes along the row => coalesced).  The 8 x M values of dY are loaded once per
+// strip; for each filter column the 8 + NT - 1 input values are loaded once and reused by all NT row taps:
+// M * NT * 8 fused multiply-adds per 8 + NT - 1 gathers.  Every thread keeps the NT x NT x M partial sums of ITS pixels in
+// registers; the workgroup reduces them once at the end (wave shuffles, then LDS) and writes Wp[split][m][tap * Cgp + c].
+template <int MODE, int NT>
+__global__ void __launch_bounds__(256) smallm_wgrad_strip_kernel(WgradArgs a) {
+    constexpr int PX = 8, NW = PX + NT - 1, MO = 3;
+    constexpr int SG = NT > 4 ? 4 : NT;     // filter columns per workgroup (blockIdx.z picks the group): keeps the
+                                            // accumulators at SG x NT x 3 registers so that 2-3 waves fit a SIMD
+    __shared__ float red[4][SG * NT * MO];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x;
+    const int s_lo = blockIdx.z * SG;
+    const int R = a.Kp / a.Cgp / a.S;       // taps: R x S
+    const int HoWo = a.Ho * a.Wo, HgWg = a.Hg * a.Wg;
+    const int spc = (a.Ho + PX - 1) / PX;   // strips per column
+    const int nstrips = a.N * spc * a.Wo;
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.dY, a.dy_bytes);
+    float acc[SG][NT][MO];   // [s - s_lo][r][m]
+#pragma unroll
+    for (int sj = 0; sj < SG; ++sj)
+#pragma unroll
+        for (int ri = 0; ri < NT; ++ri)
+#pragma unroll
+            for (int m = 0; m < MO; ++m) acc[sj][ri][m] = 0.f;
+    const int sbeg = blockIdx.y * a.chunks_per_split;      // (strips per split)
+    int send = sbeg + a.chunks_per_split;
+    if (send > nstrips) send = nstrips;
+    for (int sg = sbeg + tid; sg < send; sg += 256) {
+        const int n = sg / (spc * a.Wo);
+        const int rem = sg - n * spc * a.Wo;
+        const int ss = rem / a.Wo;
+        const int ox = rem - ss * a.Wo;
+        const int oy0 = ss * PX;
+        // input rows under the strip
+        unsigned rowoff[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            int iy = oy0 - a.pad + k;
+            if (MODE == MODE_FWD_REFLECT) {
+                iy = iy < 0 ? -iy : iy;
+                iy = iy >= a.Hg ? 2 * (a.Hg - 1) - iy : iy;
+            }
+            rowoff[k] = ((unsigned)iy < (unsigned)a.Hg) ? (unsigned)((n * a.Cg + c) * HgWg + iy * a.Wg) * 4u : SM_INV;
+        }
+        auto col_off = [&](int sj) {
+            int ix = ox - a.pad + s_lo + sj;
+            if (MODE == MODE_FWD_REFLECT) {
+                ix = ix < 0 ? -ix : ix;
+                ix = ix >= a.Wg ? 2 * (a.Wg - 1) - ix : ix;
+            }
+            return (s_lo + sj < a.S && (unsigned)ix < (unsigned)a.Wg) ? (unsigned)ix * 4u : SM_INV;
+        };
+        float xin[2][NW];
+        {
+            const unsigned co = col_off(0);
+#pragma unroll
+            for (int k = 0; k < NW; ++k) xin[0][k] = ld_b32(rX, rowoff[k] + co, 0u);
+        }
+        // dY of the strip (rows past the end: 0)
+        float dyv[MO][PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const unsigned vo = (oy0 + j < a.Ho) ? (unsigned)(n * a.M * HoWo + (oy0 + j) * a.Wo + ox) * 4u : OOB;
+#pragma unroll
+            for (int m = 0; m < MO; ++m) dyv[m][j] = m < a.M ? ld_b32(rY, vo, (unsigned)(m * HoWo) * 4u) : 0.f;
+        }
+#pragma unroll
+        for (int sj = 0; sj < SG; ++sj) {
+            if (sj + 1 < SG) {   // next filter column in flight while this one is consumed
+                const unsigned co = col_off(sj + 1);
+#pragma unroll
+                for (int k = 0; k < NW; ++k) xin[(sj + 1) & 1][k] = ld_b32(rX, rowoff[k] + co, 0u);
+            }
+#pragma unroll
+            for (int ri = 0; ri < NT; ++ri)
+#pragma unroll
+                for (int j = 0; j < PX; ++j)
+#pragma unroll
+                    for (int m = 0; m < MO; ++m) acc[sj][ri][m] += dyv[m][j] * xin[sj & 1][j + ri];
+        }
+    }
+    // workgroup reduction: 6 shuffle steps inside each wave, then the 4 waves through LDS
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int sj = 0; sj < SG; ++sj)
+#pragma unroll
+        for (int ri = 0; ri < NT; ++ri)
+#pragma unroll
+            for (int m = 0; m < MO; ++m) {
+                float v = acc[sj][ri][m];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0) red[wave][(sj * NT + ri) * MO + m] = v;
+            }
+    __syncthreads();
+    if (tid < SG * NT * MO) {
+        const int m = tid % MO, ri = (tid / MO) % NT, sj = s_lo + tid / (MO * NT);
+        if (m < a.M && ri < R && sj < a.S) {
+            const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            a.Wp[((size_t)blockIdx.y * a.M + m) * a.Kp + (ri * a.S + sj) * a.Cgp + c] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Weight gradient, pipelined version for tap-aligned K tiles (padded channel count a multiple of 128, or 64):
 // same recipe as igemm2_kernel -- few non-scalar instructions per matrix instruction, every wait long after its
@@ -1910,8 +2018,23 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
 
 static inline bool smallm_wgrad(const pcgan_conv_desc* d) { return d->K <= 4 && (round4(d->C) % 16) == 0; }
 
+// strip weight-gradient kernel: <= 3 output channels, stride 1, <= 7x7 taps, columns long enough for 8-pixel strips
+static inline bool smallm_wgrad_strip(const pcgan_conv_desc* d) {
+    static const bool off = getenv("PCGAN_NO_STRIP") != nullptr;
+    return !off && d->K <= 3 && d->stride == 1 && d->R <= 7 && d->S <= 7 && d->R >= 3 && d->P >= 16 && d->C >= 16;
+}
+
 static int wgrad_splits(const pcgan_conv_desc* d, int* chunks_per_split) {
     const int Cgp = round4(d->C);
+    if (smallm_wgrad_strip(d)) {   // one workgroup per input channel and strip range; ~2048 workgroups, >= 4 strips per thread
+        const int nstrips = d->N * ((d->P + 7) / 8) * d->Q;
+        int splits = 1024 / d->C;
+        if (splits > nstrips / 1024) splits = nstrips / 1024;
+        if (splits < 1) splits = 1;
+        const int sps = (nstrips + splits - 1) / splits;
+        *chunks_per_split = sps;
+        return (nstrips + sps - 1) / sps;
+    }
     const int Kp = d->R * d->S * Cgp;
     if (smallm_wgrad(d)) {  // one workgroup per 16 K-columns and pixel split; aim at ~2048 workgroups
         const int chunks = (d->N * d->P * d->Q + 31) / 32;
@@ -2268,6 +2391,20 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
     a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
     a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * 4);
     const int splits = wgrad_splits(d, &a.chunks_per_split);
+    if (smallm_wgrad_strip(d)) {
+        const dim3 sgrid((unsigned)d->C, (unsigned)splits, (unsigned)((d->R <= 4 && d->S <= 4) ? 1 : (d->S + 3) / 4));
+#define LWS(MODE) do { if (d->R <= 4 && d->S <= 4) hipLaunchKernelGGL((smallm_wgrad_strip_kernel<MODE, 4>), sgrid, dim3(256), 0, st, a); \
+                       else hipLaunchKernelGGL((smallm_wgrad_strip_kernel<MODE, 7>), sgrid, dim3(256), 0, st, a); } while (0)
+        if (d->pad_mode == 1) LWS(MODE_FWD_REFLECT); else LWS(MODE_FWD_ZERO);
+#undef LWS
+        PCGAN_LAUNCH_CHECK();
+        const size_t total = (size_t)d->K * RS * Cgp;
+        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, d->K, d->C,
+                           Cgp, RS, accumulate);
+        PCGAN_LAUNCH_CHECK();
+        return 0;
+    }
     if (smallm_wgrad(d)) {
         const dim3 sgrid((unsigned)(a.Kp / 16), (unsigned)splits);
         if (d->pad_mode == 1) hipLaunchKernelGGL((smallm_wgrad_kernel<MODE_FWD_REFLECT>), sgrid, dim3(256), 0, st, a);
