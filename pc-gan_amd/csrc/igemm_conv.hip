@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
 // written to LDS but never consumed.  Source order in the loop IS the issue order (sched_barrier(0) per slot).
 static constexpr int NTAP_FWD = 25;   // filter taps the offset table holds (5x5)
 static constexpr int NTAP_MIR = 9;    // ... for the fused reflect data gradient (4 source combinations)
+static constexpr int NTAP_CG4 = 49;   // ... for 3-/4-channel tensors (7x7 stems)
 
 // index along one axis of the gathered tensor for filter tap `tap`, or 0xffffffff if the tap falls outside.
 // Forward modes: p = output coordinate.  Backward modes: base = p + pad (or the padded-grid index of the mirror
@@ -391,7 +392,9 @@ __device__ __forceinline__ void pix_coord(const IgemmArgs& a, const PhaseArgs& P
     px = (rem - sy * P.Ws) * a.ostep + P.fx;
 }
 
-template <int MODE, int BM, int BP>
+// CPS = channels per K stage: 16 (chunked order, channel count a multiple of 16) or 4 (image-like tensors of 3-4 channels,
+// K order (tap, channel) with the channels padded to 4: one stage = 4 filter taps x 4 channels, up to 7x7 taps).
+template <int MODE, int BM, int BP, int CPS = 16>
 __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
     constexpr int WM = (BM == 128 || (BM == 64 && BP == 64)) ? 2 : 1;
     constexpr int WP = 4 / WM;
@@ -401,7 +404,8 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
     constexpr int KPT = BP / 16;
     constexpr int ACH = (BM * 4 + 255) / 256;
     constexpr bool MIR = MODE == MODE_BWD_REFLECT;
-    constexpr int TROWS = (MIR ? NTAP_MIR : NTAP_FWD) + 1;   // + one all-out-of-range row for dead stages
+    static_assert(CPS == 16 || (CPS == 4 && !MIR), "4-channel stages: forward and plain data gradient only");
+    constexpr int TROWS = (MIR ? NTAP_MIR : (CPS == 4 ? NTAP_CG4 : NTAP_FWD)) + 1;   // + one all-out-of-range row for dead stages
     constexpr int NCOMB = MIR ? 4 : 1;
     __shared__ __attribute__((aligned(16))) float As[2][BM * AP];
     __shared__ __attribute__((aligned(16))) float Bs[2][4 * BP * 4];
@@ -463,19 +467,22 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
     }
     const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);
 
-    const int nst_all = Kp >> 4;
+    const int nst_all = (Kp + 15) >> 4;
     const int nst_per = a.ksplit > 1 ? (nst_all + a.ksplit - 1) / a.ksplit : nst_all;
     const int st_begin = a.ksplit > 1 ? (int)blockIdx.z * nst_per : 0;
     const int st_end = st_begin + nst_per < nst_all ? st_begin + nst_per : nst_all;
 
     // load-side iterator (scalar; runs two stages ahead of the MFMA chain)
     int it_c, it_tap, it_k0;
-    {
+    if (CPS == 4) {
+        it_tap = st_begin * 4;
+        it_c = 0;
+    } else {
         const int cc0 = st_begin / T;
         it_tap = st_begin - cc0 * T;
         it_c = cc0 * 16;
-        it_k0 = st_begin * 16;
     }
+    it_k0 = st_begin * 16;
     unsigned a_base[ACH];
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
@@ -488,11 +495,21 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
     float breg[KPT];
     float bmir[MIR ? 3 : 1][MIR ? KPT : 1];
     unsigned vo[NCOMB];          // gather offsets of the next load (bit 31 = out of range)
+    unsigned vo_b = OOB;         // CPS 4, BP 128: offset of this thread's second filter tap
     int vo_c = 0, vo_k0 = 0;     // channel chunk / A column of the stage `vo` belongs to
 
     // offset-table read for the stage the iterator points at + iterator advance
     auto next_offsets = [&](auto nm_tag) {
         constexpr int NM = decltype(nm_tag)::value;
+        if constexpr (CPS == 4) {   // this thread's KPT K-slots = KPT / 4 consecutive taps x 4 channels
+            const int tA = it_tap + ksub * (KPT / 4);
+            vo[0] = offT[0][tA < T ? tA : T][pl];
+            if (KPT == 8) vo_b = offT[0][tA + 1 < T ? tA + 1 : T][pl];
+            vo_k0 = it_k0;
+            it_tap += 4;
+            it_k0 += 16;
+            return;
+        }
         const int row = it_c >= a.Cg ? T : it_tap;     // stage past the end of K: the all-out-of-range row
         const unsigned* tp = &offT[0][0][pl] + row * BP;
         vo[0] = tp[0];
@@ -512,6 +529,11 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
     auto load_a = [&](int j) { areg[j] = ld_b128s(rA, a_base[j], (unsigned)vo_k0 * 4u); };
     auto load_b = [&](int i, auto nm_tag) {
         constexpr int NM = decltype(nm_tag)::value;
+        if constexpr (CPS == 4) {
+            const unsigned v = (i & 3) < a.Cg ? (i < 4 ? vo[0] : vo_b) : OOB;   // 3-channel tensors: the pad channel reads 0
+            breg[i] = ld_b32(rX, v, (unsigned)((i & 3) * HgWg4));
+            return;
+        }
         const unsigned so = (unsigned)((vo_c + ksub * KPT + i) * HgWg4);
         breg[i] = ld_b32(rX, vo[0], so);
         if constexpr (NM >= 1) bmir[0][i] = ld_b32(rX, vo[NCOMB > 1 ? 1 : 0], so);
@@ -1873,6 +1895,9 @@ static int check_desc(const pcgan_conv_desc* d) {
 // and are cut along K instead (split-K, partial sums reduced by splitk_reduce_kernel)
 // chunked K order / igemm2_kernel: gathered channel count a multiple of 16, taps fit the LDS tables, MFMA path
 static inline bool chunked_k(int Cg, int M, int R, int S) { return (Cg % 16) == 0 && M > 4 && R * S <= NTAP_FWD; }
+// 4-channel stages (igemm2_kernel<.., 4>): 3-/4-channel gathered tensor, MFMA path, taps fit the table; weights stay in
+// the generic (tap, channel) order
+static inline bool cg4_k(int Cg, int M, int R, int S) { return round4(Cg) == 4 && M > 4 && R * S <= NTAP_CG4; }
 static inline long tile_blocks(int M, int ptot_max, int nphase, int mm, int pp) {
     return (long)((M + mm - 1) / mm) * ((ptot_max + pp - 1) / pp) * nphase;
 }
@@ -1985,8 +2010,13 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
     a.tstart[0] = 0;
     for (int i = 0; i < a.nphase; ++i) a.tstart[i + 1] = a.tstart[i] + (a.ph[i].Ptot + bp - 1) / bp;
     const dim3 grid2((unsigned)(((a.M + bm - 1) / bm) * a.tstart[a.nphase]), 1u, (unsigned)ks);
-    const bool cg16 = a.chunked != 0;
+    const bool cg16 = a.chunked == 1, cg4 = a.chunked == 2;
     PCGAN_CHECK(cg16 || MODE != MODE_BWD_REFLECT, "igemm: fused reflect data-gradient needs K %% 16 == 0");
+    if (cg4) {
+        PCGAN_CHECK(a.Cgp == 4, "igemm: 4-channel stages need a 3-/4-channel tensor");
+        for (int i = 0; i < a.nphase; ++i)
+            PCGAN_CHECK(a.ph[i].nR * a.ph[i].nS <= NTAP_CG4, "igemm: 4-channel stages: more than %d taps", NTAP_CG4);
+    }
     if (cg16) {
         PCGAN_CHECK((a.Cg % 16) == 0, "igemm: chunked K order needs a multiple of 16 channels");
         for (int i = 0; i < a.nphase; ++i)
@@ -1996,6 +2026,7 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
 #define LI(BMV, BPV)                                                                                   \
     do {                                                                                               \
         if (cg16) hipLaunchKernelGGL((igemm2_kernel<MODE, BMV, BPV>), grid2, dim3(256), 0, st, a);      \
+        else if (cg4) hipLaunchKernelGGL((igemm2_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV, 4>), grid2, dim3(256), 0, st, a); \
         else hipLaunchKernelGGL((igemm_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV>), grid, dim3(256), 0, st, a); \
     } while (0)
     if (bm == 128 && bp == 128) LI(128, 128);
@@ -2173,7 +2204,7 @@ static int conv2d_fwd_impl(const pcgan_conv_desc* d, const float* x, const float
     a.act = act; a.slope = slope;
     a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
     a.nphase = 1;
-    a.chunked = chunked_k(d->C, d->K, d->R, d->S);
+    a.chunked = chunked_k(d->C, d->K, d->R, d->S) ? 1 : (cg4_k(d->C, d->K, d->R, d->S) ? 2 : 0);
     PhaseArgs& p = a.ph[0];
     p.A = A; p.Kp = RS * Cgp; p.Hs = d->P; p.Ws = d->Q; p.fy = 0; p.fx = 0;
     if (d->K <= 4) {  // small-M path reads the weights as [k][4] / [c][ri][8][4]
@@ -2235,7 +2266,7 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     a.Yh = H; a.Yw = W;
     a.ostep = stv; a.sl = ilog2_exact(stv); a.pad = pad; a.tstep = stv;
     a.act = PCGAN_ACT_NONE; a.slope = 0.f;
-    a.chunked = chunked;
+    a.chunked = chunked ? 1 : (cg4_k(d->K, d->C, d->R, d->S) ? 2 : 0);
     a.rowfold = rowfold;
     a.x_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * 4);
 
