@@ -1897,7 +1897,10 @@ static int check_desc(const pcgan_conv_desc* d) {
 static inline bool chunked_k(int Cg, int M, int R, int S) { return (Cg % 16) == 0 && M > 4 && R * S <= NTAP_FWD; }
 // 4-channel stages (igemm2_kernel<.., 4>): 3-/4-channel gathered tensor, MFMA path, taps fit the table; weights stay in
 // the generic (tap, channel) order
-static inline bool cg4_k(int Cg, int M, int R, int S) { return round4(Cg) == 4 && M > 4 && R * S <= NTAP_CG4; }
+static inline bool cg4_k(int Cg, int M, int R, int S) {
+    static const bool off = getenv("PCGAN_NO_CG4") != nullptr;   // A/B experiments
+    return !off && round4(Cg) == 4 && M > 4 && R * S <= NTAP_CG4;
+}
 static inline long tile_blocks(int M, int ptot_max, int nphase, int mm, int pp) {
     return (long)((M + mm - 1) / mm) * ((ptot_max + pp - 1) / pp) * nphase;
 }
