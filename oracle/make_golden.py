@@ -265,6 +265,40 @@ def golden_cycle_step(rn, outdir):
     print('cycle_step.npz: %d arrays, losses it0 %s' % (len(out), out['it0/losses']))
 
 
+def golden_siamese(rn, outdir):
+    """Elo-encoder trainer: three Adam steps of the reference's SiameseNetwork (ResNet-18 trunk, head
+    [32, 1], average pooling) on seeded pairs.  siamese.py itself cannot be imported (torchvision / cv2 / tqdm at module
+    top) and BinaryNLLLoss.__init__ calls .cuda(): the loss expression (networks.py:479-481) is applied here in place."""
+    base = rn.ResNetFeature(3, 'resnet18')
+    net = rn.SiameseNetwork(base, pooling='avg', cnn_dim=[32, 1], cnn_pad=1, cnn_relu_slope=0.7, fc_dim=[],
+                            drop_layer=rn.get_dropout_layer(0.0))
+    net.load_state_dict(W.fill_state_dict(net.state_dict(), 61))
+    params = list(net.base.parameters()) + list(net.cnn.parameters())
+    optimizer = torch.optim.Adam(params, lr=2e-4)
+    lut = torch.tensor([0.0, 0.5, 1.0])
+    out = {}
+    for it in range(3):
+        img0 = W.seeded_tensor((4, 3, 64, 64), 900 + it)
+        img1 = W.seeded_tensor((4, 3, 64, 64), 950 + it)
+        label = torch.tensor([[0, 2, 1, 2], [2, 2, 0, 1], [1, 0, 0, 2]][it])
+        optimizer.zero_grad()
+        f1, f2, score = net(img0, img1)
+        prob = torch.sigmoid(score)
+        target = lut[label].reshape(prob.size(0), 1, 1, 1).expand(prob.size(0), 1, prob.size(2), prob.size(3))
+        loss = -(target * torch.log(prob + 1e-20) + (1 - target) * torch.log(1 - prob + 1e-20)).mean()
+        loss.backward()
+        p = 'it%d' % it
+        out[p + '/loss'] = np.array(float(loss))
+        out[p + '/f1'], out[p + '/f2'], out[p + '/prob'] = t2n(f1), t2n(f2), t2n(prob)
+        grads_summary([(k, q.grad) for k, q in net.named_parameters()], p + '/grad', out, False)
+        optimizer.step()
+        for k, v in net.state_dict().items():
+            a = t2n(v).astype(np.float64)
+            out['%s/after/%s' % (p, k)] = np.array([a.sum(), np.abs(a).sum()])
+    np.savez_compressed(os.path.join(outdir, 'siamese_step.npz'), **out)
+    print('siamese_step.npz: %d arrays, losses %s' % (len(out), [float(out['it%d/loss' % i]) for i in range(3)]))
+
+
 def golden_ints(outdir):
     """Integer-exact helpers."""
     from util import util as ref_util
@@ -298,3 +332,5 @@ if __name__ == '__main__':
         golden_steps(rn, a.out)
     if a.only in ('', 'cycle'):
         golden_cycle_step(rn, a.out)
+    if a.only in ('', 'siamese'):
+        golden_siamese(rn, a.out)

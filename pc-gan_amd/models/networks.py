@@ -368,6 +368,59 @@ class SiameseFeature(tnn.Module):
         self.base.load_pretrained(state_dict)
 
 
+class SiameseNetwork(SiameseFeature):
+    """The comparison network the Elo-rating encoder is trained as (reference models/networks.py:872-992): the SAME trunk
+    + conv head as SiameseFeature applied to two images, score = rating(x1) - rating(x2).  Its state_dict (`base.*`,
+    `cnn.*`) is what wsgan_emb consumes as --pretrained_model_path_E.  Configurations of the reference outside the
+    Elo recipe (fully connected comparison head `fc_dim`, `use_cxn`) raise."""
+
+    def __init__(self, base=None, pooling='avg', cnn_dim=[], cnn_pad=1, cnn_relu_slope=0.5, fc_dim=[], fc_relu_slope=0.2,
+                 fc_residual=True, dropout=0.5, use_cxn=False, noisy=False, drop_layer=None, rsample=False):
+        if fc_dim or use_cxn:
+            raise NotImplementedError('pcgan_amd: SiameseNetwork with fc_dim / use_cxn is outside the MI355X hot path')
+        super().__init__(base, pooling=pooling, cnn_dim=cnn_dim, cnn_pad=cnn_pad, cnn_relu_slope=cnn_relu_slope,
+                         noisy=noisy, drop_layer=drop_layer)
+        self._rsample = rsample
+        self.fc = self.cxn = None
+
+    def forward_once(self, x):
+        out = SiameseFeature.forward(self, x)
+        return out if self._noisy else (out, None)
+
+    def forward(self, input1, input2):
+        feature1, logvar1 = self.forward_once(input1)
+        feature2, logvar2 = self.forward_once(input2)
+        if not self._noisy:
+            return feature1, feature2, feature1 - feature2
+        if self._rsample:
+            return feature1, feature2, logvar1, logvar2
+        std = torch.sqrt(torch.exp(logvar1) + torch.exp(logvar2))      # sqrt(std1^2 + std2^2)
+        return feature1, feature2, feature1 - feature2, std
+
+    def load_pretrained(self, state_dict):
+        """only the trunk comes from the pretrained (ImageNet) file: the conv head stays as initialised (:994-997)"""
+        self.base.load_pretrained(state_dict)
+
+    def get_finetune_parameters(self):
+        return list(self.cnn.parameters()) if self.cnn is not None else []
+
+
+class BinaryNLLLoss(tnn.Module):
+    """Binary cross entropy with draws (reference models/networks.py:473-482): label 0 / 1 / 2 = "first lower" / draw /
+    "first higher" -> target 0 / 0.5 / 1; -(t log(p + 1e-20) + (1 - t) log(1 - p + 1e-20)), mean.  (N values: plain
+    tensor arithmetic; the LUT follows the probabilities' device instead of the reference's unconditional .cuda().)"""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer('LUT', torch.tensor([0.0, 0.5, 1.0]), persistent=False)
+
+    def forward(self, prob, label):
+        lut = self.LUT.to(prob.device)
+        target = lut[label].reshape(prob.size(0), 1, 1, 1).expand(prob.size(0), 1, prob.size(2), prob.size(3))
+        loss = -(target * torch.log(prob + 1e-20) + (1 - target) * torch.log(1 - prob + 1e-20))
+        return loss.mean()
+
+
 class ResNetFeature(tnn.Module):
     """reference models/networks.py:1310-1359"""
 

@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Elo-rating encoder trainer on the HIP path (reference siamese.py:41-154, 422-769, `--mode train`).
+
+Trains `networks.SiameseNetwork` (ResNet-18 trunk + 3x3 conv head, global pooling) on image pairs with a three-way
+label (0: first < second, 1: draw, 2: first > second) with the draw-aware binary NLL on sigmoid(rating1 - rating2) and
+Adam; writes `init_net.pth`, `latest_net.pth`, `<epoch>_net.pth` and `loss.txt` under <checkpoint_dir>/<name>/ -- the
+`<epoch>_net.pth` file is what `train.py --model wsgan_emb --pretrained_model_path_E` loads.
+
+Same flag names and defaults as the reference for everything implemented; the deterministic recipe only (`--noisy false
+--bayesian false`, no `fc_dim`, no `use_cxn`); image augmentation is resize + random crop + flip (torchvision's affine /
+colour jitter are not available here); `--dataroot synthetic` trains on seeded synthetic pairs whose label is decided
+by a hidden per-image score, so the loss must fall.
+
+    python siamese.py --dataroot synthetic --name elo --batch_size 32 --num_epochs 2 --pretrained_model_path ''
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 siamese.py ...        # one process per GPU, RCCL
+"""
+import argparse
+import math
+import os
+
+import numpy as np
+import torch
+
+from pcgan_amd.data.base_dataset import get_transform
+from pcgan_amd.hip import parallel
+from pcgan_amd.hip.optim import FusedAdam
+from pcgan_amd.models import networks
+from pcgan_amd.util.util import str2bool
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
+    add = ap.add_argument
+    add('--mode', type=str, default='train')
+    add('--name', type=str, default='exp')
+    add('--dataroot', required=True)
+    add('--datafile', type=str, default='')
+    add('--dataroot_val', type=str, default='')
+    add('--datafile_val', type=str, default='')
+    add('--pretrained_model_path', type=str, default='pretrained_models/resnet18-5c106cde.pth')
+    add('--checkpoint_dir', type=str, default='checkpoints')
+    add('--save_epoch_freq', type=int, default=5)
+    add('--num_workers', type=int, default=4)
+    add('--num_epochs', type=int, default=50)
+    add('--batch_size', type=int, default=100)
+    add('--lr', type=float, default=0.0002)
+    add('--which_model', type=str, default='resnet18')
+    add('--pooling', type=str, default='avg')
+    add('--loadSize', type=int, default=240)
+    add('--fineSize', type=int, default=224)
+    add('--gpu_ids', type=str, default='0')
+    add('--fc_dim', type=int, nargs='*', default=[])
+    add('--cnn_dim', type=int, nargs='*', default=[32, 1])
+    add('--no_cnn', action='store_true')
+    add('--cnn_pad', type=int, default=1)
+    add('--cnn_relu_slope', type=float, default=0.7)
+    add('--use_cxn', action='store_true')
+    add('--finetune_fc_only', action='store_true')
+    add('--print_freq', type=int, default=10)
+    add('--display_id', type=int, default=-1)
+    add('--transforms', type=str, default='resize_and_crop')
+    add('--no_flip', action='store_true')
+    add('--continue_train', action='store_true')
+    add('--which_epoch', type=str, default='latest')
+    add('--epoch_count', type=int, default=1)
+    add('--save_latest_freq', type=int, default=100)
+    add('--serial_batches', action='store_true')
+    add('--draw_prob_thresh', type=float, default=0.16)
+    add('--noisy', type=str2bool, default=False)
+    add('--bayesian', type=str2bool, default=False)
+    add('--bnn_dropout', type=float, default=0.)
+    add('--seed', type=int, default=0)
+    add('--max_dataset_size', type=int, default=1 << 30)
+    return ap
+
+
+class PairDataset(torch.utils.data.Dataset):
+    """lines "<imageA> <imageB> <label>" under --dataroot (reference siamese.py:158-180), or synthetic pairs"""
+
+    def __init__(self, opt, root, listing):
+        self.opt = opt
+        self.root = root
+        self.synthetic = root == 'synthetic'
+        if self.synthetic:
+            self.n = min(opt.max_dataset_size, 64 * opt.batch_size)
+            return
+        with open(listing) as f:
+            self.lines = [line.split() for line in f if line.strip()][:opt.max_dataset_size]
+        self.n = len(self.lines)
+        opt.isTrain = True
+        self.transform = get_transform(opt)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if self.synthetic:
+            g = torch.Generator().manual_seed(9000 + i)
+            s = self.opt.fineSize
+            level = torch.rand(2, generator=g)                                  # the hidden rating: mean brightness
+            imgs = [(torch.rand(3, s, s, generator=g) * 0.5 + level[k] - 0.75) for k in range(2)]
+            d = float(level[0] - level[1])
+            label = 1 if abs(d) < 0.1 else (2 if d > 0 else 0)
+            return imgs[0], imgs[1], torch.tensor(label)
+        from PIL import Image
+        a, b, lab = self.lines[i][:3]
+        A = self.transform(Image.open(os.path.join(self.root, a)).convert('RGB'))
+        B = self.transform(Image.open(os.path.join(self.root, b)).convert('RGB'))
+        return A, B, torch.tensor(int(lab))
+
+
+def init_like_reference(net):
+    """weights_init of the reference (siamese.py:288-296): every conv N(0, 0.02), BatchNorm weight N(1, 0.02), bias 0"""
+    for m in net.modules():
+        kind = m.__class__.__name__
+        if 'Conv' in kind:
+            m.weight.data.normal_(0.0, 0.02)
+        elif 'BatchNorm2d' in kind:
+            m.weight.data.normal_(1.0, 0.02)
+            m.bias.data.fill_(0)
+
+
+def build_net(opt, device):
+    if 'resnet' not in opt.which_model:
+        raise NotImplementedError('pcgan_amd: rating trunk [%s] is outside the MI355X hot path' % opt.which_model)
+    if opt.noisy or opt.bayesian or opt.finetune_fc_only:
+        raise NotImplementedError('pcgan_amd: siamese.py implements the deterministic Elo recipe (no --noisy / --bayesian / '
+                                  '--finetune_fc_only)')
+    base = networks.ResNetFeature(input_nc=3, which_model=opt.which_model, dropout=opt.bnn_dropout)
+    net = networks.SiameseNetwork(base, pooling=opt.pooling, cnn_dim=[] if opt.no_cnn else opt.cnn_dim, cnn_pad=opt.cnn_pad,
+                                  cnn_relu_slope=opt.cnn_relu_slope, fc_dim=opt.fc_dim, use_cxn=opt.use_cxn)
+    save_dir = os.path.join(opt.checkpoint_dir, opt.name)
+    if opt.continue_train:
+        net.load_state_dict(torch.load(os.path.join(save_dir, '%s_net.pth' % opt.which_epoch), map_location='cpu'), strict=False)
+    else:
+        init_like_reference(net)
+        if opt.pretrained_model_path:
+            net.load_pretrained(opt.pretrained_model_path)
+    return net.to(device)
+
+
+def predictions(prob, draw_thresh):
+    """0 / 1 / 2 per pair from P(first > second) (reference siamese.py:323-331 on (N,1,1,1) probabilities)"""
+    p = prob.detach().reshape(prob.size(0), -1)[:, 0]
+    draw = (0.5 - p).abs() < draw_thresh
+    return torch.where(draw, torch.ones_like(p), torch.where(p > 0.5, torch.full_like(p, 2.0), torch.zeros_like(p))).long()
+
+
+def save(net, path):
+    if not parallel.is_distributed() or torch.distributed.get_rank() == 0:
+        torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, path)
+
+
+def train(opt):
+    world, rank, local = parallel.init_process_group()
+    torch.manual_seed(opt.seed)
+    gpu = int(opt.gpu_ids.split(',')[0])
+    if gpu < 0 or not torch.cuda.is_available():
+        raise RuntimeError('pcgan_amd: siamese.py needs an MI355X (no CPU fallback)')
+    device = torch.device('cuda', local % torch.cuda.device_count() if world > 1 else gpu)
+    torch.cuda.set_device(device)
+    net = build_net(opt, device)
+    parallel.broadcast_parameters(net)
+    criterion = networks.BinaryNLLLoss()
+    params = list(net.base.parameters()) + (list(net.cnn.parameters()) if net.cnn is not None else [])
+    optimizer = FusedAdam(params, lr=opt.lr)                                   # optim.Adam(param, lr) of the reference
+    data = PairDataset(opt, opt.dataroot, opt.datafile)
+    loader = torch.utils.data.DataLoader(data, batch_size=opt.batch_size, shuffle=not opt.serial_batches,
+                                         num_workers=0 if data.synthetic else opt.num_workers)
+    save_dir = os.path.join(opt.checkpoint_dir, opt.name)
+    os.makedirs(save_dir, exist_ok=True)
+    save(net, os.path.join(save_dir, 'init_net.pth'))
+    history, total = [], 0
+    for epoch in range(opt.epoch_count, opt.num_epochs + opt.epoch_count):
+        wrong = seen = 0
+        for img0, img1, label in loader:
+            img0, img1, label = (parallel.shard_batch(t, rank, world).to(device) for t in (img0, img1, label))
+            total += 1
+            optimizer.zero_grad()
+            _, _, score = net(img0, img1)
+            prob = torch.sigmoid(score)
+            loss = criterion(prob, label)
+            loss.backward()
+            parallel.sync_gradients(optimizer)
+            optimizer.step()
+            wrong += int((predictions(prob, opt.draw_prob_thresh) != label).sum())
+            seen += int(label.numel())
+            if total % opt.print_freq == 0:
+                value = float(loss)
+                history.append(value)
+                if rank == 0:
+                    print('epoch %02d, iter %06d, loss: %.4f' % (epoch, total, value))
+            if total % opt.save_latest_freq == 0:
+                save(net, os.path.join(save_dir, 'latest_net.pth'))
+        if rank == 0:
+            print('epoch %02d: train accuracy %.4f' % (epoch, 1.0 - wrong / max(seen, 1)))
+        save(net, os.path.join(save_dir, 'latest_net.pth'))
+        if epoch % opt.save_epoch_freq == 0:
+            save(net, os.path.join(save_dir, '%d_net.pth' % epoch))
+    if rank == 0:
+        with open(os.path.join(save_dir, 'loss.txt'), 'w') as f:
+            f.writelines('%r\n' % v for v in history)
+    return history
+
+
+if __name__ == '__main__':
+    options = build_parser().parse_args()
+    if options.mode != 'train':
+        raise NotImplementedError('pcgan_amd: siamese.py --mode %s is outside the MI355X hot path (train only)' % options.mode)
+    train(options)

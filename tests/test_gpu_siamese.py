@@ -1,0 +1,71 @@
+"""GPU parity of the Elo-encoder training step: networks.SiameseNetwork + BinaryNLLLoss + FusedAdam on
+the HIP path against the reference's golden vectors (first step: identical weights) and the oracle's float64 twin for the
+gradients; then siamese.py's own loop on synthetic pairs must reduce the loss.
+Tolerances: loss 2e-4; ratings / probabilities 2e-4 of the largest magnitude; gradients |hip - g64| <= 2 |ref32 - g64| +
+3e-2 |g64| per tensor (ReLU / max-pool mask flips, see test_gpu_nets.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import weights as W
+from test_siamese_oracle_golden import build_oracle, siamese_inputs
+from util_cmp import assert_close
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_siamese_step_matches_reference_and_oracle(dev):
+    from pcgan_amd.models import networks
+    from pcgan_amd.hip.optim import FusedAdam
+    gold = np.load(os.path.join(GOLD, 'siamese_step.npz'))
+    net = networks.SiameseNetwork(networks.ResNetFeature(3, 'resnet18'), pooling='avg', cnn_dim=[32, 1], cnn_pad=1,
+                                  cnn_relu_slope=0.7)
+    net.load_state_dict(W.fill_state_dict({k: v.cpu() for k, v in net.state_dict().items()}, 61))
+    net.to(dev)
+    crit = networks.BinaryNLLLoss()
+    opt = FusedAdam(list(net.base.parameters()) + list(net.cnn.parameters()), lr=2e-4)
+    oracle, twin = build_oracle(), build_oracle(torch.float64)
+    img0, img1, label = siamese_inputs(0)
+    oracle.step(img0, img1, label)
+    twin.step(img0.double(), img1.double(), label)
+    opt.zero_grad()
+    f1, f2, score = net(img0.to(dev), img1.to(dev))
+    prob = torch.sigmoid(score)
+    loss = crit(prob, label.to(dev))
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    opt.step()
+    assert abs(float(loss) - float(gold['it0/loss'])) <= 2e-4
+    assert_close(f1, torch.from_numpy(gold['it0/f1']), 2e-4, 'rating of image 0 vs reference')
+    assert_close(prob, torch.from_numpy(gold['it0/prob']), 2e-4, 'probability vs reference')
+    for k, g64 in twin.grads.items():
+        scale = float(g64.norm())
+        e_hip = float((grads[k].double().cpu() - g64).norm())
+        e_ref = float((oracle.grads[k].double() - g64).norm())
+        assert e_hip <= 2 * e_ref + 3e-2 * scale + 1e-6, 'grad %s: |hip-g64| %.3e |ref32-g64| %.3e |g64| %.3e' % (k, e_hip, e_ref, scale)
+    for k, v in net.state_dict().items():
+        ref = gold['it0/after/' + k]
+        assert abs(float(v.double().abs().sum()) - ref[1]) <= 2e-3 * (ref[1] + 1e-3) + 2.02 * 2e-4 * v.numel(), 'after-step ' + k
+
+
+def test_siamese_script_trains_on_synthetic_pairs(tmp_path, dev):
+    sys.path.insert(0, ROOT)
+    import siamese
+    opt = siamese.build_parser().parse_args(
+        ['--dataroot', 'synthetic', '--name', 'elo', '--checkpoint_dir', str(tmp_path), '--batch_size', '16',
+         '--num_epochs', '2', '--fineSize', '64', '--max_dataset_size', '256', '--print_freq', '1', '--save_epoch_freq', '1',
+         '--pretrained_model_path', '', '--lr', '0.001'])
+    history = siamese.train(opt)
+    assert len(history) == 32 and all(np.isfinite(history))
+    assert np.mean(history[-8:]) < np.mean(history[:8]) - 0.05, 'loss did not fall: %s' % history
+    for f in ('init_net.pth', 'latest_net.pth', '1_net.pth', '2_net.pth', 'loss.txt'):
+        assert os.path.exists(os.path.join(str(tmp_path), 'elo', f)), f
+    # the checkpoint is what wsgan_emb's encoder loads (SiameseFeature.load_pretrained, strict)
+    from pcgan_amd.models import networks
+    e = networks.define_E('resnet18', 3, 'normal', 'avg', [32, 1], 1, 0.7)
+    e.load_pretrained(os.path.join(str(tmp_path), 'elo', '2_net.pth'))
