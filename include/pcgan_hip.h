@@ -142,6 +142,18 @@ int pcgan_norm_bwd_apply(const float* dy, const float* x, const float* y, const 
                          int act, float slope, pcgan_stream_t s);
 int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, float* s2_c, int N, int C,
                         pcgan_stream_t s);
+/* BatchNorm2d in training mode for small tensors (used up to N * HW = 8192 per channel), ONE launch per pass: batch statistics,
+ * running-statistics update (+ num_batches_tracked when `batches` != NULL), normalise + affine (+ residual) + activation
+ * -- replaces nn.BatchNorm2d (+ the following ReLU / LeakyReLU) of the PatchGAN and of the Elo encoder's late stages
+ * (models/networks.py:24-26, 756-771; models/resnet.py:58-71).  mean_c / var_c (biased) are kept for the backward pass;
+ * backward returns s1_c = d(beta), s2_c = d(gamma) and dx (dx / dres may be NULL). */
+int pcgan_bn_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                       float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches, int N,
+                       int C, int HW, float momentum, float eps, int act, float slope, pcgan_stream_t s);
+int pcgan_bn_bwd_fused(const float* dy, const float* x, const float* y, const float* mean_c, const float* var_c,
+                       const float* gamma, float* dx, float* dres, float* s1_c, float* s2_c, int N, int C, int HW, float eps,
+                       int act, float slope, pcgan_stream_t s);
+
 /* Fused instance norm (the generator's 23 norm sites per pass, models/networks.py:580-601,633,646): the
  * (n,c) plane stays in registers, so forward = one read + one write (statistics + normalise + residual +
  * activation; mean / M2 are also returned for the backward and the running-stat update) and backward = one

@@ -218,6 +218,100 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(NormArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused BatchNorm for small tensors (N * HW <= 8192 per channel: the Elo encoder's 14x14 / 7x7 maps, the PatchGAN's
+// 16x16 / 15x15): ONE workgroup per channel does statistics (exact two-pass over the channel's N planes, which stay in
+// L2), the running-statistics update and normalise + affine (+ residual) + activation -- one launch instead of
+// plane_stats + bn_merge + norm_act (+ the batch counter); these layers are launch-latency bound, not bandwidth bound.
+// Backward likewise: sum g, sum g * xhat, then dx (and the raw masked gradient for a residual branch).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_fwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res,
+                                                           float* __restrict__ y, float* __restrict__ mean_c,
+                                                           float* __restrict__ var_c, float* running_mean, float* running_var,
+                                                           long long* batches, int N, int C, int HW, float momentum, float eps,
+                                                           int act, float slope) {
+    __shared__ float scratch[16];
+    const int c = blockIdx.x;
+    const int cnt = N * HW;
+    // the 4 waves take the N planes of the channel round-robin; lanes stride over a plane (no per-element division)
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    float s = 0.f;
+    for (int n = wv; n < N; n += 4) {
+        const float* xp = x + ((size_t)n * C + c) * HW;
+        for (int k = ln; k < HW; k += 64) s += xp[k];
+    }
+    const float mean = block_sum(s, scratch) / (float)cnt;
+    float q = 0.f;
+    for (int n = wv; n < N; n += 4) {
+        const float* xp = x + ((size_t)n * C + c) * HW;
+        for (int k = ln; k < HW; k += 64) {
+            const float d = xp[k] - mean;
+            q += d * d;
+        }
+    }
+    const float m2 = block_sum(q, scratch);
+    const float var = m2 / (float)cnt;
+    if (threadIdx.x == 0) {
+        mean_c[c] = mean;
+        var_c[c] = var;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / ((float)cnt - 1.f));
+        if (batches && c == 0) batches[0] += 1;
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = rsqrtf(var + eps) * g, sh = b - mean * sc;
+    for (int n = wv; n < N; n += 4) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        for (int k = ln; k < HW; k += 64) {
+            float v = x[base + k] * sc + sh;
+            if (res) v += res[base + k];
+            y[base + k] = act_apply(v, act, slope);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, const float* __restrict__ mean_c,
+                                                           const float* __restrict__ var_c, const float* __restrict__ gamma,
+                                                           float* __restrict__ dx, float* __restrict__ dres,
+                                                           float* __restrict__ s1_c, float* __restrict__ s2_c, int N, int C,
+                                                           int HW, float eps, int act, float slope) {
+    __shared__ float scratch[16];
+    const int c = blockIdx.x;
+    const int cnt = N * HW;
+    const float mean = mean_c[c], rstd = rsqrtf(var_c[c] + eps);
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = wv; n < N; n += 4) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        for (int k = ln; k < HW; k += 64) {
+            float g = dy[base + k];
+            if (act != PCGAN_ACT_NONE) g *= act_grad_from_out(y[base + k], act, slope);
+            s1 += g;
+            s2 += g * ((x[base + k] - mean) * rstd);
+        }
+    }
+    s1 = block_sum(s1, scratch);
+    s2 = block_sum(s2, scratch);
+    if (threadIdx.x == 0) {
+        s1_c[c] = s1;
+        s2_c[c] = s2;
+    }
+    if (!dx && !dres) return;
+    const float m1 = s1 / (float)cnt, m2 = s2 / (float)cnt;
+    const float kk = rstd * (gamma ? gamma[c] : 1.f);
+    for (int n = wv; n < N; n += 4) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        for (int k = ln; k < HW; k += 64) {
+            float g = dy[base + k];
+            if (act != PCGAN_ACT_NONE) g *= act_grad_from_out(y[base + k], act, slope);
+            if (dx) dx[base + k] = kk * (g - m1 - ((x[base + k] - mean) * rstd) * m2);
+            if (dres) dres[base + k] = g;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused instance norm: the whole (n,c) plane lives in the workgroup's registers, so forward is ONE read
 // + ONE write (statistics, normalise, residual, activation) and backward ONE read of dy/x(/y) + ONE write.
 // T threads x E float4 per thread cover planes up to T*E*4 elements (HW % 4 == 0).
@@ -455,6 +549,27 @@ extern "C" int pcgan_instnorm_bwd(const float* dy, const float* x, const float* 
     if (E == 1) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1>), dim3(N * C), dim3(T), 0, st, dy, x, y, mean_nc, m2_nc, dx, HW, eps, act, slope);
     else if (E == 4) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<4>), dim3(N * C), dim3(T), 0, st, dy, x, y, mean_nc, m2_nc, dx, HW, eps, act, slope);
     else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<16>), dim3(N * C), dim3(T), 0, st, dy, x, y, mean_nc, m2_nc, dx, HW, eps, act, slope);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_bn_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                                  float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches,
+                                  int N, int C, int HW, float momentum, float eps, int act, float slope, pcgan_stream_t s) {
+    PCGAN_CHECK(x && y && mean_c && var_c && N > 0 && C > 0 && HW > 0 && (long long)N * HW > 1, "bn_fwd_fused: bad arguments");
+    hipLaunchKernelGGL(bn_fwd_fused_kernel, dim3(C), dim3(256), 0, (hipStream_t)s, x, gamma, beta, residual, y, mean_c, var_c,
+                       running_mean, running_var, batches, N, C, HW, momentum, eps, act, slope);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_bn_bwd_fused(const float* dy, const float* x, const float* y, const float* mean_c, const float* var_c,
+                                  const float* gamma, float* dx, float* dres, float* s1_c, float* s2_c, int N, int C, int HW,
+                                  float eps, int act, float slope, pcgan_stream_t s) {
+    PCGAN_CHECK(dy && x && mean_c && var_c && s1_c && s2_c && N > 0 && C > 0 && HW > 0, "bn_bwd_fused: bad arguments");
+    PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "bn_bwd_fused: activation mask needs y");
+    hipLaunchKernelGGL(bn_bwd_fused_kernel, dim3(C), dim3(256), 0, (hipStream_t)s, dy, x, y, mean_c, var_c, gamma, dx, dres,
+                       s1_c, s2_c, N, C, HW, eps, act, slope);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

@@ -171,47 +171,59 @@ def instance_norm_act(x, running_mean=None, running_var=None, momentum=0.1, eps=
 
 class _BatchNormActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope, training):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope, training, batches):
         x, residual = _c(x), _c(residual)
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
-        if training:
-            mean_nc, m2_nc = ops.plane_stats(x)
-            mean, var = ops.bn_merge(mean_nc, m2_nc, N, C, HW, running_mean, running_var, momentum)
+        fused = training and N * HW <= ops.BN_FUSED_MAX and N * HW > 1
+        if fused:      # one launch: statistics + running update + batch counter + normalise / activation
+            y, mean, var = ops.bn_fwd_fused(x, gamma, beta, residual, running_mean, running_var, batches, momentum, eps, act, slope)
         else:
-            mean, var = running_mean, running_var
-        y = ops.norm_act_fwd(x, mean, var, gamma, beta, residual, False, eps, act, slope)
-        ctx.cfg = (eps, act, slope, training, residual is not None)
+            if training:
+                mean_nc, m2_nc = ops.plane_stats(x)
+                mean, var = ops.bn_merge(mean_nc, m2_nc, N, C, HW, running_mean, running_var, momentum)
+                if batches is not None:
+                    batches.add_(1)
+            else:
+                mean, var = running_mean, running_var
+            y = ops.norm_act_fwd(x, mean, var, gamma, beta, residual, False, eps, act, slope)
+        ctx.cfg = (eps, act, slope, training, residual is not None, fused)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, var, gamma)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, var, gamma = ctx.saved_tensors
-        eps, act, slope, training, has_res = ctx.cfg
+        eps, act, slope, training, has_res, fused = ctx.cfg
         if not training:
             raise NotImplementedError('pcgan_amd: backward through eval-mode BatchNorm is not on the hot path')
         dy = _c(dy)
         N, C = x.shape[0], x.shape[1]
         want_res = has_res and ctx.needs_input_grad[3]
-        s1n, s2n = ops.norm_bwd_stats(dy, x, y, mean, var, False, eps, act, slope)
-        s1, s2 = ops.bn_bwd_reduce(s1n, s2n, N, C)
+        want_dx = ctx.needs_input_grad[0]
         dx = dres = None
-        if ctx.needs_input_grad[0] or (want_res and act != ACT_NONE):
-            dx, dres = ops.norm_bwd_apply(dy, x, y, mean, var, gamma, s1, s2, False, eps, act, slope,
-                                          want_res and act != ACT_NONE)
+        if fused:
+            dx, dres, s1, s2 = ops.bn_bwd_fused(dy, x, y, mean, var, gamma, eps, act, slope, want_dx,
+                                                want_res and act != ACT_NONE)
+        else:
+            s1n, s2n = ops.norm_bwd_stats(dy, x, y, mean, var, False, eps, act, slope)
+            s1, s2 = ops.bn_bwd_reduce(s1n, s2n, N, C)
+            if want_dx or (want_res and act != ACT_NONE):
+                dx, dres = ops.norm_bwd_apply(dy, x, y, mean, var, gamma, s1, s2, False, eps, act, slope,
+                                              want_res and act != ACT_NONE)
         if want_res and dres is None:
             dres = dy
         dgamma = s2 if ctx.needs_input_grad[1] else None
         dbeta = s1 if ctx.needs_input_grad[2] else None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
-                   residual=None, training=True):
-    """act( BatchNorm2d(affine=True)(x) + residual ) with batch statistics in train mode."""
+                   residual=None, training=True, batches=None):
+    """act( BatchNorm2d(affine=True)(x) + residual ) with batch statistics in train mode; `batches` = the module's
+    num_batches_tracked counter (incremented on the device, inside the fused kernel when the tensor is small)."""
     return _BatchNormActFn.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope,
-                                 training)
+                                 training, batches)
 
 
 # ---------------------------------------------------------------------------- pointwise

@@ -51,6 +51,8 @@ SIGNATURES = {
     'pcgan_norm_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp]),
     'pcgan_norm_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp]),
     'pcgan_bn_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'pcgan_bn_fwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _vp]),
+    'pcgan_bn_bwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
     'pcgan_instnorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
     'pcgan_instnorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
     'pcgan_maxpool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -55,10 +55,9 @@ class BatchNorm2d(tnn.BatchNorm2d):
 
     def forward(self, x, act=ACT_NONE, slope=0.0, residual=None):
         training = self.training or self.running_mean is None
-        if training and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
         return F.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
-                                self.eps, act, slope, residual, training)
+                                self.eps, act, slope, residual, training,
+                                self.num_batches_tracked if training else None)
 
 
 class Dropout2d(tnn.Dropout2d):

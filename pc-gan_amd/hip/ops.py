@@ -382,6 +382,38 @@ def norm_bwd_apply(dy, x, y, mean, var, gamma, s1, s2, per_plane, eps, act, slop
     return dx, dres
 
 
+BN_FUSED_MAX = int(os.environ.get('PCGAN_BN_FUSED_MAX', 8192))   # elements per channel (N * HW) up to which BatchNorm runs as one launch per pass
+
+
+def bn_fwd_fused(x, gamma, beta, residual, running_mean, running_var, batches, momentum, eps, act, slope):
+    """training-mode BatchNorm2d (+ residual + activation) of a small tensor in one launch; returns y, mean, var (biased)"""
+    _chk(x, gamma, beta, residual, running_mean, running_var)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    var = torch.empty(C, dtype=torch.float32, device=x.device)
+    if batches is not None:
+        assert batches.dtype == torch.int64 and batches.is_cuda
+    _L.check(_L.load().pcgan_bn_fwd_fused(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(mean), _p(var), _p(running_mean),
+                                          _p(running_var), _p(batches), N, C, HW, float(momentum), float(eps), act, float(slope),
+                                          _stream()), 'bn_fwd_fused')
+    return y, mean, var
+
+
+def bn_bwd_fused(dy, x, y, mean, var, gamma, eps, act, slope, want_dx, want_dres):
+    _chk(dy, x, y, mean, var, gamma)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    dx = torch.empty_like(x) if want_dx else None
+    dres = torch.empty_like(x) if want_dres else None
+    s1 = torch.empty(C, dtype=torch.float32, device=x.device)
+    s2 = torch.empty(C, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().pcgan_bn_bwd_fused(_p(dy), _p(x), _p(y), _p(mean), _p(var), _p(gamma), _p(dx), _p(dres), _p(s1), _p(s2),
+                                          N, C, HW, float(eps), act, float(slope), _stream()), 'bn_bwd_fused')
+    return dx, dres, s1, s2
+
+
 def instnorm_fwd(x, residual, eps, act, slope):
     """fused instance norm forward: returns y, mean[N*C], m2[N*C]"""
     _chk(x, residual)

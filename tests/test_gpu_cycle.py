@@ -99,7 +99,7 @@ def test_cycle_step_matches_reference_and_oracle(tmp_path, dev):
             assert e_hip <= 2 * e_ref + 3e-2 * scale + 1e-6, \
                 'grad%s %s: |hip-g64| %.3e, |ref32-g64| %.3e, |g64| %.3e' % (tag, k, e_hip, e_ref, scale)
             st = gold['it0/grad%s/stat/%s' % (tag, k)]
-            assert abs(float(hip.double().norm()) - st[2]) <= 3e-2 * st[2] + 1e-5, 'grad%s %s norm vs reference' % (tag, k)
+            assert abs(float(hip.double().norm()) - st[2]) <= 3e-2 * st[2] + 1e-4, 'grad%s %s norm vs reference' % (tag, k)   # (+1e-4: tensors whose true gradient is 0 carry only noise)
     # parameters after the three Adam steps.  The first Adam step moves every parameter by lr * sign(gradient): where
     # the true gradient is 0 (biases in front of an affine-less InstanceNorm) the sign is noise, so each entry may
     # differ from the reference by up to 2 lr -- bound the |.|-sum accordingly.
