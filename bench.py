@@ -165,7 +165,7 @@ def main():
                                'PatchGAN + ResNet-18 Elo encoder@224 + AlexNet IP@224, full optimize_parameters()',
                    'global_batch': PER_GPU_BATCH * world, 'parallelism': 'dp%d' % world},
         'step_flop_fraction': round(GFLOP_PER_IMG_FULL * 1e9 * value / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4),
-        'roofline': {'bound': 'mfma', 'kernel': 'igemm2_kernel<1,128,128> (FWD_REFLECT, 128x128 tile) 256->256 3x3 reflect @32x32, bs32',
+        'roofline': {'bound': 'mfma', 'kernel': 'igemm2_kernel<1,128,128,16> (FWD_REFLECT, 128x128 tile, 16-channel K stages) 256->256 3x3 reflect @32x32, bs32',
                      'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'ms_per_launch': round(conv_ms, 4),
                      'launches_timed': conv_launches, 'flop_per_launch': conv_flop,
