@@ -106,6 +106,29 @@ def test_generator(nb, dev):
     assert_close(out, torch.from_numpy(_gold()['G%d/out_zbroadcast' % nb]), 1e-4, 'z broadcast (1,nz,1,1)')
 
 
+@pytest.mark.parametrize('ngf,size,bs,nb', [(16, 36, 3, 2), (20, 24, 5, 3), (32, 40, 2, 2)])
+def test_generator_odd_configurations(ngf, size, bs, nb, dev):
+    """widths that are (16, 32) and are not (20) multiples of 16 -- chunked-K and generic kernels --, spatial sizes whose
+    down-sampled planes are odd (36 -> 9x9: planes not a multiple of 4 pixels), odd batch sizes; against the float64 twin."""
+    from pcgan_amd.models import networks
+    ref = N.ResnetGeneratorRef(3, 3, 1, ngf, 'instance', nb)
+    ref.load_state_dict(W.fill_state_dict(ref.state_dict(), 70 + ngf))
+    hip = networks.define_G(3, 3, 1, ngf, 'resnet_%dblocks' % nb, norm='instance', init_type='normal')
+    x = W.seeded_tensor((bs, 3, size, size), 170 + ngf)
+    z = W.seeded_normal((bs, 1, 1, 1), 270 + ngf)
+    _compare(hip, ref, [x, z], 370 + ngf, dev)
+
+
+@pytest.mark.parametrize('ndf,size,bs,nl', [(16, 48, 3, 3), (12, 40, 5, 2), (32, 64, 2, 4)])
+def test_discriminator_odd_configurations(ndf, size, bs, nl, dev):
+    from pcgan_amd.models import networks
+    ref = N.NLayerDiscriminatorRef(3, 1, ndf, nl, 'batch', True)
+    ref.load_state_dict(W.fill_state_dict(ref.state_dict(), 80 + ndf))
+    hip = networks.define_D(3, 1, ndf, 'n_layers', nl, 'batch', True, 'normal')
+    _compare(hip, ref, [W.seeded_tensor((bs, 3, size, size), 180 + ndf), W.seeded_normal((bs, 1, 1, 1), 280 + ndf)],
+             380 + ndf, dev)
+
+
 def test_generator_state_dict_keys_match_reference_layout(dev):
     from pcgan_amd.models import networks
     ref = N.ResnetGeneratorRef(3, 3, 1, 8, 'instance', 9)
