@@ -64,18 +64,20 @@ __global__ void scale_kernel(const float* __restrict__ x, const float* __restric
     for (size_t i = (n4 << 2) + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = x[i] * k;
 }
 
-// one workgroup per output plane (n, c_out)
+// blockIdx.x = output plane (n, c_out), blockIdx.y = 4096-element chunk of it (128-bit accesses when HW % 4 == 0)
 __global__ void concat_z_kernel(const float* __restrict__ img, const float* __restrict__ z, float* __restrict__ out,
                                 int C, int nz, int HW, int z_batch) {
     const int Ct = C + nz;
     const int n = blockIdx.x / Ct, c = blockIdx.x % Ct;
+    const int lo = blockIdx.y * 4096, hi = lo + 4096 < HW ? lo + 4096 : HW;
     float* op = out + (size_t)blockIdx.x * HW;
-    if (c < C) {
-        const float* ip = img + ((size_t)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) op[i] = ip[i];
+    const float* ip = c < C ? img + ((size_t)n * C + c) * HW : nullptr;
+    const float v = c < C ? 0.f : z[(z_batch == 1 ? 0 : n) * nz + (c - C)];
+    if ((HW & 3) == 0) {
+        for (int i = lo + threadIdx.x * 4; i < hi; i += blockDim.x * 4)
+            *reinterpret_cast<float4*>(op + i) = ip ? *reinterpret_cast<const float4*>(ip + i) : make_float4(v, v, v, v);
     } else {
-        const float v = z[(z_batch == 1 ? 0 : n) * nz + (c - C)];
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) op[i] = v;
+        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) op[i] = ip ? ip[i] : v;
     }
 }
 
@@ -149,8 +151,8 @@ extern "C" int pcgan_concat_z(const float* img, const float* z, float* out, int 
                               int z_batch, pcgan_stream_t s) {
     PCGAN_CHECK(img && z && out && N > 0 && C > 0 && nz > 0 && HW > 0, "concat_z: bad arguments");
     PCGAN_CHECK(z_batch == 1 || z_batch == N, "concat_z: z batch %d must be 1 or N=%d", z_batch, N);
-    hipLaunchKernelGGL(concat_z_kernel, dim3(N * (C + nz)), dim3(256), 0, (hipStream_t)s, img, z, out, C, nz, HW,
-                       z_batch);
+    hipLaunchKernelGGL(concat_z_kernel, dim3(N * (C + nz), (HW + 4095) / 4096), dim3(256), 0, (hipStream_t)s, img, z, out, C,
+                       nz, HW, z_batch);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

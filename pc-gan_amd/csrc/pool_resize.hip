@@ -40,11 +40,12 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, float* __restrict__ dx,
                                    int H, int W, int k, int stride, int pad, int P, int Q, size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ix = (int)(i % W);
-        const int iy = (int)((i / W) % H);
-        const size_t nc = i / ((size_t)H * W);
-        const int me = iy * W + ix;
+    // blockIdx.y = plane, blockIdx.x = 256-element chunk of the plane: no 64-bit divisions per element
+    const size_t nc = blockIdx.y;
+    for (int me = blockIdx.x * blockDim.x + threadIdx.x; me < H * W; me += gridDim.x * blockDim.x) {
+        const int iy = me / W;
+        const int ix = me - iy * W;
+        const size_t i = nc * (size_t)H * W + me;
         // output rows p with p*stride - pad <= iy <= p*stride - pad + k - 1
         int p_lo = (iy + pad - k + 1 + stride - 1);
         p_lo = p_lo <= 0 ? 0 : p_lo / stride;
@@ -131,10 +132,11 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restri
 // lie in [ceil((iy-1)/sh), floor((iy+1)/sh)]; every candidate is re-derived exactly.
 __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int P, int Q,
                                     float sh, float sw, size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ix = (int)(i % W);
-        const int iy = (int)((i / W) % H);
-        const size_t nc = i / ((size_t)H * W);
+    const size_t nc = blockIdx.y;   // plane; blockIdx.x = chunk of the plane (32-bit index math)
+    for (int me = blockIdx.x * blockDim.x + threadIdx.x; me < H * W; me += gridDim.x * blockDim.x) {
+        const int iy = me / W;
+        const int ix = me - iy * W;
+        const size_t i = nc * (size_t)H * W + me;
         int p_lo = 0, p_hi = P - 1, q_lo = 0, q_hi = Q - 1;
         if (sh > 0.f) {
             p_lo = (int)floorf((float)(iy - 1) / sh) - 1;
@@ -197,7 +199,9 @@ extern "C" int pcgan_maxpool_bwd(const float* dy, const int32_t* argmax, float* 
                                  int stride, int pad, int P, int Q, pcgan_stream_t s) {
     PCGAN_CHECK(dy && argmax && dx && NC > 0, "maxpool_bwd: bad arguments");
     const size_t total = (size_t)NC * H * W;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, dy, argmax, dx, H, W,
+    PCGAN_CHECK(NC <= 65535, "maxpool_bwd: more than 65535 planes");
+    const int bx = (H * W + 255) / 256;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s, dy, argmax, dx, H, W,
                        k, stride, pad, P, Q, total);
     PCGAN_LAUNCH_CHECK();
     return 0;
@@ -236,7 +240,9 @@ extern "C" int pcgan_bilinear_fwd(const float* x, float* y, int NC, int H, int W
 extern "C" int pcgan_bilinear_bwd(const float* dy, float* dx, int NC, int H, int W, int P, int Q, pcgan_stream_t s) {
     PCGAN_CHECK(dy && dx && NC > 0 && H > 0 && W > 0 && P > 0 && Q > 0, "bilinear_bwd: bad arguments");
     const size_t total = (size_t)NC * H * W;
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, dy, dx, H, W, P, Q,
+    PCGAN_CHECK(NC <= 65535, "bilinear_bwd: more than 65535 planes");
+    const int bx = (H * W + 255) / 256;
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s, dy, dx, H, W, P, Q,
                        ac_scale(H, P), ac_scale(W, Q), total);
     PCGAN_LAUNCH_CHECK();
     return 0;
