@@ -12,10 +12,11 @@ namespace pcgan {
 
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ arg,
                                    int H, int W, int k, int stride, int pad, int P, int Q, size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int q = (int)(i % Q);
-        const int p = (int)((i / Q) % P);
-        const size_t nc = i / ((size_t)P * Q);
+    const size_t nc = blockIdx.y;   // plane; blockIdx.x = chunk of the output plane (32-bit index math)
+    for (int me = blockIdx.x * blockDim.x + threadIdx.x; me < P * Q; me += gridDim.x * blockDim.x) {
+        const int p = me / Q;
+        const int q = me - p * Q;
+        const size_t i = nc * (size_t)P * Q + me;
         const float* xp = x + nc * (size_t)H * W;
         const int y0 = p * stride - pad, x0 = q * stride - pad;
         float best = -FLT_MAX;
@@ -114,10 +115,11 @@ __device__ __forceinline__ void bilin_src(int dst, float scale, int in_size, int
 
 __global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int P, int Q,
                                     float sh, float sw, size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int q = (int)(i % Q);
-        const int p = (int)((i / Q) % P);
-        const size_t nc = i / ((size_t)P * Q);
+    const size_t nc = blockIdx.y;   // plane; blockIdx.x = chunk of the output plane (32-bit index math)
+    for (int me = blockIdx.x * blockDim.x + threadIdx.x; me < P * Q; me += gridDim.x * blockDim.x) {
+        const int p = me / Q;
+        const int q = me - p * Q;
+        const size_t i = nc * (size_t)P * Q + me;
         int y0, y1, x0, x1;
         float ly, lx;
         bilin_src(p, sh, H, y0, y1, ly);
@@ -189,7 +191,9 @@ extern "C" int pcgan_maxpool_fwd(const float* x, float* y, int32_t* argmax, int 
     PCGAN_CHECK(P == (H + 2 * pad - k) / stride + 1 && Q == (W + 2 * pad - k) / stride + 1,
                 "maxpool_fwd: output dims do not match (floor mode)");
     const size_t total = (size_t)NC * P * Q;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, x, y, argmax, H, W, k,
+    PCGAN_CHECK(NC <= 65535, "maxpool_fwd: more than 65535 planes");
+    const int bx = (P * Q + 255) / 256;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s, x, y, argmax, H, W, k,
                        stride, pad, P, Q, total);
     PCGAN_LAUNCH_CHECK();
     return 0;
@@ -231,7 +235,9 @@ static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1)
 extern "C" int pcgan_bilinear_fwd(const float* x, float* y, int NC, int H, int W, int P, int Q, pcgan_stream_t s) {
     PCGAN_CHECK(x && y && NC > 0 && H > 0 && W > 0 && P > 0 && Q > 0, "bilinear_fwd: bad arguments");
     const size_t total = (size_t)NC * P * Q;
-    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, x, y, H, W, P, Q,
+    PCGAN_CHECK(NC <= 65535, "bilinear_fwd: more than 65535 planes");
+    const int bx = (P * Q + 255) / 256;
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s, x, y, H, W, P, Q,
                        ac_scale(H, P), ac_scale(W, Q), total);
     PCGAN_LAUNCH_CHECK();
     return 0;
