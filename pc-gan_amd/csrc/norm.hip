@@ -224,31 +224,41 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(NormArgs a) {
 // plane_stats + bn_merge + norm_act (+ the batch counter); these layers are launch-latency bound, not bandwidth bound.
 // Backward likewise: sum g, sum g * xhat, then dx (and the raw masked gradient for a residual branch).
 // ------------------------------------------------------------------------------------------------
+// element access of the fused BatchNorm kernels: the 4 waves take the N planes of channel c round-robin, lanes stride
+// over a plane with 128-bit accesses when HW % 4 == 0 (V = 4) -- f(index, value...) is called once per element
+template <int V, typename F>
+__device__ __forceinline__ void bn_for_each(int N, int C, int HW, int c, F f) {
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    for (int n = wv; n < N; n += 4) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        for (int k = ln * V; k < HW; k += 64 * V) f(base + k);
+    }
+}
+
+template <int V>
 __global__ void __launch_bounds__(256) bn_fwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ res,
                                                            float* __restrict__ y, float* __restrict__ mean_c,
                                                            float* __restrict__ var_c, float* running_mean, float* running_var,
                                                            long long* batches, int N, int C, int HW, float momentum, float eps,
                                                            int act, float slope) {
+    typedef float vec __attribute__((ext_vector_type(V)));
     __shared__ float scratch[16];
     const int c = blockIdx.x;
     const int cnt = N * HW;
-    // the 4 waves take the N planes of the channel round-robin; lanes stride over a plane (no per-element division)
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
     float s = 0.f;
-    for (int n = wv; n < N; n += 4) {
-        const float* xp = x + ((size_t)n * C + c) * HW;
-        for (int k = ln; k < HW; k += 64) s += xp[k];
-    }
+    bn_for_each<V>(N, C, HW, c, [&](size_t i) {
+        const vec v = *reinterpret_cast<const vec*>(x + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s += v[e];
+    });
     const float mean = block_sum(s, scratch) / (float)cnt;
     float q = 0.f;
-    for (int n = wv; n < N; n += 4) {
-        const float* xp = x + ((size_t)n * C + c) * HW;
-        for (int k = ln; k < HW; k += 64) {
-            const float d = xp[k] - mean;
-            q += d * d;
-        }
-    }
+    bn_for_each<V>(N, C, HW, c, [&](size_t i) {
+        const vec v = *reinterpret_cast<const vec*>(x + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) q += (v[e] - mean) * (v[e] - mean);
+    });
     const float m2 = block_sum(q, scratch);
     const float var = m2 / (float)cnt;
     if (threadIdx.x == 0) {
@@ -260,37 +270,45 @@ __global__ void __launch_bounds__(256) bn_fwd_fused_kernel(const float* __restri
     }
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float sc = rsqrtf(var + eps) * g, sh = b - mean * sc;
-    for (int n = wv; n < N; n += 4) {
-        const size_t base = ((size_t)n * C + c) * HW;
-        for (int k = ln; k < HW; k += 64) {
-            float v = x[base + k] * sc + sh;
-            if (res) v += res[base + k];
-            y[base + k] = act_apply(v, act, slope);
+    bn_for_each<V>(N, C, HW, c, [&](size_t i) {
+        vec v = *reinterpret_cast<const vec*>(x + i);
+        vec r;
+        if (res) r = *reinterpret_cast<const vec*>(res + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t = v[e] * sc + sh;
+            if (res) t += r[e];
+            v[e] = act_apply(t, act, slope);
         }
-    }
+        *reinterpret_cast<vec*>(y + i) = v;
+    });
 }
 
+template <int V>
 __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ mean_c,
                                                            const float* __restrict__ var_c, const float* __restrict__ gamma,
                                                            float* __restrict__ dx, float* __restrict__ dres,
                                                            float* __restrict__ s1_c, float* __restrict__ s2_c, int N, int C,
                                                            int HW, float eps, int act, float slope) {
+    typedef float vec __attribute__((ext_vector_type(V)));
     __shared__ float scratch[16];
     const int c = blockIdx.x;
     const int cnt = N * HW;
     const float mean = mean_c[c], rstd = rsqrtf(var_c[c] + eps);
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
     float s1 = 0.f, s2 = 0.f;
-    for (int n = wv; n < N; n += 4) {
-        const size_t base = ((size_t)n * C + c) * HW;
-        for (int k = ln; k < HW; k += 64) {
-            float g = dy[base + k];
-            if (act != PCGAN_ACT_NONE) g *= act_grad_from_out(y[base + k], act, slope);
+    bn_for_each<V>(N, C, HW, c, [&](size_t i) {
+        const vec d = *reinterpret_cast<const vec*>(dy + i), xv = *reinterpret_cast<const vec*>(x + i);
+        vec yv;
+        if (act != PCGAN_ACT_NONE) yv = *reinterpret_cast<const vec*>(y + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float g = d[e];
+            if (act != PCGAN_ACT_NONE) g *= act_grad_from_out(yv[e], act, slope);
             s1 += g;
-            s2 += g * ((x[base + k] - mean) * rstd);
+            s2 += g * ((xv[e] - mean) * rstd);
         }
-    }
+    });
     s1 = block_sum(s1, scratch);
     s2 = block_sum(s2, scratch);
     if (threadIdx.x == 0) {
@@ -300,15 +318,20 @@ __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const float* __restri
     if (!dx && !dres) return;
     const float m1 = s1 / (float)cnt, m2 = s2 / (float)cnt;
     const float kk = rstd * (gamma ? gamma[c] : 1.f);
-    for (int n = wv; n < N; n += 4) {
-        const size_t base = ((size_t)n * C + c) * HW;
-        for (int k = ln; k < HW; k += 64) {
-            float g = dy[base + k];
-            if (act != PCGAN_ACT_NONE) g *= act_grad_from_out(y[base + k], act, slope);
-            if (dx) dx[base + k] = kk * (g - m1 - ((x[base + k] - mean) * rstd) * m2);
-            if (dres) dres[base + k] = g;
+    bn_for_each<V>(N, C, HW, c, [&](size_t i) {
+        const vec d = *reinterpret_cast<const vec*>(dy + i), xv = *reinterpret_cast<const vec*>(x + i);
+        vec yv, o, gr;
+        if (act != PCGAN_ACT_NONE) yv = *reinterpret_cast<const vec*>(y + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float g = d[e];
+            if (act != PCGAN_ACT_NONE) g *= act_grad_from_out(yv[e], act, slope);
+            gr[e] = g;
+            o[e] = kk * (g - m1 - ((xv[e] - mean) * rstd) * m2);
         }
-    }
+        if (dx) *reinterpret_cast<vec*>(dx + i) = o;
+        if (dres) *reinterpret_cast<vec*>(dres + i) = gr;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -557,8 +580,12 @@ extern "C" int pcgan_bn_fwd_fused(const float* x, const float* gamma, const floa
                                   float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches,
                                   int N, int C, int HW, float momentum, float eps, int act, float slope, pcgan_stream_t s) {
     PCGAN_CHECK(x && y && mean_c && var_c && N > 0 && C > 0 && HW > 0 && (long long)N * HW > 1, "bn_fwd_fused: bad arguments");
-    hipLaunchKernelGGL(bn_fwd_fused_kernel, dim3(C), dim3(256), 0, (hipStream_t)s, x, gamma, beta, residual, y, mean_c, var_c,
-                       running_mean, running_var, batches, N, C, HW, momentum, eps, act, slope);
+    if ((HW & 3) == 0)
+        hipLaunchKernelGGL(bn_fwd_fused_kernel<4>, dim3(C), dim3(256), 0, (hipStream_t)s, x, gamma, beta, residual, y, mean_c,
+                           var_c, running_mean, running_var, batches, N, C, HW, momentum, eps, act, slope);
+    else
+        hipLaunchKernelGGL(bn_fwd_fused_kernel<1>, dim3(C), dim3(256), 0, (hipStream_t)s, x, gamma, beta, residual, y, mean_c,
+                           var_c, running_mean, running_var, batches, N, C, HW, momentum, eps, act, slope);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -568,8 +595,12 @@ extern "C" int pcgan_bn_bwd_fused(const float* dy, const float* x, const float* 
                                   float eps, int act, float slope, pcgan_stream_t s) {
     PCGAN_CHECK(dy && x && mean_c && var_c && s1_c && s2_c && N > 0 && C > 0 && HW > 0, "bn_bwd_fused: bad arguments");
     PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "bn_bwd_fused: activation mask needs y");
-    hipLaunchKernelGGL(bn_bwd_fused_kernel, dim3(C), dim3(256), 0, (hipStream_t)s, dy, x, y, mean_c, var_c, gamma, dx, dres,
-                       s1_c, s2_c, N, C, HW, eps, act, slope);
+    if ((HW & 3) == 0)
+        hipLaunchKernelGGL(bn_bwd_fused_kernel<4>, dim3(C), dim3(256), 0, (hipStream_t)s, dy, x, y, mean_c, var_c, gamma, dx, dres,
+                           s1_c, s2_c, N, C, HW, eps, act, slope);
+    else
+        hipLaunchKernelGGL(bn_bwd_fused_kernel<1>, dim3(C), dim3(256), 0, (hipStream_t)s, dy, x, y, mean_c, var_c, gamma, dx, dres,
+                           s1_c, s2_c, N, C, HW, eps, act, slope);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
