@@ -237,3 +237,20 @@ def test_checkpoint_roundtrip_and_lr_schedule(tmp_path, dev):
     # one more step after the LR changed: the device-side lr follows
     model.optimize_parameters()
     assert abs(float(model.optimizer_G.lr_dev) - model.optimizer_G.param_groups[0]['lr']) < 1e-10
+
+
+def test_step_is_deterministic_with_streams(tmp_path, dev):
+    """Side stream (parameter gradients) and branch streams (D / IP / E in backward_G) must not change results: two
+    models built the same way and stepped three times end bit-identical."""
+    outs = []
+    for run in range(2):
+        model, opt = build_hip_model('default', tmp_path)
+        for it in range(3):
+            A, B, label = step_inputs(it % 2)
+            model.set_input({'A': A, 'B': B, 'label': torch.tensor(label), 'A_paths': ['a'] * 4, 'B_paths': ['b'] * 4})
+            model.optimize_parameters()
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().clone() for net in (model.netG, model.netD) for k, v in net.state_dict().items()}
+                    | {'fake_B': model.fake_B.detach().clone()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), 'run-to-run difference in ' + k
