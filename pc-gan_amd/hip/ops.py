@@ -80,7 +80,7 @@ class fork_side(object):
             try:    # join automatically when the running backward pass ends
                 torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
                 _side_state['queued'] = True
-            except RuntimeError:
+            except Exception:      # not inside a backward pass (or no such hook): FusedAdam.step / zero_grad join
                 pass
         return st
 
