@@ -55,20 +55,23 @@ class _Conv2dFn(torch.autograd.Function):
         if act != ACT_NONE:
             dy = ops.act_bwd(dy, y, act, slope)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_bwd_data(dy, w, (x.shape[2], x.shape[3]), stride, pad, pad_mode, pack_cache=ctx.pack)
         want_w = ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         wt = _fused_grad_target(ctx.params[0]) if want_w else None
         bt = _fused_grad_target(ctx.params[1]) if want_b else None
         if ops.SIDE_STREAM and (not want_w or wt is not None) and (not want_b or bt is not None) and (want_w or want_b):
-            # both go straight into the optimizer's gradient buffer: nobody in this backward pass reads them
+            # both go straight into the optimizer's gradient buffer: nobody in this backward pass reads them.  Forked
+            # BEFORE the data gradient is queued, so the two kernels of this layer may run side by side.
             with ops.fork_side(x, dy):
                 if want_w:
                     ops.conv2d_bwd_weight(x, dy, tuple(w.shape), stride, pad, pad_mode, accumulate_into=wt)
                 if want_b:
                     ops.channel_sum(dy, accumulate_into=bt)
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv2d_bwd_data(dy, w, (x.shape[2], x.shape[3]), stride, pad, pad_mode, pack_cache=ctx.pack)
             return dx, None, None, None, None, None, None, None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_bwd_data(dy, w, (x.shape[2], x.shape[3]), stride, pad, pad_mode, pack_cache=ctx.pack)
         if want_w:
             dw = ops.conv2d_bwd_weight(x, dy, tuple(w.shape), stride, pad, pad_mode, accumulate_into=wt)
             if wt is not None:
