@@ -156,6 +156,7 @@ def main():
         return
     ms_per_step = dt / args.steps * 1e3
     value = PER_GPU_BATCH * world * args.steps / dt
+    assert conv_launches > 0, 'the residual convolution was not launched inside the timed region'
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12
     out = {
         'metric': 'images/sec (G+D step) 128x128 bs32 per GPU', 'value': round(value, 3), 'unit': 'images/sec',
