@@ -204,6 +204,33 @@ int pcgan_adam_step_dev(float* param, const float* grad, float* exp_avg, float* 
                         const float* lr_dev, int* step_dev, float beta1, float beta2, float eps,
                         pcgan_stream_t s);
 
+/* ---- loader image pipeline ----------------------------------
+ * transforms.Resize([loadSize, loadSize], Image.BICUBIC) -> RandomCrop(fineSize) ->
+ * RandomHorizontalFlip -> ToTensor -> Normalize(.5, .5) of get_transform
+ * (data/base_dataset.py:24-64) and the RGB -> gray mix of the pair dataset
+ * (data/wsgan_emb_dataset.py:46-49), for n equally sized uint8 RGB images
+ * src[n][H][W][3] -> out[dst][out_channels][FH][FW] fp32.  Pillow's two-pass 22-bit
+ * fixed-point resampling (horizontal first, uint8 intermediate): the caller builds the
+ * coefficient tables kh[RW][ksize_h] / kv[RH][ksize_v] and bounds bh[RW][2] / bv[RH][2]
+ * (first source index, tap count) the way Pillow's precompute_coeffs /
+ * normalize_coeffs_8bpc do; a dimension that keeps its size gets the identity table
+ * (ksize 1, coefficient 1 << 22).  aug[n][4] (device) = crop x0, crop y0, flip, dst index;
+ * the caller guarantees 0 <= x0 <= RW - FW, 0 <= y0 <= RH - FH.  Integer arithmetic up to
+ * the last three correctly rounded fp32 operations: bit-exact with the PIL path.
+ * pcgan_image_transform_band (host only, bv_host in host memory) picks the band of output
+ * rows one workgroup takes and the LDS rows it needs. */
+typedef struct {
+    int H, W;     /* source image                     */
+    int RH, RW;   /* after the resize (loadSize)      */
+    int FH, FW;   /* after the crop (fineSize)        */
+    int ksize_h, ksize_v;
+    int out_channels; /* 3, or 1 = gray mix           */
+} pcgan_image_desc;
+int pcgan_image_transform_band(const pcgan_image_desc* d, const int32_t* bv_host, int* band, int* max_rows);
+int pcgan_image_transform(const pcgan_image_desc* d, const uint8_t* src, const int32_t* kh, const int32_t* bh,
+                          const int32_t* kv, const int32_t* bv, const int32_t* aug, float* out, int n, int band,
+                          int max_rows, pcgan_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,14 @@ def create_dataset(opt):
     return dataset
 
 
+def _collate_keep_raw(samples):
+    """default collate, except that decoded images ('*_raw', possibly of different sizes) stay a list"""
+    raw = {k: [s[k] for s in samples] for k in samples[0] if k.endswith('_raw')}
+    rest = torch.utils.data.default_collate([{k: v for k, v in s.items() if not k.endswith('_raw')} for s in samples])
+    rest.update(raw)
+    return rest
+
+
 class CustomDatasetDataLoader(object):
     """Iterable over dict batches, capped at --max_dataset_size samples (reference data/__init__.py:42-69)."""
 
@@ -35,9 +43,23 @@ class CustomDatasetDataLoader(object):
     def initialize(self, opt):
         self.opt = opt
         self.dataset = create_dataset(opt)
+        self.gpu_transform = None
+        if getattr(opt, 'gpu_transform', False) and opt.dataroot != 'synthetic':
+            from .gpu_transform import GpuTransform
+            self.gpu_transform = GpuTransform(opt, 'cuda:%d' % opt.gpu_ids[0] if opt.gpu_ids else 'cpu')
         self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=opt.batchSize, num_workers=int(opt.nThreads),
-                                                      shuffle=not opt.serial_batches)
+                                                      shuffle=not opt.serial_batches,
+                                                      collate_fn=_collate_keep_raw if self.gpu_transform else None)
         return self
+
+    def _finish_on_gpu(self, batch):
+        """'<key>_raw' + '<key>_aug' -> '<key>': one image-pipeline launch per image set (A with input_nc channels, B
+        with output_nc, the gray mix of the pair dataset included)"""
+        for raw_key in [k for k in batch if k.endswith('_raw')]:
+            key = raw_key[:-4]
+            channels = self.opt.input_nc if key.endswith('A') else self.opt.output_nc
+            batch[key] = self.gpu_transform(batch.pop(raw_key), batch.pop(key + '_aug'), out_channels=channels)
+        return batch
 
     def load_data(self):
         return self
@@ -51,7 +73,7 @@ class CustomDatasetDataLoader(object):
             if seen >= self.opt.max_dataset_size:
                 return
             seen += self.opt.batchSize
-            yield batch
+            yield self._finish_on_gpu(batch) if self.gpu_transform else batch
 
 
 def CreateDataLoader(opt):

@@ -43,3 +43,17 @@ def get_transform(opt):
         t = torch.from_numpy(arr.transpose(2, 0, 1).copy())
         return (t - 0.5) / 0.5
     return tf
+
+
+def decode_raw(img, opt):
+    """--gpu_transform: what a worker hands to the loader instead of the transformed tensor -- the decoded image as a
+    uint8 (H, W, 3) tensor and the (x0, y0, flip) draws of get_transform, taken from `random` in the same order."""
+    from .gpu_transform import draw_augmentation
+    if opt.transforms == 'resize_and_crop':
+        w = h = opt.loadSize
+    elif opt.transforms == 'crop':
+        w, h = img.size
+    else:
+        raise NotImplementedError('pcgan_amd: --transforms %s is outside the hot path' % opt.transforms)
+    aug = draw_augmentation(w, h, opt.fineSize, opt.isTrain and not opt.no_flip)
+    return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()), torch.tensor(aug, dtype=torch.int32)

@@ -1,0 +1,147 @@
+"""The loader's image pipeline on the GPU: decoded uint8 RGB images in, the fp32 NCHW batch the
+model's set_input reads out -- `Resize([loadSize, loadSize], BICUBIC) -> RandomCrop(fineSize) -> RandomHorizontalFlip
+-> ToTensor -> Normalize(.5, .5)` of the reference's get_transform (data/base_dataset.py:24-64) in ONE launch of
+`pcgan_image_transform` per batch of equally sized images (include/pcgan_hip.h).
+
+torchvision's Resize on a PIL image is Pillow's `Image.resize`; its resampling is a separable two-pass filter in 22-bit
+fixed point.  `resample_table` rebuilds Pillow's coefficient tables (libImaging/Resample.c: bicubic_filter,
+precompute_coeffs, normalize_coeffs_8bpc) in the same double arithmetic, the kernel applies them in integers, so the
+batch equals the PIL path bit for bit (tests/test_gpu_transform.py holds it to `Image.resize` itself).
+
+JPEG/PNG decoding stays in the DataLoader workers; what moves to the GPU is the per-pixel work (about 1 ms per image
+and core with PIL at 200x200 -> 143x143 -> 128x128).
+"""
+import ctypes
+import math
+import random
+
+import numpy as np
+import torch
+
+from ..hip import lib as _L
+
+PRECISION_BITS = 32 - 8 - 2     # Resample.c
+
+
+def _bicubic(x):
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def resample_table(in_size, out_size):
+    """(coefficients int32 [out][ksize], bounds int32 [out][2], ksize) of Pillow's bicubic resampling of a whole
+    axis from in_size to out_size; the identity table when the size does not change (Pillow skips that pass)."""
+    if in_size == out_size:
+        k = np.full((out_size, 1), 1 << PRECISION_BITS, dtype=np.int32)
+        b = np.stack([np.arange(out_size, dtype=np.int32), np.ones(out_size, dtype=np.int32)], axis=1)
+        return k, np.ascontiguousarray(b), 1
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << PRECISION_BITS))
+        bounds[xx, 0], bounds[xx, 1] = xmin, xmax
+    return kk, bounds, ksize
+
+
+def draw_augmentation(w, h, fine, flip_enabled):
+    """crop offsets and flip of ONE image, drawn from `random` in the order the PIL path draws them"""
+    x0 = random.randint(0, w - fine) if w > fine else 0
+    y0 = random.randint(0, h - fine) if h > fine else 0
+    flip = 1 if (flip_enabled and random.random() < 0.5) else 0
+    return x0, y0, flip
+
+
+class _Geometry(object):
+    """device-resident tables of one (source size -> resized size -> crop size)"""
+
+    def __init__(self, H, W, RH, RW, fine, out_channels, device):
+        kh, bh, ksh = resample_table(W, RW)
+        kv, bv, ksv = resample_table(H, RH)
+        self.desc = _L.ImageDesc(H, W, RH, RW, fine, fine, ksh, ksv, out_channels)
+        band, rows = ctypes.c_int(0), ctypes.c_int(0)
+        bv = np.ascontiguousarray(bv)
+        _L.check(_L.load().pcgan_image_transform_band(ctypes.byref(self.desc), bv.ctypes.data_as(ctypes.c_void_p),
+                                                      ctypes.byref(band), ctypes.byref(rows)), 'image_transform_band')
+        self.band, self.rows = band.value, rows.value
+        self.kh, self.bh, self.kv, self.bv = (torch.from_numpy(np.ascontiguousarray(t)).to(device) for t in (kh, bh, kv, bv))
+
+
+class GpuTransform(object):
+    """callable: list of uint8 (H, W, 3) tensors + per-image (x0, y0, flip) -> float (n, C, fine, fine) on `device`"""
+
+    def __init__(self, opt, device):
+        if opt.transforms not in ('resize_and_crop', 'crop'):
+            raise NotImplementedError('pcgan_amd: --transforms %s is outside the hot path' % opt.transforms)
+        self.load = opt.loadSize if opt.transforms == 'resize_and_crop' else None
+        self.fine = opt.fineSize
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('pcgan_amd: the GPU image pipeline needs a GPU device (got %s); there is no fallback' % device)
+        self._geo = {}
+
+    def resized(self, h, w):
+        return (self.load, self.load) if self.load else (h, w)
+
+    def geometry(self, H, W, out_channels):
+        key = (H, W, out_channels)
+        if key not in self._geo:
+            RH, RW = self.resized(H, W)
+            if RH < self.fine or RW < self.fine:
+                raise ValueError('image %dx%d (resized %dx%d) is smaller than --fineSize %d' % (H, W, RH, RW, self.fine))
+            self._geo[key] = _Geometry(H, W, RH, RW, self.fine, out_channels, self.device)
+        return self._geo[key]
+
+    def __call__(self, images, aug, out_channels=3):
+        n = len(images)
+        aug = torch.as_tensor(aug, dtype=torch.int32).reshape(n, 3)
+        out = torch.empty((n, out_channels, self.fine, self.fine), dtype=torch.float32, device=self.device)
+        groups = {}
+        for i, im in enumerate(images):
+            if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
+                raise ValueError('GpuTransform: image %d is not a uint8 (H, W, 3) tensor' % i)
+            groups.setdefault((int(im.shape[0]), int(im.shape[1])), []).append(i)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        for (H, W), idx in groups.items():
+            g = self.geometry(H, W, out_channels)
+            RH, RW = self.resized(H, W)
+            a = torch.empty((len(idx), 4), dtype=torch.int32)
+            a[:, :3] = aug[idx]
+            a[:, 3] = torch.as_tensor(idx, dtype=torch.int32)
+            # the kernel trusts the offsets: check them where they are still host data
+            if int(a[:, 0].min()) < 0 or int(a[:, 0].max()) > RW - self.fine or int(a[:, 1].min()) < 0 \
+                    or int(a[:, 1].max()) > RH - self.fine:
+                raise ValueError('GpuTransform: crop offset outside the resized image')
+            src = torch.stack([images[i] for i in idx]).contiguous().to(self.device, non_blocking=True)
+            a_dev = a.to(self.device, non_blocking=True)
+            _L.check(_L.load().pcgan_image_transform(
+                ctypes.byref(g.desc), src.data_ptr(), g.kh.data_ptr(), g.bh.data_ptr(), g.kv.data_ptr(), g.bv.data_ptr(),
+                a_dev.data_ptr(), out.data_ptr(), len(idx), g.band, g.rows, stream), 'image_transform')
+            src.record_stream(torch.cuda.current_stream(self.device))
+            a_dev.record_stream(torch.cuda.current_stream(self.device))
+        return out

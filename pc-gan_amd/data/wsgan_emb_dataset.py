@@ -8,7 +8,7 @@ import random
 
 import torch
 
-from .base_dataset import BaseDataset, get_transform
+from .base_dataset import BaseDataset, get_transform, decode_raw
 
 
 class WSGANEmbDataset(BaseDataset):
@@ -37,11 +37,17 @@ class WSGANEmbDataset(BaseDataset):
         else:
             self.size = min(len(self.sourcefile), opt.max_dataset_size)
         self.transform = get_transform(opt)
+        self.raw = bool(getattr(opt, 'gpu_transform', False))
 
     def _pair(self, line):
         from PIL import Image
         a, b, lab = line.split()[:3]
         pa, pb = os.path.join(self.root, a), os.path.join(self.root, b)
+        if self.raw:
+            # workers only decode and draw the augmentation (same draws, same order as the PIL path); the per-pixel work
+            # is one launch per batch in the loader (gpu_transform.py), which also does the gray mix
+            A, B = decode_raw(Image.open(pa).convert('RGB'), self.opt), decode_raw(Image.open(pb).convert('RGB'), self.opt)
+            return A, B, int(lab), pa, pb
         A = self.transform(Image.open(pa).convert('RGB'))
         B = self.transform(Image.open(pb).convert('RGB'))
         if self.opt.input_nc == 1:
@@ -62,11 +68,17 @@ class WSGANEmbDataset(BaseDataset):
                     'B_paths': 'synthetic_B_%d' % index}
         if not o.no_mixed_label_D:
             A, B, lab, pa, pb = self._pair(self.sourcefile[index])
+            if self.raw:
+                return {'A_raw': A[0], 'A_aug': A[1], 'B_raw': B[0], 'B_aug': B[1], 'label': lab, 'A_paths': pa, 'B_paths': pb}
             return {'A': A, 'B': B, 'label': lab, 'A_paths': pa, 'B_paths': pb}
         ret = {}
         for L, lines in self.sourcefiles.items():
             A, B, _, pa, pb = self._pair(lines[index % len(lines)])
-            ret[str(L) + '_A'], ret[str(L) + '_B'] = A, B
+            if self.raw:
+                ret[str(L) + '_A_raw'], ret[str(L) + '_A_aug'] = A
+                ret[str(L) + '_B_raw'], ret[str(L) + '_B_aug'] = B
+            else:
+                ret[str(L) + '_A'], ret[str(L) + '_B'] = A, B
             ret[str(L) + '_A_paths'], ret[str(L) + '_B_paths'] = pa, pb
         return ret
 

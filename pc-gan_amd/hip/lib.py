@@ -14,6 +14,11 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PASS_FWD, PASS_BWD_DATA, PASS_BWD_WEIGHT = 0, 1, 2
 
 
+class ImageDesc(ctypes.Structure):
+    """pcgan_image_desc (include/pcgan_hip.h)."""
+    _fields_ = [(n, ctypes.c_int) for n in ('H', 'W', 'RH', 'RW', 'FH', 'FW', 'ksize_h', 'ksize_v', 'out_channels')]
+
+
 class ConvDesc(ctypes.Structure):
     """pcgan_conv_desc (include/pcgan_hip.h)."""
     _fields_ = [(n, ctypes.c_int) for n in
@@ -22,6 +27,7 @@ class ConvDesc(ctypes.Structure):
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 _dp = ctypes.POINTER(ConvDesc)
+_ip = ctypes.POINTER(ImageDesc)
 
 # name -> (restype, argtypes); kept in one table so tests can check that the library
 # exports every symbol the header declares.
@@ -67,6 +73,8 @@ SIGNATURES = {
     'pcgan_loss_workspace_bytes': (_sz, [_sz]),
     'pcgan_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _vp]),
     'pcgan_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _f, _f, _f, _vp]),
+    'pcgan_image_transform_band': (_i, [_ip, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    'pcgan_image_transform': (_i, [_ip, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 
 _lib = None

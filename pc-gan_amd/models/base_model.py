@@ -58,7 +58,7 @@ class BaseModel(object):
         """learning-rate schedulers (training); weights from disk (testing or --continue_train); network summary"""
         if self.isTrain:
             self.schedulers = [networks.get_scheduler(o, opt) for o in self.optimizers]
-        if opt.continue_train or not self.isTrain:
+        if not self.isTrain or opt.continue_train:
             self.load_networks(opt.which_epoch)
         self.print_networks(opt.verbose)
 

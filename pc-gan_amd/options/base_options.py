@@ -3,7 +3,7 @@
 then the dataset's; `parse()` resolves gpu_ids / attr_bins and writes opt_<phase>.txt and
 cmd_<phase>.txt under <checkpoints_dir>/<name>/.
 
-Build-only additions (do not change any existing name): --seed, --local_rank.  Under torchrun
+Build-only additions (do not change any existing name): --seed, --local_rank, --gpu_transform.  Under torchrun
 (LOCAL_RANK set) gpu_ids becomes [LOCAL_RANK]: one process drives one GPU.
 """
 import argparse
@@ -67,6 +67,8 @@ _BASE_FLAGS = [
     # build-only
     ('--seed', dict(type=int, default=None, help='(pcgan_amd) seed torch/numpy if given')),
     ('--local_rank', dict(type=int, default=None, help='(pcgan_amd) set by launchers; LOCAL_RANK env wins')),
+    ('--gpu_transform', dict(action='store_true', help='(pcgan_amd) resize / crop / flip / normalise on the GPU '
+                                                       '(bit-exact with the PIL path); workers only decode')),
 ]
 
 

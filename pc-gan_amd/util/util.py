@@ -106,3 +106,9 @@ def tensor2im(image, imtype=np.uint8):
     if arr.shape[0] == 1:
         arr = np.tile(arr, (3, 1, 1))
     return ((np.transpose(arr, (1, 2, 0)) + 1) / 2.0 * 255.0).astype(imtype)
+
+
+def save_image(image_numpy, image_path):
+    """reference util/util.py:43-45"""
+    from PIL import Image
+    Image.fromarray(image_numpy).save(image_path)
