@@ -8,8 +8,8 @@ fixed point.  `resample_table` rebuilds Pillow's coefficient tables (libImaging/
 precompute_coeffs, normalize_coeffs_8bpc) in the same double arithmetic, the kernel applies them in integers, so the
 batch equals the PIL path bit for bit (tests/test_gpu_transform.py holds it to `Image.resize` itself).
 
-JPEG/PNG decoding stays in the DataLoader workers; what moves to the GPU is the per-pixel work (about 1 ms per image
-and core with PIL at 200x200 -> 143x143 -> 128x128).
+JPEG/PNG decoding stays in the DataLoader workers; what moves to the GPU is the per-pixel work (4.7 ms per image and
+core with PIL at 200x200 -> 143x143 -> 128x128 on the MI355X box's host, scripts/bench_transform.py).
 """
 import ctypes
 import math
@@ -104,6 +104,7 @@ class GpuTransform(object):
         if self.device.type != 'cuda':
             raise RuntimeError('pcgan_amd: the GPU image pipeline needs a GPU device (got %s); there is no fallback' % device)
         self._geo = {}
+        self._stage = {}        # (H, W) -> reusable host buffer uint8 (cap, H, W, 3)
 
     def resized(self, h, w):
         return (self.load, self.load) if self.load else (h, w)
@@ -116,6 +117,18 @@ class GpuTransform(object):
                 raise ValueError('image %dx%d (resized %dx%d) is smaller than --fineSize %d' % (H, W, RH, RW, self.fine))
             self._geo[key] = _Geometry(H, W, RH, RW, self.fine, out_channels, self.device)
         return self._geo[key]
+
+    def _upload(self, images, H, W):
+        """decoded bytes -> one reusable host buffer per source size (numpy row copies: torch's copy_ would fork its
+        whole intra-op thread pool for every 120 KB image, 0.24 ms each on a 128-thread host) -> one copy to the GPU
+        (measured on the MI355X box: 0.2 ms + 0.15 ms for 64 images of 200x200, scripts/diag_h2d.py)"""
+        n = len(images)
+        buf = self._stage.get((H, W))
+        if buf is None or buf.shape[0] < n:
+            buf = self._stage[(H, W)] = np.empty((n, H, W, 3), dtype=np.uint8)
+        for j, im in enumerate(images):
+            buf[j] = im.numpy()
+        return torch.from_numpy(buf[:n]).to(self.device)     # blocking copy: the buffer is free again on return
 
     def __call__(self, images, aug, out_channels=3):
         n = len(images)
@@ -137,11 +150,10 @@ class GpuTransform(object):
             if int(a[:, 0].min()) < 0 or int(a[:, 0].max()) > RW - self.fine or int(a[:, 1].min()) < 0 \
                     or int(a[:, 1].max()) > RH - self.fine:
                 raise ValueError('GpuTransform: crop offset outside the resized image')
-            src = torch.stack([images[i] for i in idx]).contiguous().to(self.device, non_blocking=True)
+            src = self._upload([images[i] for i in idx], H, W)
             a_dev = a.to(self.device, non_blocking=True)
             _L.check(_L.load().pcgan_image_transform(
                 ctypes.byref(g.desc), src.data_ptr(), g.kh.data_ptr(), g.bh.data_ptr(), g.kv.data_ptr(), g.bv.data_ptr(),
                 a_dev.data_ptr(), out.data_ptr(), len(idx), g.band, g.rows, stream), 'image_transform')
-            src.record_stream(torch.cuda.current_stream(self.device))
             a_dev.record_stream(torch.cuda.current_stream(self.device))
         return out

@@ -59,3 +59,12 @@ for im in pimgs:
     pil(im)
 dt = (time.perf_counter() - t0)
 print('PIL path, 1 core: %.2f ms per image = %.0f images/s' % (dt / n * 1e3, n / dt))
+if os.environ.get('PCGAN_PROFILE_HOST'):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(20):
+        tf(imgs, aug)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats('tottime').print_stats(14)

@@ -165,4 +165,4 @@ def test_image_transform_argument_checks():
     d = lib.ImageDesc(200, 200, 143, 143, 128, 128, 7, 7, 3)
     bv = np.ascontiguousarray(bv)
     assert h.pcgan_image_transform_band(ctypes.byref(d), bv.ctypes.data_as(ctypes.c_void_p), ctypes.byref(band), ctypes.byref(rows)) == 0
-    assert band.value == 32 and 32 * 200 / 143 <= rows.value <= 32 * 200 / 143 + 8 and rows.value * 128 * 3 <= 48 * 1024
+    assert band.value == 16 and 16 * 200 / 143 <= rows.value <= 16 * 200 / 143 + 8
