@@ -316,6 +316,35 @@ def golden_ints(outdir):
     print('ints.npz labels', labels)
 
 
+def golden_fid(outdir):
+    """Frechet distance (compute_fid_score.py:126-205) on seeded Gaussians' statistics, incl. a rank-deficient pair that
+    takes the eps branch.  The reference module imports `scipy.misc.imread` (removed from SciPy) and
+    `torchvision.models` at its top without touching them in these two functions: ordinary missing-module stubs."""
+    import scipy
+    if 'scipy.misc' not in sys.modules:
+        misc = types.ModuleType('scipy.misc')
+        misc.imread = None
+        sys.modules['scipy.misc'] = misc
+        scipy.misc = misc
+    if 'torchvision.models' not in sys.modules:
+        sys.modules['torchvision.models'] = types.ModuleType('torchvision.models')
+        sys.modules['torchvision'].models = sys.modules['torchvision.models']
+    import compute_fid_score as ref_fid
+    rng = np.random.default_rng(2024)
+    out = {}
+    cases = [(8, 40), (16, 200), (64, 500), (32, 20)]          # (dims, samples); the last one is rank deficient
+    for i, (d, n) in enumerate(cases):
+        a = rng.normal(size=(n, d)) @ rng.normal(size=(d, d)) + rng.normal(size=d)
+        b = rng.normal(size=(n, d)) * rng.uniform(0.5, 2.0, size=d) + rng.normal(size=d) * 0.3
+        m1, s1 = a.mean(axis=0), np.cov(a, rowvar=False)
+        m2, s2 = b.mean(axis=0), np.cov(b, rowvar=False)
+        out['act1_%d' % i], out['act2_%d' % i] = a, b
+        out['fid_%d' % i] = np.float64(ref_fid.calculate_frechet_distance(m1, s1, m2, s2))
+        out['fid_self_%d' % i] = np.float64(ref_fid.calculate_frechet_distance(m1, s1, m1, s1))
+    np.savez(os.path.join(outdir, 'fid.npz'), **out)
+    print('fid.npz', [float(out['fid_%d' % i]) for i in range(len(cases))], [float(out['fid_self_%d' % i]) for i in range(len(cases))])
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
@@ -334,3 +363,5 @@ if __name__ == '__main__':
         golden_cycle_step(rn, a.out)
     if a.only in ('', 'siamese'):
         golden_siamese(rn, a.out)
+    if a.only in ('', 'fid'):
+        golden_fid(a.out)

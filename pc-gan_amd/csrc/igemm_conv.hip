@@ -1247,26 +1247,37 @@ __global__ void repack_bwd_multi_kernel(PackBwdArgs a) {
 }
 
 // fold the gradient of a reflection-padded tensor back onto the unpadded tensor
+// grid = (row groups, planes): one thread = 4 consecutive pixels of one row, plane-local 32-bit index math
 __global__ void reflect_fold_kernel(const float* __restrict__ t, float* __restrict__ dx, int NC, int H, int W,
                                     int pad) {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    const size_t total = (size_t)NC * H * W;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W);
-        const int y = (int)((i / W) % H);
-        const size_t nc = i / ((size_t)W * H);
-        int ys[3], xs[3], ny = 0, nx = 0;
+    const int W4 = (W + 3) >> 2;
+    const float* tp = t + (size_t)blockIdx.y * Hp * Wp;
+    float* dp = dx + (size_t)blockIdx.y * H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W4; i += gridDim.x * blockDim.x) {
+        const int y = i / W4, x0 = (i - y * W4) * 4;
+        int ys[3], ny = 0;
         ys[ny++] = y + pad;
         if (y >= 1 && y <= pad) ys[ny++] = pad - y;
         if (y >= H - 1 - pad && y <= H - 2) ys[ny++] = pad + 2 * (H - 1) - y;
-        xs[nx++] = x + pad;
-        if (x >= 1 && x <= pad) xs[nx++] = pad - x;
-        if (x >= W - 1 - pad && x <= W - 2) xs[nx++] = pad + 2 * (W - 1) - x;
-        const float* tp = t + nc * Hp * Wp;
-        float acc = 0.f;
-        for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) acc += tp[ys[a] * Wp + xs[b]];
-        dx[i] = acc;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a) {
+            const float* row = tp + ys[a] * Wp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = x0 + j;
+                if (x >= W) continue;
+                float v = row[x + pad];
+                if (x >= 1 && x <= pad) v += row[pad - x];
+                if (x >= W - 1 - pad && x <= W - 2) v += row[pad + 2 * (W - 1) - x];
+                acc[j] += v;
+            }
+        }
+        if ((W & 3) == 0) {
+            *reinterpret_cast<float4*>(dp + y * W + x0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
+            for (int j = 0; j < 4 && x0 + j < W; ++j) dp[y * W + x0 + j] = acc[j];
+        }
     }
 }
 
@@ -2386,10 +2397,10 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     if (fused ? launch_igemm<MODE_BWD_REFLECT>(a, st, part, bwd_part_bytes(d)) : launch_igemm<MODE_BWD>(a, st, part, bwd_part_bytes(d)))
         return 2;
     if (reflect) {
-        const size_t total = (size_t)d->N * d->C * d->H * d->W;
-        const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-        hipLaunchKernelGGL(reflect_fold_kernel, dim3(blocks), dim3(256), 0, st, out, dx, d->N * d->C, d->H,
-                           d->W, d->pad);
+        PCGAN_CHECK(d->N * d->C <= 65535, "conv2d_bwd_data: more than 65535 planes in the reflect fold");
+        const int per_plane = d->H * ((d->W + 3) / 4);
+        hipLaunchKernelGGL(reflect_fold_kernel, dim3((per_plane + 255) / 256, d->N * d->C), dim3(256), 0, st, out, dx,
+                           d->N * d->C, d->H, d->W, d->pad);
         PCGAN_LAUNCH_CHECK();
     }
     return 0;

@@ -35,3 +35,68 @@ def test_test_py_writes_results(dev, tmp_path):
     page = open(tmp_path / 'res' / 'run' / 'test_latest' / 'index.html').read()
     assert page.count('<h3>') == 3 and names[0] in page
     assert os.path.exists(ck / 'test_net_G.pth')
+
+
+def _write_pairs(root, n=8, size=(50, 50)):
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 256, size + (3,), dtype=np.uint8)).save(root / ('img_%d.png' % i))
+    with open(root / 'pairs.txt', 'w') as f:
+        for i in range(n):
+            f.write('img_%d.png img_%d.png %d\n' % (i, (i + 3) % n, (0, 2)[i % 2]))
+
+
+def test_train_py_on_image_files_same_losses_with_gpu_transform(dev, tmp_path):
+    """train.py on a pair file of PNGs: the PIL loader and --gpu_transform feed bit-identical batches, so the loss
+    lines of the two runs (same seed) are identical"""
+    import re
+    import torch
+    from pcgan_amd.models import networks
+    _write_pairs(tmp_path)
+    torch.manual_seed(0)
+    E = networks.define_E('resnet18', 3, 'normal', 'avg', [32, 1], 1, 0.7)
+    IP = networks.define_IP('alexnet', 3)
+    torch.save(E.state_dict(), tmp_path / 'E.pth')
+    torch.save(IP.state_dict(), tmp_path / 'IP.pth')
+    logs = []
+    for extra in ([], ['--gpu_transform']):
+        name = 'run_gpu' if extra else 'run_pil'
+        cmd = [sys.executable, os.path.join(ROOT, 'train.py'), '--dataroot', str(tmp_path), '--sourcefile_A', str(tmp_path / 'pairs.txt'),
+               '--model', 'wsgan_emb', '--name', name, '--checkpoints_dir', str(tmp_path / 'ck'), '--which_model_netG', 'resnet_2blocks',
+               '--which_model_netD', 'n_layers', '--n_layers_D', '3', '--ngf', '8', '--ndf', '8', '--loadSize', '40', '--fineSize', '32',
+               '--fineSize_E', '64', '--fineSize_IP', '64', '--batchSize', '4', '--nThreads', '0', '--niter', '1', '--niter_decay', '0',
+               '--print_freq', '1', '--display_id', '-1', '--seed', '3', '--serial_batches', '--pretrained_model_path_E', str(tmp_path / 'E.pth'),
+               '--pretrained_model_path_IP', str(tmp_path / 'IP.pth'), '--gpu_ids', '0'] + extra
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        lines = [re.sub(r'time: [0-9.]+, data: [0-9.]+', '', l) for l in open(tmp_path / 'ck' / name / 'loss_log.txt') if l.startswith('(epoch')]
+        assert len(lines) == 2, lines
+        logs.append(lines)
+        assert os.path.exists(tmp_path / 'ck' / name / 'latest_net_G.pth')
+    assert logs[0] == logs[1]
+
+
+def test_compute_fid_score_alexnet_features(dev, tmp_path):
+    """compute_fid_score.py on image directories with the HIP AlexNet as the feature extractor: a set against itself is 0,
+    against a different set positive; .npz statistics reproduce the value"""
+    import re
+    import torch
+    from PIL import Image
+    from pcgan_amd.models import networks
+    rng = np.random.default_rng(9)
+    for name, lo in (('a', 0), ('b', 96)):
+        os.makedirs(tmp_path / name)
+        for i in range(12):
+            Image.fromarray(rng.integers(lo, lo + 160, (32, 32, 3), dtype=np.uint8)).save(tmp_path / name / ('%02d.png' % i))
+    torch.manual_seed(1)
+    torch.save(networks.define_IP('alexnet', 3).state_dict(), tmp_path / 'IP.pth')
+
+    def run(p1, p2):
+        cmd = [sys.executable, os.path.join(ROOT, 'compute_fid_score.py'), str(p1), str(p2), '--features', 'alexnet', '--batch-size', '4',
+               '--pretrained_model_path_IP', str(tmp_path / 'IP.pth')]
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        return float(re.search(r': ([-0-9.e]+)\s*$', p.stdout.strip()).group(1))
+    same, diff = run(tmp_path / 'a', tmp_path / 'a'), run(tmp_path / 'a', tmp_path / 'b')
+    assert abs(same) < 1e-3 * max(1.0, abs(diff)) and diff > 0
