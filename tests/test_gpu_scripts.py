@@ -66,7 +66,7 @@ def test_train_py_on_image_files_same_losses_with_gpu_transform(dev, tmp_path):
                '--model', 'wsgan_emb', '--name', name, '--checkpoints_dir', str(tmp_path / 'ck'), '--which_model_netG', 'resnet_2blocks',
                '--which_model_netD', 'n_layers', '--n_layers_D', '3', '--ngf', '8', '--ndf', '8', '--loadSize', '40', '--fineSize', '32',
                '--fineSize_E', '64', '--fineSize_IP', '64', '--batchSize', '4', '--nThreads', '0', '--niter', '1', '--niter_decay', '0',
-               '--print_freq', '1', '--display_id', '-1', '--seed', '3', '--serial_batches', '--pretrained_model_path_E', str(tmp_path / 'E.pth'),
+               '--print_freq', '1', '--save_epoch_freq', '1', '--display_id', '-1', '--seed', '3', '--serial_batches', '--pretrained_model_path_E', str(tmp_path / 'E.pth'),
                '--pretrained_model_path_IP', str(tmp_path / 'IP.pth'), '--gpu_ids', '0'] + extra
         p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
