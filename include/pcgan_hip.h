@@ -231,6 +231,17 @@ int pcgan_image_transform(const pcgan_image_desc* d, const uint8_t* src, const i
                           const int32_t* kv, const int32_t* bv, const int32_t* aug, float* out, int n, int band,
                           int max_rows, pcgan_stream_t s);
 
+/* ---- experiment: fp32-accurate convolution forward on the bf16 matrix pipe -----------
+ * Same call sites as pcgan_conv2d_fwd_packed for stride-1 convolutions with C % 16 == 0, K >= 32, at most 25 taps
+ * (the ResnetBlock convolutions, models/networks.py:621-648).  Every fp32 operand is split exactly into three bf16
+ * pieces and the six piece products that matter are accumulated in fp32 (v_mfma_f32_32x32x16_bf16): error as the fp32
+ * MFMA path (scripts/micro/bf16_split.hip).  Opt-in on the host side (PCGAN_BF16X6=1); pack once per weight version. */
+int pcgan_conv2d_bsplit_supported(const pcgan_conv_desc* d);
+size_t pcgan_conv2d_bsplit_packed_bytes(const pcgan_conv_desc* d);
+int pcgan_conv2d_bsplit_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s);
+int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y,
+                            int act, float slope, pcgan_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

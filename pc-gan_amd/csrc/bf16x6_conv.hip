@@ -1,0 +1,264 @@
+// EXPERIMENT (opt-in, PCGAN_BF16X6=1): stride-1 convolution forward with fp32 accuracy on the bf16 matrix pipe.
+//
+// An fp32 value is the exact sum of three bf16 pieces, x = h + m + l (8 + 8 + 8 significand bits).  A product a*b then needs
+// the piece pairs (h,h) | (h,m) (m,h) | (h,l) (m,m) (l,h) to keep every term above 2^-24 |a||b|; everything is accumulated in
+// the fp32 accumulators of v_mfma_f32_32x32x16_bf16.  scripts/micro/bf16_split measures, for K = 2304 (the residual-block
+// convolution): relative L2 error 7.0e-7 against float64, fp32 MFMA 6.1e-7; sustained rate of the six instructions that stand
+// for one fp32 K = 16 step 304 TFLOP/s fp32-equivalent against 155 TFLOP/s of v_mfma_f32_32x32x2_f32.
+//
+// Replaces the same call sites as the fp32 implicit GEMM (nn.ReflectionPad2d + nn.Conv2d of the ResnetBlocks,
+// models/networks.py:621-648; stride-1 nn.Conv2d elsewhere) when the gathered channel count is a multiple of 16.
+//
+// Y[m][pix] = sum_k A[m][k] * G(k, pix), K ordered (16-channel chunk, tap, channel).  Workgroup = 128 output channels x 128
+// pixels, 4 waves of 64 x 64 (2 x 2 accumulators), one K stage = 16 channels of one tap:
+//   weights  pre-split by the pack kernel, stored [piece][M tile][stage][k half][128 rows][8 bf16]: a stage is 3 coalesced
+//            16-byte loads per thread that go to LDS unchanged;
+//   pixels   8 channels of one pixel per thread (lanes along pixels: coalesced), split into the three pieces in registers,
+//            three 16-byte LDS writes;
+//   LDS      [piece][k half][row or pixel][8 bf16]: every access 16 bytes, 16 consecutive lanes = 256 contiguous bytes;
+//   per wave and stage 12 ds_read_b128 and 24 MFMAs (smallest terms first); loads run two stages ahead, one barrier per stage.
+#include "common.h"
+
+namespace pcgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static constexpr unsigned BS_OOB = 0x80000000u;
+static constexpr int BS_MAXTAP = 25;
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+struct BsplitArgs {
+    const float* X;      // [N][C][H][W]
+    const void* A;       // packed weights, see above
+    const float* bias;   // [M] or null
+    float* Y;            // [N][M][P][Q]
+    int N, C, H, W, M, R, S, pad, reflect, P, Q;
+    int nMt, nst, act;
+    float slope;
+    unsigned x_bytes, a_bytes;
+};
+
+// weights w[M][C][R][S] -> [piece][mt][stage][half][128][8] bf16, stage = chunk * T + tap, k in stage = channel in chunk
+__global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int M, int C, int T, int nMt, int nst) {
+    const size_t per_piece = (size_t)nMt * nst * 2048;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_piece; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), row = (int)((i >> 3) & 127), half = (int)((i >> 10) & 1);
+        const size_t q = i >> 11;
+        const int st = (int)(q % nst), mt = (int)(q / nst);
+        const int m = mt * 128 + row, c = (st / T) * 16 + half * 8 + j, tap = st % T;
+        const float v = m < M ? w[((size_t)m * C + c) * T + tap] : 0.f;
+        __bf16 h, mm, l;
+        split3(v, h, mm, l);
+        A[i] = h;
+        A[per_piece + i] = mm;
+        A[2 * per_piece + i] = l;
+    }
+}
+
+template <bool REFLECT>
+__global__ void __launch_bounds__(256) bsplit_conv_fwd_kernel(BsplitArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16x8 As[2][3][256];   // [buffer][piece][half * 128 + row]
+    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][3][256];   // [buffer][piece][half * 128 + pixel]
+    __shared__ unsigned offT[BS_MAXTAP][128];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wp = wave & 1;
+    const int mt = blockIdx.x % a.nMt, pt = blockIdx.x / a.nMt;
+    const int T = a.R * a.S, PQ = a.P * a.Q, Ptot = a.N * PQ;
+    const int HW4 = a.H * a.W * 4;
+    const int pl = tid & 127;
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+
+    // gather offsets (bytes, channel 0) of this workgroup's 128 pixels for every tap
+    {
+        const int pg = pt * 128 + pl;
+        const bool pv = pg < Ptot;
+        const int n = pv ? pg / PQ : 0, rem = pv ? pg - n * PQ : 0;
+        const int py = rem / a.Q, px = rem - py * a.Q;
+        for (int t = half; t < T; t += 2) {
+            const int r = t / a.S, s = t - r * a.S;
+            int iy = py - a.pad + r, ix = px - a.pad + s;
+            bool ok = pv;
+            if (REFLECT) {
+                iy = iy < 0 ? -iy : iy;
+                iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+                ix = ix < 0 ? -ix : ix;
+                ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+            } else {
+                ok = ok & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+            }
+            offT[t][pl] = ok ? ((unsigned)n * (unsigned)a.C * (unsigned)(a.H * a.W) + (unsigned)(iy * a.W + ix)) * 4u : BS_OOB;
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)a.a_bytes, 0x00020000);
+    const unsigned piece_bytes = (unsigned)a.nMt * (unsigned)a.nst * 4096u;
+    const unsigned a_tile = (unsigned)mt * (unsigned)a.nst * 4096u;
+
+    struct Stage {
+        u32x4 ap[3];
+        float b[8];
+    };
+    auto load = [&](Stage& r, int s) {
+        const bool live = s < a.nst;
+        const int cc = s / T, tap = s - cc * T;
+        const unsigned avo = live ? (unsigned)tid * 16u : BS_OOB;
+        const unsigned aso = a_tile + (unsigned)(live ? s : 0) * 4096u;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) r.ap[p] = __builtin_amdgcn_raw_buffer_load_b128(rA, avo, aso + p * piece_bytes, 0);
+        const unsigned bvo = live ? offT[tap][pl] : BS_OOB;
+        const unsigned bso = live ? (unsigned)(cc * 16 + half * 8) * (unsigned)HW4 : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, bvo, bso + j * HW4, 0));
+    };
+    auto stash = [&](const Stage& r, int buf) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&As[buf][p][tid]) = r.ap[p];
+        bf16x8 h, m, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 x, y, z;
+            split3(r.b[j], x, y, z);
+            h[j] = x;
+            m[j] = y;
+            l[j] = z;
+        }
+        Bs[buf][0][tid] = h;
+        Bs[buf][1][tid] = m;
+        Bs[buf][2][tid] = l;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        bf16x8 A[3][2], B[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                A[p][i] = As[buf][p][hi * 128 + wm * 64 + i * 32 + lo];
+                B[p][i] = Bs[buf][p][hi * 128 + wp * 64 + i * 32 + lo];
+            }
+        // smallest terms first: (l,h) (h,l) (m,m) | (m,h) (h,m) | (h,h); the four accumulators take turns, so consecutive
+        // MFMAs are independent
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[q]][i], B[PB[q]][j], acc[i][j], 0, 0, 0);
+    };
+
+    // loads run two stages ahead of the MFMAs; the stage pair is unrolled so both register sets are static.  An odd stage
+    // count is rounded up: the dead stage loads zeros (out-of-range offsets) and adds nothing.
+    Stage r0, r1;
+    load(r0, 0);
+    load(r1, 1);
+    stash(r0, 0);
+    __syncthreads();
+    const int nst2 = (a.nst + 1) & ~1;
+    for (int s = 0; s < nst2; s += 2) {
+        load(r0, s + 2);
+        compute(0);
+        stash(r1, 1);
+        __syncthreads();
+        load(r1, s + 3);
+        compute(1);
+        stash(r0, 0);
+        __syncthreads();
+    }
+
+    // epilogue: acc[i][j][r] = Y[m0 + wm*64 + i*32 + (r/4)*8 + hi*4 + r%4][pixel wp*64 + j*32 + lo]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pg = pt * 128 + wp * 64 + j * 32 + lo;
+        if (pg >= Ptot) continue;
+        const int n = pg / PQ, rem = pg - n * PQ;
+        float* yb = a.Y + (size_t)n * a.M * PQ + rem;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * 128 + wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+                if (m < a.M) {
+                    float v = acc[i][j][r] + (a.bias ? a.bias[m] : 0.f);
+                    yb[(size_t)m * PQ] = act_apply(v, a.act, a.slope);
+                }
+            }
+    }
+}
+
+static int bsplit_check(const pcgan_conv_desc* d) {
+    PCGAN_CHECK(d, "conv2d_bsplit: null descriptor");
+    PCGAN_CHECK(d->stride == 1 && d->C % 16 == 0 && d->R * d->S <= BS_MAXTAP && d->K >= 32, "conv2d_bsplit: unsupported shape");
+    PCGAN_CHECK(d->P == d->H + 2 * d->pad - d->R + 1 && d->Q == d->W + 2 * d->pad - d->S + 1, "conv2d_bsplit: output dims");
+    PCGAN_CHECK(d->pad_mode == 0 || (d->pad < d->H && d->pad < d->W), "conv2d_bsplit: reflection pad too large");
+    PCGAN_CHECK((size_t)d->N * d->C * d->H * d->W * 4 < 0x80000000ull, "conv2d_bsplit: input beyond 2 GiB");
+    return 0;
+}
+
+}  // namespace pcgan
+
+extern "C" int pcgan_conv2d_bsplit_supported(const pcgan_conv_desc* d) {
+    return d && d->stride == 1 && d->C % 16 == 0 && d->R * d->S <= pcgan::BS_MAXTAP && d->K >= 32 &&
+           (size_t)d->N * d->C * d->H * d->W * 4 < 0x80000000ull && (d->pad_mode == 0 || (d->pad < d->H && d->pad < d->W));
+}
+
+extern "C" size_t pcgan_conv2d_bsplit_packed_bytes(const pcgan_conv_desc* d) {
+    if (!pcgan_conv2d_bsplit_supported(d)) return 0;
+    const size_t nMt = (d->K + 127) / 128, nst = (size_t)(d->C / 16) * d->R * d->S;
+    return 3 * nMt * nst * 4096;
+}
+
+extern "C" int pcgan_conv2d_bsplit_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s) {
+    if (pcgan::bsplit_check(d)) return 1;
+    PCGAN_CHECK(w && packed, "conv2d_bsplit_pack: null pointer");
+    const int T = d->R * d->S, nMt = (d->K + 127) / 128, nst = (d->C / 16) * T;
+    const size_t per_piece = (size_t)nMt * nst * 2048;
+    const int blocks = (int)((per_piece + 255) / 256 > 4096 ? 4096 : (per_piece + 255) / 256);
+    hipLaunchKernelGGL(pcgan::bsplit_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (__bf16*)packed, d->K, d->C, T, nMt, nst);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y,
+                                       int act, float slope, pcgan_stream_t s) {
+    if (pcgan::bsplit_check(d)) return 1;
+    PCGAN_CHECK(x && packed && y, "conv2d_fwd_bsplit: null pointer");
+    pcgan::BsplitArgs a;
+    a.X = x; a.A = packed; a.bias = bias; a.Y = y;
+    a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->K; a.R = d->R; a.S = d->S; a.pad = d->pad; a.reflect = d->pad_mode;
+    a.P = d->P; a.Q = d->Q;
+    a.nMt = (d->K + 127) / 128;
+    a.nst = (d->C / 16) * d->R * d->S;
+    a.act = act; a.slope = slope;
+    a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
+    const size_t ab = 3 * (size_t)a.nMt * a.nst * 4096;
+    PCGAN_CHECK(ab < 0x80000000ull, "conv2d_fwd_bsplit: packed weights beyond 2 GiB");
+    a.a_bytes = (unsigned)ab;
+    const long ptiles = ((long)d->N * d->P * d->Q + 127) / 128;
+    const dim3 grid((unsigned)(ptiles * a.nMt));
+    if (d->pad_mode == 1) hipLaunchKernelGGL(pcgan::bsplit_conv_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, a);
+    else hipLaunchKernelGGL(pcgan::bsplit_conv_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, a);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}

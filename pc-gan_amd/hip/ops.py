@@ -157,6 +157,12 @@ def invalidate_packed_weights():
     _PACK_EPOCH[0] += 1
 
 
+# EXPERIMENT (default off): stride-1 convolutions with C % 16 == 0 forward on the bf16 matrix pipe, every fp32 operand
+# split exactly into three bf16 pieces, six piece products per term (csrc/bf16x6_conv.hip): fp32-level error.
+BF16X6 = os.environ.get('PCGAN_BF16X6', '0') == '1'
+PASS_FWD_BSPLIT = 100    # cache key only
+
+
 def _packed_weights(lib, d, pass_, w, cache):
     key = (pass_, d.stride, d.pad, d.pad_mode)
     stamp = (_PACK_EPOCH[0], w._version, w.data_ptr(), tuple(w.shape))
@@ -166,7 +172,8 @@ def _packed_weights(lib, d, pass_, w, cache):
         if ent[3] != cur.cuda_stream:      # packed on another stream (branch streams): order this use after the pack
             cur.wait_event(ent[2])
         return ent[1]
-    nb = max(int(lib.pcgan_conv2d_packed_bytes(ctypes.byref(d), pass_)), 256)
+    bsplit = pass_ == PASS_FWD_BSPLIT
+    nb = max(int(lib.pcgan_conv2d_bsplit_packed_bytes(ctypes.byref(d)) if bsplit else lib.pcgan_conv2d_packed_bytes(ctypes.byref(d), pass_)), 256)
     if ent is not None and ent[1].numel() == nb and ent[1].device == w.device:
         buf = ent[1]
         if ent[3] != cur.cuda_stream:      # re-pack into a buffer another stream may still be reading
@@ -174,7 +181,10 @@ def _packed_weights(lib, d, pass_, w, cache):
                 cur.wait_stream(st)
     else:
         buf = _ws(nb, w.device)
-    _L.check(lib.pcgan_conv2d_pack_weights(ctypes.byref(d), pass_, _p(w), _p(buf), _stream()), 'conv2d_pack_weights')
+    if bsplit:
+        _L.check(lib.pcgan_conv2d_bsplit_pack(ctypes.byref(d), _p(w), _p(buf), _stream()), 'conv2d_bsplit_pack')
+    else:
+        _L.check(lib.pcgan_conv2d_pack_weights(ctypes.byref(d), pass_, _p(w), _p(buf), _stream()), 'conv2d_pack_weights')
     ev = torch.cuda.Event()
     ev.record(cur)
     cache[key] = (stamp, buf, ev, cur.cuda_stream)
@@ -194,13 +204,19 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
     nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_FWD)
     ws = _ws(nb, x.device)
     if pack_cache is not None:
-        pk = _packed_weights(lib, d, _L.PASS_FWD, w, pack_cache)
+        # (one tile shape, no split-K yet: only where whole 128 x 128 tiles fill the chip, i.e. the residual-block convolutions)
+        bsplit = BF16X6 and K % 128 == 0 and N * d.P * d.Q >= 16384 and lib.pcgan_conv2d_bsplit_supported(ctypes.byref(d))
+        pk = _packed_weights(lib, d, PASS_FWD_BSPLIT if bsplit else _L.PASS_FWD, w, pack_cache)
         ev = None
         if KERNEL_TIMER is not None and KERNEL_TIMER['key'] == (N, C, H, W, K, R, S, stride, pad, pad_mode):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        _L.check(lib.pcgan_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(pk), _p(bias), _p(y), act, float(slope),
-                                             _p(ws), ws.numel(), _stream()), 'conv2d_fwd_packed')
+        if bsplit:
+            _L.check(lib.pcgan_conv2d_fwd_bsplit(ctypes.byref(d), _p(x), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
+                     'conv2d_fwd_bsplit')
+        else:
+            _L.check(lib.pcgan_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(pk), _p(bias), _p(y), act, float(slope),
+                                                 _p(ws), ws.numel(), _stream()), 'conv2d_fwd_packed')
         if ev is not None:
             ev[1].record()
             KERNEL_TIMER['events'].append(ev)

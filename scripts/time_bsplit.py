@@ -1,0 +1,36 @@
+"""res-conv forward (256->256 3x3 reflect @32x32, bs 32): fp32 MFMA implicit GEMM vs the bf16-split experiment"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from pcgan_amd.hip import lib as L, ops
+dev = torch.device('cuda:0')
+x = torch.randn(32, 256, 32, 32, device=dev).relu_()
+w = torch.randn(256, 256, 3, 3, device=dev) * 0.02
+b = torch.zeros(256, device=dev)
+d = ops.make_desc(32, 256, 32, 32, 256, 3, 3, 1, 1, 1)
+lib = L.load()
+pk = torch.empty(lib.pcgan_conv2d_bsplit_packed_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+L.check(lib.pcgan_conv2d_bsplit_pack(ctypes.byref(d), w.data_ptr(), pk.data_ptr(), st), 'pack')
+y = torch.empty(32, 256, 32, 32, device=dev)
+cache = {}
+def f6():
+    L.check(lib.pcgan_conv2d_fwd_bsplit(ctypes.byref(d), x.data_ptr(), pk.data_ptr(), b.data_ptr(), y.data_ptr(), 0, 0.0, st), 'fwd')
+def f32():
+    ops.conv2d_fwd(x, w, b, 1, 1, 1, pack_cache=cache)
+for name, fn in (('fp32 MFMA', f32), ('bf16x6   ', f6)):
+    for _ in range(5):
+        fn()
+    best = 1e9
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(50):
+            fn()
+        e.record(); torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / 50)
+    print('%s %.4f ms  %.1f TFLOP/s fp32-equivalent' % (name, best, 38.65 / best))
+y32 = ops.conv2d_fwd(x, w, b, 1, 1, 1, pack_cache=cache)
+f6(); torch.cuda.synchronize()
+print('max |bf16x6 - fp32| = %.3e, rel L2 %.3e' % (float((y - y32).abs().max()), float((y - y32).norm() / y32.norm())))

@@ -1,0 +1,84 @@
+"""GPU: the opt-in bf16-split convolution forward (csrc/bf16x6_conv.hip, through the C-ABI) against the oracle's convolution
+in float64: its error must be at the level of the fp32 path's own (tolerance 3e-6 relative L2, the fp32 MFMA kernel measures
+~6e-7 at K = 2304), for reflect and zero padding, ragged pixel / channel tiles, 1x1 / 3x3 / 5x5 filters, bias + activation."""
+import ctypes
+
+import pytest
+import torch
+
+from oracle import ops_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, N, C, H, W, K, k, pad, pad_mode, act=0, bias=True, seed=0):
+    from pcgan_amd.hip import lib as L, ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=g).relu_()
+    w = torch.randn(K, C, k, k, generator=g) * 0.05
+    b = torch.randn(K, generator=g) if bias else None
+    d = ops.make_desc(N, C, H, W, K, k, k, 1, pad, pad_mode)
+    lib = L.load()
+    assert lib.pcgan_conv2d_bsplit_supported(ctypes.byref(d))
+    xd, wd = x.to(dev), w.to(dev)
+    bd = b.to(dev) if bias else None
+    pk = torch.empty(lib.pcgan_conv2d_bsplit_packed_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.pcgan_conv2d_bsplit_pack(ctypes.byref(d), wd.data_ptr(), pk.data_ptr(), st), 'pack')
+    y = torch.full((N, K, d.P, d.Q), float('nan'), device=dev)
+    L.check(lib.pcgan_conv2d_fwd_bsplit(ctypes.byref(d), xd.data_ptr(), pk.data_ptr(), bd.data_ptr() if bias else None, y.data_ptr(),
+                                        act, 0.2, st), 'fwd')
+    ref = R.conv2d(x.double(), w.double(), b.double() if bias else None, 1, pad, pad_mode)
+    if act == 1:
+        ref = ref.relu()
+    elif act == 2:
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    # the fp32 path of the product on the same inputs
+    y32 = ops.conv2d_fwd(xd, wd, bd, 1, pad, pad_mode, act, 0.2)
+    torch.cuda.synchronize()
+    e = lambda t: float((t.double().cpu() - ref).norm() / ref.norm())
+    return e(y), e(y32)
+
+
+@pytest.mark.parametrize('N,C,H,W,K,k,pad,mode,act', [
+    (2, 256, 32, 32, 256, 3, 1, 1, 0),       # the residual-block convolution (reflect)
+    (2, 64, 20, 28, 128, 3, 1, 0, 1),        # zero padding, ReLU
+    (3, 32, 9, 7, 40, 3, 1, 1, 2),           # ragged pixel tile (189 pixels), ragged channel tile (40 of 128)
+    (1, 16, 13, 13, 32, 5, 2, 0, 0),         # 25 taps
+    (2, 48, 8, 8, 200, 1, 0, 0, 0),          # 1x1, two channel tiles
+    (1, 128, 6, 6, 64, 3, 0, 0, 0),          # valid convolution (output 4x4)
+])
+def test_bsplit_forward_has_fp32_accuracy(dev, N, C, H, W, K, k, pad, mode, act):
+    e6, e32 = _run(dev, N, C, H, W, K, k, pad, mode, act)
+    assert e6 < 3e-6 and e6 < 4 * e32 + 5e-7, (e6, e32)
+
+
+def test_bsplit_unsupported_shapes_are_refused(dev):
+    from pcgan_amd.hip import lib as L, ops
+    lib = L.load()
+    for args in [(1, 3, 8, 8, 64, 3, 3, 1, 1, 0), (1, 16, 8, 8, 64, 3, 3, 2, 1, 0), (1, 16, 8, 8, 3, 3, 3, 1, 1, 0)]:
+        d = ops.make_desc(*args)
+        assert not lib.pcgan_conv2d_bsplit_supported(ctypes.byref(d))
+        assert lib.pcgan_conv2d_bsplit_packed_bytes(ctypes.byref(d)) == 0
+
+
+def test_host_switch_routes_large_convs_and_follows_the_weights(dev, monkeypatch):
+    """PCGAN_BF16X6=1 (here: the module flag) sends packed forward calls of full-tile stride-1 convolutions to the split
+    kernel; the packed pieces are re-made when the weights change; small layers keep the fp32 kernel"""
+    from pcgan_amd.hip import ops
+    monkeypatch.setattr(ops, 'BF16X6', True)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 128, 64, 64, generator=g).relu_().to(dev)
+    w = (torch.randn(128, 128, 3, 3, generator=g) * 0.05).to(dev)
+    ref = R.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1, 1)
+    cache = {}
+    y = ops.conv2d_fwd(x, w, None, 1, 1, 1, pack_cache=cache)
+    assert list(cache) == [(ops.PASS_FWD_BSPLIT, 1, 1, 1)]
+    assert float((y.double().cpu() - ref).norm() / ref.norm()) < 3e-6
+    assert not torch.equal(y, ops.conv2d_fwd(x, w, None, 1, 1, 1))            # another kernel: other low bits
+    w.mul_(2.0)
+    y2 = ops.conv2d_fwd(x, w, None, 1, 1, 1, pack_cache=cache)
+    assert float((y2.double().cpu() - 2 * ref).norm() / ref.norm()) < 6e-6
+    small = {}
+    ops.conv2d_fwd(x[:1, :, :16, :16].contiguous(), w, None, 1, 1, 1, pack_cache=small)
+    assert list(small) == [(0, 1, 1, 1)]

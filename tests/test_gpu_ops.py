@@ -105,7 +105,11 @@ def test_conv2d_fwd_bwd(case, dev):
     # prepacked-weight entry points: same kernels on the same operand -> bit-identical; a second batch size
     # reuses the packed copy (it does not depend on N)
     cache = {}
-    assert torch.equal(ops.conv2d_fwd(xd, wd, bd, stride, pad, pm, pack_cache=cache), y), name + ' fwd_packed'
+    if ops.BF16X6:    # experiment on: eligible shapes take the bf16-split kernel when packed -- same accuracy, other bits
+        assert_close(ops.conv2d_fwd(xd, wd, bd, stride, pad, pm, pack_cache=cache), y_ref, 2e-5, name + ' fwd_packed')
+        y = ops.conv2d_fwd(xd, wd, bd, stride, pad, pm, pack_cache=cache)
+    else:
+        assert torch.equal(ops.conv2d_fwd(xd, wd, bd, stride, pad, pm, pack_cache=cache), y), name + ' fwd_packed'
     assert torch.equal(ops.conv2d_bwd_data(dyd, wd, (H, W), stride, pad, pm, pack_cache=cache), dx), name + ' bwd_packed'
     assert len(cache) == 2
     stamps = {k: v[0] for k, v in cache.items()}
