@@ -121,7 +121,7 @@ class GpuTransform(object):
     def _upload(self, images, H, W):
         """decoded bytes -> one reusable host buffer per source size (numpy row copies: torch's copy_ would fork its
         whole intra-op thread pool for every 120 KB image, 0.24 ms each on a 128-thread host) -> one copy to the GPU
-        (measured on the MI355X box: 0.2 ms + 0.15 ms for 64 images of 200x200, scripts/diag_h2d.py)"""
+        (measured on the MI355X box: 0.2 ms + 0.15 ms for 64 images of 200x200, scripts/diag/diag_h2d.py)"""
         n = len(images)
         buf = self._stage.get((H, W))
         if buf is None or buf.shape[0] < n:

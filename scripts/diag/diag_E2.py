@@ -1,5 +1,5 @@
 import sys, os, tempfile, pathlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch, torch.nn.functional as F
 from test_gpu_step import build_hip_model

@@ -1,6 +1,6 @@
 """diagnostic: per-quantity error of the HIP step vs the oracle step (not a test)."""
 import sys, os, tempfile, pathlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from test_gpu_step import build_hip_model, _grab_grads, _rel_l2

@@ -1,6 +1,6 @@
 """diagnostic: per-layer gradient error of HIP and of the fp32 oracle vs the fp64 twin."""
 import sys, os, tempfile, pathlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from test_gpu_step import build_hip_model, _grab_grads, _rel_l2

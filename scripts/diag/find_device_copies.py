@@ -1,6 +1,6 @@
 """which torch ops still launch device copies / elementwise kernels inside one optimize_parameters()"""
 import os, sys, tempfile, collections
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from torch.profiler import profile, ProfilerActivity

@@ -1,6 +1,6 @@
 """fixed (prologue + epilogue + launch) vs per-K cost of the chunked conv kernel: time C = 16..256 -> 256, 3x3 reflect @32x32 bs32"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from pcgan_amd.hip import ops

@@ -1,6 +1,6 @@
 """host-side issue time vs GPU time of one optimize_parameters(): is the step launch-bound?"""
 import os, sys, time, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench

@@ -1,6 +1,6 @@
 """times the dominant convolution (256->256 3x3 reflect @32x32, bs 32): fwd / dgrad / wgrad, HIP events, packed weights."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from pcgan_amd.hip import ops

@@ -35,12 +35,12 @@ def _run(net, inputs, seed_dy):
 def _assert_mostly_close(got, ref, name, rel_l2=3e-2):
     """Relative-L2 criterion for gradients that have passed through ReLU / max-pool decisions.
 
-    Measured on the encoder fixture (scripts/diag_E5.py): the HIP and fp64 forward passes agree to 3e-6, but
+    Measured on the encoder fixture (scripts/diag/diag_E5.py): the HIP and fp64 forward passes agree to 3e-6, but
     ONE of 12288 pre-activations of layer3.0 is +6.9e-6 in fp32 and <= 0 in fp64; that single ReLU mask flip
     (a legitimate rounding outcome -- oneDNN fp32 has its own) changes the block's gradient by 1.2e-3 relative
     L2, and BatchNorm/conv backward then spread it over ~20 % of the upstream elements.  Element-wise bands
     are therefore meaningless here; an indexing / layout bug shows up as an O(1) relative L2 error instead.
-    Every op of the block agrees with fp64 to < 1e-6 on identical inputs (scripts/diag_E4.py, test_gpu_ops)."""
+    Every op of the block agrees with fp64 to < 1e-6 on identical inputs (scripts/diag/diag_E4.py, test_gpu_ops)."""
     g, r = got.detach().double().cpu(), ref.detach().double().cpu()
     l2 = float((g - r).norm() / (r.norm() + 1e-300))
     assert l2 <= rel_l2, '%s: relative L2 error %.3e > %.1e' % (name, l2, rel_l2)

@@ -173,7 +173,7 @@ def test_step_matches_reference_and_oracle(variant, tmp_path, dev):
                 # 1e-6-level differences between implementations flip a few decisions: measured on these fixtures,
                 # either side can be the odd one out (HIP 1.2e-3 off the twin while oneDNN was at 1.6e-5; after the
                 # fixture change HIP at 1.6e-5 while oneDNN on the GPU box's host was 1.6e-2 off), whereas E alone
-                # on IDENTICAL inputs agrees to 1e-5 (scripts/diag_E2.py, tests/test_gpu_nets.py).  5e-3 / 2e-2
+                # on IDENTICAL inputs agrees to 1e-5 (scripts/diag/diag_E2.py, tests/test_gpu_nets.py).  5e-3 / 2e-2
                 # (heteroscedastic variants: division by an MC variance) cover that without masking O(1) errors.
                 slack = 2e-4 if variant == 'no_ip_no_z' else (2e-2 if hetero else 5e-3)
                 assert e_hip <= 2 * e_ref + slack, '%s it%d grad%s %s: rel-L2 vs fp64 twin hip %.3e, fp32 oracle %.3e' % (
