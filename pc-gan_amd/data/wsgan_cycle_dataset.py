@@ -9,7 +9,7 @@ import random
 
 import torch
 
-from .base_dataset import BaseDataset, get_transform
+from .base_dataset import BaseDataset, get_transform, decode_raw
 from ..util.util import get_attr_value
 
 
@@ -36,6 +36,7 @@ class WSGANCycleDataset(BaseDataset):
         self.B_paths = [p.rstrip('\n').split()[0] for p in lines_B]      # attribute source only: not joined with the root
         self.A_size, self.B_size = len(self.A_paths), len(self.B_paths)
         self.transform = get_transform(opt)
+        self.raw = bool(getattr(opt, 'gpu_transform', False))     # workers decode, the loader finishes the batch on the GPU
 
     def __getitem__(self, index):
         o = self.opt
@@ -49,8 +50,11 @@ class WSGANCycleDataset(BaseDataset):
         A_path = self.A_paths[index % self.A_size]
         index_B = index % self.B_size if o.serial_batches else random.randint(0, self.B_size - 1)
         B_path = self.B_paths[index_B]
-        A = self.transform(Image.open(A_path).convert('RGB'))
         B_attr = torch.Tensor([get_attr_value(B_path)]).reshape(1, 1, 1)
+        if self.raw:
+            A_raw, A_aug = decode_raw(Image.open(A_path).convert('RGB'), o)
+            return {'A_raw': A_raw, 'A_aug': A_aug, 'B_attr': B_attr, 'A_paths': A_path, 'B_paths': B_path}
+        A = self.transform(Image.open(A_path).convert('RGB'))
         if o.input_nc == 1:
             A = (A[0] * 0.299 + A[1] * 0.587 + A[2] * 0.114).unsqueeze(0)
         return {'A': A, 'B_attr': B_attr, 'A_paths': A_path, 'B_paths': B_path}

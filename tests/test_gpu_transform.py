@@ -139,3 +139,35 @@ def test_loader_end_to_end(dev, tmp_path):
         assert sorted(a) == sorted(b)
         assert b['A'].is_cuda and torch.equal(a['A'], b['A'].cpu()) and torch.equal(a['B'], b['B'].cpu())
         assert torch.equal(a['label'], b['label']) and a['A_paths'] == b['A_paths'] and a['B_paths'] == b['B_paths']
+
+
+def test_cycle_loader_end_to_end(dev, tmp_path):
+    """the unpaired image + attribute dataset (wsgan_cycle) through both loader modes: identical batches"""
+    from pcgan_amd.data import CreateDataLoader
+    from pcgan_amd.options.train_options import TrainOptions
+    imgs = _images([(50, 50)] * 6, seed=8)
+    with open(tmp_path / 'a.txt', 'w') as fa, open(tmp_path / 'b.txt', 'w') as fb:
+        for i, a in enumerate(imgs):
+            Image.fromarray(a).save(tmp_path / ('%d_img.png' % (20 + i)))
+            fa.write('%d_img.png\n' % (20 + i))
+            fb.write('%d_img.png\n' % (20 + i))
+
+    def opt(extra):
+        argv = ['train.py', '--dataroot', str(tmp_path), '--model', 'wsgan_cycle', '--gpu_ids', '0', '--checkpoints_dir', str(tmp_path / 'ck'),
+                '--sourcefile_A', str(tmp_path / 'a.txt'), '--sourcefile_B', str(tmp_path / 'b.txt'), '--loadSize', '40', '--fineSize', '32',
+                '--nThreads', '0', '--batchSize', '3', '--which_model_netG', 'resnet_9blocks'] + extra
+        old, sys.argv = sys.argv, argv
+        try:
+            return TrainOptions().parse()
+        finally:
+            sys.argv = old
+    random.seed(33)
+    torch.manual_seed(5)        # the DataLoader's shuffle
+    pil = list(CreateDataLoader(opt([])).load_data())
+    random.seed(33)
+    torch.manual_seed(5)
+    gpu = list(CreateDataLoader(opt(['--gpu_transform'])).load_data())
+    assert len(pil) == len(gpu) == 2
+    for a, b in zip(pil, gpu):
+        assert sorted(a) == sorted(b) == ['A', 'A_paths', 'B_attr', 'B_paths']
+        assert torch.equal(a['A'], b['A'].cpu()) and torch.equal(a['B_attr'], b['B_attr']) and a['A_paths'] == b['A_paths']
