@@ -1,0 +1,34 @@
+"""CPU: the bench.py contract -- flags, and the shape of the JSON line (checked on the latest line committed under
+profiles/, which bench.py printed on an MI355X)."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_flags_and_defaults():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True, cwd=ROOT).stdout
+    for flag in ('--gpus', '--steps', '--warmup'):
+        assert flag in out
+    import bench
+    assert bench.PER_GPU_BATCH == 32 and bench.SIZE == 128 and bench.GFLOP_PER_IMG_FULL == 183.95
+    assert bench.RES_CONV_FLOP == 2.0 * 32 * 32 * 32 * 256 * 256 * 9
+
+
+def test_committed_line_has_the_contract_fields():
+    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r01_bench_n1_v*.json')), key=lambda p: int(p.split('_v')[-1].split('.')[0]))
+    line = json.loads(open(lines[-1]).read())
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in line, key
+    assert line['unit'] == 'images/sec' and line['higher_is_better'] is True and line['scaling'] == 'weak' and line['vs_baseline'] is None
+    assert line['dtype'] == 'f32' and line['data'] == 'synthetic' and 'workload' in line['config'] and 'model' not in line['config']
+    assert abs(line['value'] - 32 * line['n_gpus'] / line['ms_per_step'] * 1e3) < 0.01 * line['value']
+    r = line['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic'] > 0
+    assert abs(r['achieved'] - r['flop_per_launch'] / (r['ms_per_launch'] * 1e-3) / 1e12) < 0.05 and r['launches_timed'] == 36 * line['steps']
+    c = line['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
