@@ -16,7 +16,8 @@
 //   pixels   8 channels of one pixel per thread (lanes along pixels: coalesced), split into the three pieces in registers,
 //            three 16-byte LDS writes;
 //   LDS      [piece][k half][row or pixel][8 bf16]: every access 16 bytes, 16 consecutive lanes = 256 contiguous bytes;
-//   per wave and stage 12 ds_read_b128 and 24 MFMAs (smallest terms first); loads run two stages ahead, one barrier per stage.
+//   per wave and stage 12 ds_read_b128 and 24 MFMAs (smallest terms first); global loads run three stages ahead, the LDS reads
+//   of the next stage sit under the MFMAs of the current one (operands double-buffered in registers), one barrier per stage.
 #include "common.h"
 
 namespace pcgan {
@@ -45,14 +46,17 @@ struct BsplitArgs {
     unsigned x_bytes, a_bytes;
 };
 
-// weights w[M][C][R][S] -> [piece][mt][stage][half][128][8] bf16, stage = chunk * T + tap, k in stage = channel in chunk
-__global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int M, int C, int T, int nMt, int nst) {
-    const size_t per_piece = (size_t)nMt * nst * 2048;
+// weights w[M][C][R][S] -> [piece][mt][stage][half][BM][8] bf16 (BM = 128 << bm_shift), stage = chunk * T + tap, k in stage =
+// channel in chunk
+__global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int M, int C, int T, int nMt, int nst,
+                                   int bm_shift) {
+    const int BM = 128 << bm_shift;
+    const size_t per_piece = (size_t)nMt * nst * 16 * BM;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_piece; i += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 7), row = (int)((i >> 3) & 127), half = (int)((i >> 10) & 1);
-        const size_t q = i >> 11;
+        const int j = (int)(i & 7), row = (int)((i >> 3) & (BM - 1)), half = (int)((i >> (10 + bm_shift)) & 1);
+        const size_t q = i >> (11 + bm_shift);
         const int st = (int)(q % nst), mt = (int)(q / nst);
-        const int m = mt * 128 + row, c = (st / T) * 16 + half * 8 + j, tap = st % T;
+        const int m = mt * BM + row, c = (st / T) * 16 + half * 8 + j, tap = st % T;
         const float v = m < M ? w[((size_t)m * C + c) * T + tap] : 0.f;
         __bf16 h, mm, l;
         split3(v, h, mm, l);
@@ -62,10 +66,16 @@ __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restri
     }
 }
 
-template <bool REFLECT>
-__global__ void __launch_bounds__(256) bsplit_conv_fwd_kernel(BsplitArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16x8 As[2][3][256];   // [buffer][piece][half * 128 + row]
-    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][3][256];   // [buffer][piece][half * 128 + pixel]
+// BM = 128: 4 waves, two workgroups per CU, each thread gathers 8 channels of its pixel per stage.
+// BM = 256: 8 waves (4 x 2 of 64 x 64) share ONE gathered / split pixel tile for all 256 output channels: half the gathers, split
+//           arithmetic and pixel LDS writes per MFMA; each thread gathers 4 channels; one workgroup per CU.
+template <bool REFLECT, int BM>
+__global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
+    constexpr int NT = BM * 2;              // threads
+    constexpr int KB = 2048 / NT;           // channels of one pixel a thread gathers per stage (8 or 4)
+    constexpr unsigned ASTAGE = BM * 32;    // bytes of one stage of one piece of the weights
+    __shared__ __attribute__((aligned(16))) bf16x8 As[2][3][2 * BM];   // [buffer][piece][half * BM + row]
+    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][3][256];      // [buffer][piece][half * 128 + pixel]
     __shared__ unsigned offT[BS_MAXTAP][128];
 
     const int tid = threadIdx.x;
@@ -76,7 +86,8 @@ __global__ void __launch_bounds__(256) bsplit_conv_fwd_kernel(BsplitArgs a) {
     const int T = a.R * a.S, PQ = a.P * a.Q, Ptot = a.N * PQ;
     const int HW4 = a.H * a.W * 4;
     const int pl = tid & 127;
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int kq = __builtin_amdgcn_readfirstlane(tid >> 7);      // which KB-channel slice of the 16-channel stage
+    const int half = (kq * KB) >> 3;
 
     // gather offsets (bytes, channel 0) of this workgroup's 128 pixels for every tap
     {
@@ -84,7 +95,7 @@ __global__ void __launch_bounds__(256) bsplit_conv_fwd_kernel(BsplitArgs a) {
         const bool pv = pg < Ptot;
         const int n = pv ? pg / PQ : 0, rem = pv ? pg - n * PQ : 0;
         const int py = rem / a.Q, px = rem - py * a.Q;
-        for (int t = half; t < T; t += 2) {
+        for (int t = kq; t < T; t += NT / 128) {
             const int r = t / a.S, s = t - r * a.S;
             int iy = py - a.pad + r, ix = px - a.pad + s;
             bool ok = pv;
@@ -103,40 +114,43 @@ __global__ void __launch_bounds__(256) bsplit_conv_fwd_kernel(BsplitArgs a) {
 
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)a.a_bytes, 0x00020000);
-    const unsigned piece_bytes = (unsigned)a.nMt * (unsigned)a.nst * 4096u;
-    const unsigned a_tile = (unsigned)mt * (unsigned)a.nst * 4096u;
+    const unsigned piece_bytes = (unsigned)a.nMt * (unsigned)a.nst * ASTAGE;
+    const unsigned a_tile = (unsigned)mt * (unsigned)a.nst * ASTAGE;
 
     struct Stage {
         u32x4 ap[3];
-        float b[8];
+        float b[KB];
     };
     auto load = [&](Stage& r, int s) {
         const bool live = s < a.nst;
         const int cc = s / T, tap = s - cc * T;
         const unsigned avo = live ? (unsigned)tid * 16u : BS_OOB;
-        const unsigned aso = a_tile + (unsigned)(live ? s : 0) * 4096u;
+        const unsigned aso = a_tile + (unsigned)(live ? s : 0) * ASTAGE;
 #pragma unroll
         for (int p = 0; p < 3; ++p) r.ap[p] = __builtin_amdgcn_raw_buffer_load_b128(rA, avo, aso + p * piece_bytes, 0);
         const unsigned bvo = live ? offT[tap][pl] : BS_OOB;
-        const unsigned bso = live ? (unsigned)(cc * 16 + half * 8) * (unsigned)HW4 : 0u;
+        const unsigned bso = live ? (unsigned)(cc * 16 + kq * KB) * (unsigned)HW4 : 0u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, bvo, bso + j * HW4, 0));
+        for (int j = 0; j < KB; ++j) r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, bvo, bso + j * HW4, 0));
     };
     auto stash = [&](const Stage& r, int buf) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&As[buf][p][tid]) = r.ap[p];
-        bf16x8 h, m, l;
+        typedef __bf16 bfv __attribute__((ext_vector_type(KB)));
+        bfv h, m, l;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < KB; ++j) {
             __bf16 x, y, z;
             split3(r.b[j], x, y, z);
             h[j] = x;
             m[j] = y;
             l[j] = z;
         }
-        Bs[buf][0][tid] = h;
-        Bs[buf][1][tid] = m;
-        Bs[buf][2][tid] = l;
+        // this thread's KB consecutive k of pixel pl: offset (kq * KB) % 8 inside the pixel's 8-wide half
+        const int sub = (kq * KB) & 7;
+        *reinterpret_cast<bfv*>(reinterpret_cast<__bf16*>(&Bs[buf][0][half * 128 + pl]) + sub) = h;
+        *reinterpret_cast<bfv*>(reinterpret_cast<__bf16*>(&Bs[buf][1][half * 128 + pl]) + sub) = m;
+        *reinterpret_cast<bfv*>(reinterpret_cast<__bf16*>(&Bs[buf][2][half * 128 + pl]) + sub) = l;
     };
 
     f32x16 acc[2][2];
@@ -147,15 +161,19 @@ __global__ void __launch_bounds__(256) bsplit_conv_fwd_kernel(BsplitArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int buf) {
+    struct Operands {
         bf16x8 A[3][2], B[3][2];
+    };
+    auto fetch = [&](Operands& o, int buf) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                A[p][i] = As[buf][p][hi * 128 + wm * 64 + i * 32 + lo];
-                B[p][i] = Bs[buf][p][hi * 128 + wp * 64 + i * 32 + lo];
+                o.A[p][i] = As[buf][p][hi * BM + wm * 64 + i * 32 + lo];
+                o.B[p][i] = Bs[buf][p][hi * 128 + wp * 64 + i * 32 + lo];
             }
+    };
+    auto mma = [&](const Operands& o) {
         // smallest terms first: (l,h) (h,l) (m,m) | (m,h) (h,m) | (h,h); the four accumulators take turns, so consecutive
         // MFMAs are independent
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -165,26 +183,37 @@ __global__ void __launch_bounds__(256) bsplit_conv_fwd_kernel(BsplitArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[q]][i], B[PB[q]][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.A[PA[q]][i], o.B[PB[q]][j], acc[i][j], 0, 0, 0);
     };
 
-    // loads run two stages ahead of the MFMAs; the stage pair is unrolled so both register sets are static.  An odd stage
-    // count is rounded up: the dead stage loads zeros (out-of-range offsets) and adds nothing.
+    // Software pipeline, stage pair unrolled so that every register set is static:
+    //   global loads run three stages ahead of the MFMAs (two register sets r0 / r1),
+    //   LDS holds stages s+1 and s+2 while the MFMAs of stage s run out of registers (two operand sets),
+    //   so the LDS reads of the next stage and the writes of the one after sit under the matrix instructions; one barrier per stage.
+    // An odd stage count is rounded up: dead stages load zeros (out-of-range offsets) and add nothing.
     Stage r0, r1;
+    Operands oa, ob;
     load(r0, 0);
     load(r1, 1);
     stash(r0, 0);
     __syncthreads();
+    load(r0, 2);
+    fetch(oa, 0);
+    stash(r1, 1);
+    __syncthreads();
+    load(r1, 3);
     const int nst2 = (a.nst + 1) & ~1;
     for (int s = 0; s < nst2; s += 2) {
-        load(r0, s + 2);
-        compute(0);
-        stash(r1, 1);
+        fetch(ob, 1);         // operands of stage s+1
+        mma(oa);              // stage s
+        stash(r0, 0);         // stage s+2 -> buffer 0 (its stage s was read before the last barrier)
         __syncthreads();
-        load(r1, s + 3);
-        compute(1);
-        stash(r0, 0);
+        load(r0, s + 4);
+        fetch(oa, 0);         // operands of stage s+2
+        mma(ob);              // stage s+1
+        stash(r1, 1);         // stage s+3 -> buffer 1
         __syncthreads();
+        load(r1, s + 5);
     }
 
     // epilogue: acc[i][j][r] = Y[m0 + wm*64 + i*32 + (r/4)*8 + hi*4 + r%4][pixel wp*64 + j*32 + lo]
@@ -198,7 +227,7 @@ __global__ void __launch_bounds__(256) bsplit_conv_fwd_kernel(BsplitArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mt * 128 + wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+                const int m = mt * BM + wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
                 if (m < a.M) {
                     float v = acc[i][j][r] + (a.bias ? a.bias[m] : 0.f);
                     yb[(size_t)m * PQ] = act_apply(v, a.act, a.slope);
@@ -223,19 +252,25 @@ extern "C" int pcgan_conv2d_bsplit_supported(const pcgan_conv_desc* d) {
            (size_t)d->N * d->C * d->H * d->W * 4 < 0x80000000ull && (d->pad_mode == 0 || (d->pad < d->H && d->pad < d->W));
 }
 
+// M tile: 256 rows (8 waves share one gathered pixel tile) when the output channels fill it, else 128
+static inline int bsplit_bm(const pcgan_conv_desc* d) { return d->K % 256 == 0 ? 256 : 128; }
+
 extern "C" size_t pcgan_conv2d_bsplit_packed_bytes(const pcgan_conv_desc* d) {
     if (!pcgan_conv2d_bsplit_supported(d)) return 0;
-    const size_t nMt = (d->K + 127) / 128, nst = (size_t)(d->C / 16) * d->R * d->S;
-    return 3 * nMt * nst * 4096;
+    const int bm = bsplit_bm(d);
+    const size_t nMt = (d->K + bm - 1) / bm, nst = (size_t)(d->C / 16) * d->R * d->S;
+    return 3 * nMt * nst * 32 * bm;
 }
 
 extern "C" int pcgan_conv2d_bsplit_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s) {
     if (pcgan::bsplit_check(d)) return 1;
     PCGAN_CHECK(w && packed, "conv2d_bsplit_pack: null pointer");
-    const int T = d->R * d->S, nMt = (d->K + 127) / 128, nst = (d->C / 16) * T;
-    const size_t per_piece = (size_t)nMt * nst * 2048;
+    const int bm = bsplit_bm(d);
+    const int T = d->R * d->S, nMt = (d->K + bm - 1) / bm, nst = (d->C / 16) * T;
+    const size_t per_piece = (size_t)nMt * nst * 16 * bm;
     const int blocks = (int)((per_piece + 255) / 256 > 4096 ? 4096 : (per_piece + 255) / 256);
-    hipLaunchKernelGGL(pcgan::bsplit_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (__bf16*)packed, d->K, d->C, T, nMt, nst);
+    hipLaunchKernelGGL(pcgan::bsplit_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (__bf16*)packed, d->K, d->C, T, nMt, nst,
+                       bm == 256 ? 1 : 0);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -248,17 +283,23 @@ extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const float* x,
     a.X = x; a.A = packed; a.bias = bias; a.Y = y;
     a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->K; a.R = d->R; a.S = d->S; a.pad = d->pad; a.reflect = d->pad_mode;
     a.P = d->P; a.Q = d->Q;
-    a.nMt = (d->K + 127) / 128;
+    const int bm = bsplit_bm(d);
+    a.nMt = (d->K + bm - 1) / bm;
     a.nst = (d->C / 16) * d->R * d->S;
     a.act = act; a.slope = slope;
     a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
-    const size_t ab = 3 * (size_t)a.nMt * a.nst * 4096;
+    const size_t ab = 3 * (size_t)a.nMt * a.nst * 32 * bm;
     PCGAN_CHECK(ab < 0x80000000ull, "conv2d_fwd_bsplit: packed weights beyond 2 GiB");
     a.a_bytes = (unsigned)ab;
     const long ptiles = ((long)d->N * d->P * d->Q + 127) / 128;
     const dim3 grid((unsigned)(ptiles * a.nMt));
-    if (d->pad_mode == 1) hipLaunchKernelGGL(pcgan::bsplit_conv_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, a);
-    else hipLaunchKernelGGL(pcgan::bsplit_conv_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, a);
+    if (bm == 256) {
+        if (d->pad_mode == 1) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<true, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
+        else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<false, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
+    } else {
+        if (d->pad_mode == 1) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<true, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
+        else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<false, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
+    }
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

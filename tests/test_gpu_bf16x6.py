@@ -47,6 +47,7 @@ def _run(dev, N, C, H, W, K, k, pad, pad_mode, act=0, bias=True, seed=0):
     (1, 16, 13, 13, 32, 5, 2, 0, 0),         # 25 taps
     (2, 48, 8, 8, 200, 1, 0, 0, 0),          # 1x1, two channel tiles
     (1, 128, 6, 6, 64, 3, 0, 0, 0),          # valid convolution (output 4x4)
+    (2, 32, 12, 10, 512, 3, 1, 1, 1),        # two 256-row channel tiles (8-wave workgroups), ragged pixel tile
 ])
 def test_bsplit_forward_has_fp32_accuracy(dev, N, C, H, W, K, k, pad, mode, act):
     e6, e32 = _run(dev, N, C, H, W, K, k, pad, mode, act)
