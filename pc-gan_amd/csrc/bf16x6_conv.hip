@@ -4,7 +4,8 @@
 // the piece pairs (h,h) | (h,m) (m,h) | (h,l) (m,m) (l,h) to keep every term above 2^-24 |a||b|; everything is accumulated in
 // the fp32 accumulators of v_mfma_f32_32x32x16_bf16.  scripts/micro/bf16_split measures, for K = 2304 (the residual-block
 // convolution): relative L2 error 7.0e-7 against float64, fp32 MFMA 6.1e-7; sustained rate of the six instructions that stand
-// for one fp32 K = 16 step 304 TFLOP/s fp32-equivalent against 155 TFLOP/s of v_mfma_f32_32x32x2_f32.
+// for one fp32 K = 16 step 304 TFLOP/s fp32-equivalent against 155 TFLOP/s of v_mfma_f32_32x32x2_f32.  This kernel: 0.171-0.179 ms
+// on the residual convolution (fp32 implicit GEMM: 0.269 ms).
 //
 // Replaces the same call sites as the fp32 implicit GEMM (nn.ReflectionPad2d + nn.Conv2d of the ResnetBlocks,
 // models/networks.py:621-648; stride-1 nn.Conv2d elsewhere) when the gathered channel count is a multiple of 16.
@@ -203,17 +204,32 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
     __syncthreads();
     load(r1, 3);
     const int nst2 = (a.nst + 1) & ~1;
+    // issue order inside a stage (a hint the scheduler follows where dependences allow): every MFMA is followed by its share of
+    // the other work -- LDS reads of the next stage first, then the split arithmetic and LDS writes of the stage after, then the
+    // global loads three stages ahead (0.178 -> 0.171 ms)
+    auto interleave = [&]() {
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+            if (q < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // two VALU
+            if (q >= 12 && q < 18) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // one LDS write
+            if (q >= 14 && q < 14 + 3 + KB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one global load
+        }
+    };
     for (int s = 0; s < nst2; s += 2) {
         fetch(ob, 1);         // operands of stage s+1
         mma(oa);              // stage s
         stash(r0, 0);         // stage s+2 -> buffer 0 (its stage s was read before the last barrier)
-        __syncthreads();
         load(r0, s + 4);
+        interleave();
+        __syncthreads();
         fetch(oa, 0);         // operands of stage s+2
         mma(ob);              // stage s+1
         stash(r1, 1);         // stage s+3 -> buffer 1
-        __syncthreads();
         load(r1, s + 5);
+        interleave();
+        __syncthreads();
     }
 
     // epilogue: acc[i][j][r] = Y[m0 + wm*64 + i*32 + (r/4)*8 + hi*4 + r%4][pixel wp*64 + j*32 + lo]
