@@ -241,6 +241,12 @@ size_t pcgan_conv2d_bsplit_packed_bytes(const pcgan_conv_desc* d);
 int pcgan_conv2d_bsplit_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s);
 int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y,
                             int act, float slope, pcgan_stream_t s);
+/* the same for the data gradient of nn.ReflectionPad2d(1) + nn.Conv2d(k=3, stride 1) (the ResnetBlock convolutions): row
+ * mirrors folded into three per-row-class weight sets by the pack call, column mirrors gathered as a second source. */
+int pcgan_conv2d_bsplit_dgrad_supported(const pcgan_conv_desc* d);
+size_t pcgan_conv2d_bsplit_dgrad_packed_bytes(const pcgan_conv_desc* d);
+int pcgan_conv2d_bsplit_dgrad_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s);
+int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const float* dy, const void* packed, float* dx, pcgan_stream_t s);
 
 #ifdef __cplusplus
 }

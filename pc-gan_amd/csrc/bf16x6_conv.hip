@@ -1,4 +1,5 @@
-// EXPERIMENT (opt-in, PCGAN_BF16X6=1): stride-1 convolution forward with fp32 accuracy on the bf16 matrix pipe.
+// EXPERIMENT (opt-in, PCGAN_BF16X6=1): stride-1 convolution forward -- and the data gradient of the reflection-padded 3x3
+// convolution -- with fp32 accuracy on the bf16 matrix pipe.
 //
 // An fp32 value is the exact sum of three bf16 pieces, x = h + m + l (8 + 8 + 8 significand bits).  A product a*b then needs
 // the piece pairs (h,h) | (h,m) (m,h) | (h,l) (m,m) (l,h) to keep every term above 2^-24 |a||b|; everything is accumulated in
@@ -45,7 +46,13 @@ struct BsplitArgs {
     int nMt, nst, act;
     float slope;
     unsigned x_bytes, a_bytes;
+    // data gradient of the reflection-padded 3x3 convolution: three row classes (rows without a mirror image | row 1 | row H-2),
+    // each with its own packed weights (the row mirror is folded into them) and its own run of pixel tiles in the grid
+    int tstart[4];       // first pixel tile of each phase, tstart[3] = total
+    unsigned phase_bytes;
 };
+
+enum { BS_FWD_ZERO = 0, BS_FWD_REFLECT = 1, BS_DGRAD_REFLECT = 2 };
 
 // weights w[M][C][R][S] -> [piece][mt][stage][half][BM][8] bf16 (BM = 128 << bm_shift), stage = chunk * T + tap, k in stage =
 // channel in chunk
@@ -70,8 +77,40 @@ __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restri
 // BM = 128: 4 waves, two workgroups per CU, each thread gathers 8 channels of its pixel per stage.
 // BM = 256: 8 waves (4 x 2 of 64 x 64) share ONE gathered / split pixel tile for all 256 output channels: half the gathers, split
 //           arithmetic and pixel LDS writes per MFMA; each thread gathers 4 channels; one workgroup per CU.
-template <bool REFLECT, int BM>
+// data-gradient weights of the reflect-padded 3x3 convolution: A[phase][piece][mt][stage][half][BM][8], rows = input channels c,
+// k = (16-chunk of output channels, tap (r', s'), channel), value = wf[c][k][r'][s'] = w[k][c][2-r'][2-s'] with the row mirror
+// folded in: row class 1 (row 1) reads row 0 through tap r'=0 for itself AND for padded row -1: wf'[0] = wf[0] + wf[2];
+// row class 2 (row H-2): wf'[2] = wf[2] + wf[0].
+__global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int K, int C, int nMt, int nst, int bm_shift) {
+    const int BM = 128 << bm_shift;
+    const size_t per_piece = (size_t)nMt * nst * 16 * BM, per_phase = 3 * per_piece;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_phase; i += (size_t)gridDim.x * blockDim.x) {
+        const int phase = (int)(i / per_piece);
+        const size_t e = i - (size_t)phase * per_piece;
+        const int j = (int)(e & 7), row = (int)((e >> 3) & (BM - 1)), half = (int)((e >> (10 + bm_shift)) & 1);
+        const size_t q = e >> (11 + bm_shift);
+        const int st = (int)(q % nst), mt = (int)(q / nst);
+        const int c = mt * BM + row, k = (st / 9) * 16 + half * 8 + j, tap = st % 9;
+        const int rp = tap / 3, sp = tap - rp * 3;
+        float v = 0.f;
+        if (c < C) {
+            const float* wk = w + ((size_t)k * C + c) * 9;
+            v = wk[(2 - rp) * 3 + (2 - sp)];
+            if ((phase == 1 && rp == 0) || (phase == 2 && rp == 2)) v += wk[rp * 3 + (2 - sp)];   // + wf[2 - rp][sp]
+        }
+        __bf16 h, mm, l;
+        split3(v, h, mm, l);
+        __bf16* out = A + (size_t)phase * per_phase;
+        out[e] = h;
+        out[per_piece + e] = mm;
+        out[2 * per_piece + e] = l;
+    }
+}
+
+template <int MODE, int BM>
 __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
+    constexpr bool REFLECT = MODE == BS_FWD_REFLECT;
+    constexpr bool DGRAD = MODE == BS_DGRAD_REFLECT;
     constexpr int NT = BM * 2;              // threads
     constexpr int KB = 2048 / NT;           // channels of one pixel a thread gathers per stage (8 or 4)
     constexpr unsigned ASTAGE = BM * 32;    // bytes of one stage of one piece of the weights
@@ -83,8 +122,15 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wp = wave & 1;
-    const int mt = blockIdx.x % a.nMt, pt = blockIdx.x / a.nMt;
-    const int T = a.R * a.S, PQ = a.P * a.Q, Ptot = a.N * PQ;
+    const int mt = blockIdx.x % a.nMt;
+    int pt = blockIdx.x / a.nMt;
+    int phase = 0;
+    if (DGRAD) {
+        phase = (pt >= a.tstart[1]) + (pt >= a.tstart[2]);
+        pt -= a.tstart[phase];
+    }
+    const int Hs = DGRAD ? (phase == 0 ? a.H - 2 : 1) : a.P;      // rows per image of this phase's pixel list
+    const int T = a.R * a.S, PQ = Hs * a.Q, Ptot = a.N * PQ;
     const int HW4 = a.H * a.W * 4;
     const int pl = tid & 127;
     const int kq = __builtin_amdgcn_readfirstlane(tid >> 7);      // which KB-channel slice of the 16-channel stage
@@ -95,7 +141,10 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
         const int pg = pt * 128 + pl;
         const bool pv = pg < Ptot;
         const int n = pv ? pg / PQ : 0, rem = pv ? pg - n * PQ : 0;
-        const int py = rem / a.Q, px = rem - py * a.Q;
+        int py = rem / a.Q;
+        const int px = rem - py * a.Q;
+        if (DGRAD) py = phase == 0 ? (py == 0 ? 0 : (py == Hs - 1 ? a.H - 1 : py + 1)) : (phase == 1 ? 1 : a.H - 2);
+        const unsigned nbase = (unsigned)n * (unsigned)a.C * (unsigned)(a.H * a.W);
         for (int t = kq; t < T; t += NT / 128) {
             const int r = t / a.S, s = t - r * a.S;
             int iy = py - a.pad + r, ix = px - a.pad + s;
@@ -108,7 +157,12 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
             } else {
                 ok = ok & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
             }
-            offT[t][pl] = ok ? ((unsigned)n * (unsigned)a.C * (unsigned)(a.H * a.W) + (unsigned)(iy * a.W + ix)) * 4u : BS_OOB;
+            offT[t][pl] = ok ? (nbase + (unsigned)(iy * a.W + ix)) * 4u : BS_OOB;
+            if (DGRAD) {   // column mirror: column 1 also receives padded column -1 (source column 0 through tap s'=2), column W-2 padded column W
+                const int ix2 = (px == 1 && s == 2) ? 0 : ((px == a.W - 2 && s == 0) ? a.W - 1 : -1);
+                const bool ok2 = pv & (ix2 >= 0) & ((unsigned)iy < (unsigned)a.H);
+                offT[9 + t][pl] = ok2 ? (nbase + (unsigned)(iy * a.W + ix2)) * 4u : BS_OOB;
+            }
         }
     }
     __syncthreads();
@@ -116,11 +170,12 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)a.a_bytes, 0x00020000);
     const unsigned piece_bytes = (unsigned)a.nMt * (unsigned)a.nst * ASTAGE;
-    const unsigned a_tile = (unsigned)mt * (unsigned)a.nst * ASTAGE;
+    const unsigned a_tile = (DGRAD ? (unsigned)phase * a.phase_bytes : 0u) + (unsigned)mt * (unsigned)a.nst * ASTAGE;
 
     struct Stage {
         u32x4 ap[3];
         float b[KB];
+        float b2[DGRAD ? KB : 1];     // column-mirror source (two lanes per image row are in range)
     };
     auto load = [&](Stage& r, int s) {
         const bool live = s < a.nst;
@@ -133,6 +188,11 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
         const unsigned bso = live ? (unsigned)(cc * 16 + kq * KB) * (unsigned)HW4 : 0u;
 #pragma unroll
         for (int j = 0; j < KB; ++j) r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, bvo, bso + j * HW4, 0));
+        if (DGRAD) {
+            const unsigned bvo2 = live ? offT[9 + tap][pl] : BS_OOB;
+#pragma unroll
+            for (int j = 0; j < KB; ++j) r.b2[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, bvo2, bso + j * HW4, 0));
+        }
     };
     auto stash = [&](const Stage& r, int buf) {
 #pragma unroll
@@ -142,7 +202,7 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             __bf16 x, y, z;
-            split3(r.b[j], x, y, z);
+            split3(DGRAD ? r.b[j] + r.b2[j] : r.b[j], x, y, z);
             h[j] = x;
             m[j] = y;
             l[j] = z;
@@ -237,8 +297,15 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
     for (int j = 0; j < 2; ++j) {
         const int pg = pt * 128 + wp * 64 + j * 32 + lo;
         if (pg >= Ptot) continue;
-        const int n = pg / PQ, rem = pg - n * PQ;
-        float* yb = a.Y + (size_t)n * a.M * PQ + rem;
+        const int n = pg / PQ;
+        int rem = pg - n * PQ;
+        if (DGRAD) {
+            const int sy = rem / a.Q, x = rem - sy * a.Q;
+            const int y = phase == 0 ? (sy == 0 ? 0 : (sy == Hs - 1 ? a.H - 1 : sy + 1)) : (phase == 1 ? 1 : a.H - 2);
+            rem = y * a.Q + x;
+        }
+        const int PQo = a.P * a.Q;
+        float* yb = a.Y + (size_t)n * a.M * PQo + rem;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -246,7 +313,7 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
                 const int m = mt * BM + wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
                 if (m < a.M) {
                     float v = acc[i][j][r] + (a.bias ? a.bias[m] : 0.f);
-                    yb[(size_t)m * PQ] = act_apply(v, a.act, a.slope);
+                    yb[(size_t)m * PQo] = act_apply(v, a.act, a.slope);
                 }
             }
     }
@@ -304,18 +371,78 @@ extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const float* x,
     a.nst = (d->C / 16) * d->R * d->S;
     a.act = act; a.slope = slope;
     a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
+    a.tstart[0] = a.tstart[1] = a.tstart[2] = a.tstart[3] = 0;
+    a.phase_bytes = 0;
     const size_t ab = 3 * (size_t)a.nMt * a.nst * 32 * bm;
     PCGAN_CHECK(ab < 0x80000000ull, "conv2d_fwd_bsplit: packed weights beyond 2 GiB");
     a.a_bytes = (unsigned)ab;
     const long ptiles = ((long)d->N * d->P * d->Q + 127) / 128;
     const dim3 grid((unsigned)(ptiles * a.nMt));
     if (bm == 256) {
-        if (d->pad_mode == 1) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<true, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
-        else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<false, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
+        if (d->pad_mode == 1) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_FWD_REFLECT, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
+        else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_FWD_ZERO, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
     } else {
-        if (d->pad_mode == 1) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<true, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
-        else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<false, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
+        if (d->pad_mode == 1) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_FWD_REFLECT, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
+        else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_FWD_ZERO, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
     }
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- data gradient of the reflection-padded 3x3 stride-1 convolution ---------------------------------------------------------
+extern "C" int pcgan_conv2d_bsplit_dgrad_supported(const pcgan_conv_desc* d) {
+    return d && d->stride == 1 && d->pad_mode == 1 && d->pad == 1 && d->R == 3 && d->S == 3 && d->K % 16 == 0 && d->C >= 32 &&
+           d->H >= 4 && d->W >= 4 && d->P == d->H && d->Q == d->W && (size_t)d->N * d->K * d->H * d->W * 4 < 0x80000000ull;
+}
+
+static inline int bsplit_dgrad_bm(const pcgan_conv_desc* d) { return d->C % 256 == 0 ? 256 : 128; }
+
+extern "C" size_t pcgan_conv2d_bsplit_dgrad_packed_bytes(const pcgan_conv_desc* d) {
+    if (!pcgan_conv2d_bsplit_dgrad_supported(d)) return 0;
+    const int bm = bsplit_dgrad_bm(d);
+    const size_t nMt = (d->C + bm - 1) / bm, nst = (size_t)(d->K / 16) * 9;
+    return 3 * 3 * nMt * nst * 32 * bm;
+}
+
+extern "C" int pcgan_conv2d_bsplit_dgrad_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s) {
+    PCGAN_CHECK(pcgan_conv2d_bsplit_dgrad_supported(d), "conv2d_bsplit_dgrad_pack: unsupported shape");
+    PCGAN_CHECK(w && packed, "conv2d_bsplit_dgrad_pack: null pointer");
+    const int bm = bsplit_dgrad_bm(d);
+    const int nMt = (d->C + bm - 1) / bm, nst = (d->K / 16) * 9;
+    const size_t total = 3 * (size_t)nMt * nst * 16 * bm;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pcgan::bsplit_pack_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (__bf16*)packed, d->K, d->C, nMt, nst,
+                       bm == 256 ? 1 : 0);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const float* dy, const void* packed, float* dx, pcgan_stream_t s) {
+    PCGAN_CHECK(pcgan_conv2d_bsplit_dgrad_supported(d), "conv2d_bwd_data_bsplit: unsupported shape");
+    PCGAN_CHECK(dy && packed && dx, "conv2d_bwd_data_bsplit: null pointer");
+    pcgan::BsplitArgs a;
+    a.X = dy; a.A = packed; a.bias = nullptr; a.Y = dx;
+    a.N = d->N; a.C = d->K; a.H = d->H; a.W = d->W; a.M = d->C; a.R = 3; a.S = 3; a.pad = 1; a.reflect = 1;
+    a.P = d->H; a.Q = d->W;
+    const int bm = bsplit_dgrad_bm(d);
+    a.nMt = (d->C + bm - 1) / bm;
+    a.nst = (d->K / 16) * 9;
+    a.act = PCGAN_ACT_NONE; a.slope = 0.f;
+    a.x_bytes = (unsigned)((size_t)d->N * d->K * d->H * d->W * 4);
+    const size_t per_phase = 3 * (size_t)a.nMt * a.nst * 32 * bm;
+    PCGAN_CHECK(3 * per_phase < 0x80000000ull, "conv2d_bwd_data_bsplit: packed weights beyond 2 GiB");
+    a.phase_bytes = (unsigned)per_phase;
+    a.a_bytes = (unsigned)(3 * per_phase);
+    const long rows[3] = {(long)d->H - 2, 1, 1};
+    long t = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.tstart[p] = (int)t;
+        t += ((long)d->N * rows[p] * d->W + 127) / 128;
+    }
+    a.tstart[3] = (int)t;
+    const dim3 grid((unsigned)(t * a.nMt));
+    if (bm == 256) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_DGRAD_REFLECT, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
+    else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_DGRAD_REFLECT, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

@@ -77,6 +77,10 @@ SIGNATURES = {
     'pcgan_conv2d_bsplit_packed_bytes': (_sz, [_dp]),
     'pcgan_conv2d_bsplit_pack': (_i, [_dp, _vp, _vp, _vp]),
     'pcgan_conv2d_fwd_bsplit': (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
+    'pcgan_conv2d_bsplit_dgrad_supported': (_i, [_dp]),
+    'pcgan_conv2d_bsplit_dgrad_packed_bytes': (_sz, [_dp]),
+    'pcgan_conv2d_bsplit_dgrad_pack': (_i, [_dp, _vp, _vp, _vp]),
+    'pcgan_conv2d_bwd_data_bsplit': (_i, [_dp, _vp, _vp, _vp, _vp]),
     'pcgan_image_transform_band': (_i, [_ip, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     'pcgan_image_transform': (_i, [_ip, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }

@@ -160,7 +160,8 @@ def invalidate_packed_weights():
 # EXPERIMENT (default off): stride-1 convolutions with C % 16 == 0 forward on the bf16 matrix pipe, every fp32 operand
 # split exactly into three bf16 pieces, six piece products per term (csrc/bf16x6_conv.hip): fp32-level error.
 BF16X6 = os.environ.get('PCGAN_BF16X6', '0') == '1'
-PASS_FWD_BSPLIT = 100    # cache key only
+PASS_FWD_BSPLIT = 100    # cache keys only
+PASS_BWD_BSPLIT = 101
 
 
 def _packed_weights(lib, d, pass_, w, cache):
@@ -172,8 +173,14 @@ def _packed_weights(lib, d, pass_, w, cache):
         if ent[3] != cur.cuda_stream:      # packed on another stream (branch streams): order this use after the pack
             cur.wait_event(ent[2])
         return ent[1]
-    bsplit = pass_ == PASS_FWD_BSPLIT
-    nb = max(int(lib.pcgan_conv2d_bsplit_packed_bytes(ctypes.byref(d)) if bsplit else lib.pcgan_conv2d_packed_bytes(ctypes.byref(d), pass_)), 256)
+    bsplit = pass_ in (PASS_FWD_BSPLIT, PASS_BWD_BSPLIT)
+    if pass_ == PASS_FWD_BSPLIT:
+        nb = int(lib.pcgan_conv2d_bsplit_packed_bytes(ctypes.byref(d)))
+    elif pass_ == PASS_BWD_BSPLIT:
+        nb = int(lib.pcgan_conv2d_bsplit_dgrad_packed_bytes(ctypes.byref(d)))
+    else:
+        nb = int(lib.pcgan_conv2d_packed_bytes(ctypes.byref(d), pass_))
+    nb = max(nb, 256)
     if ent is not None and ent[1].numel() == nb and ent[1].device == w.device:
         buf = ent[1]
         if ent[3] != cur.cuda_stream:      # re-pack into a buffer another stream may still be reading
@@ -181,8 +188,10 @@ def _packed_weights(lib, d, pass_, w, cache):
                 cur.wait_stream(st)
     else:
         buf = _ws(nb, w.device)
-    if bsplit:
+    if pass_ == PASS_FWD_BSPLIT:
         _L.check(lib.pcgan_conv2d_bsplit_pack(ctypes.byref(d), _p(w), _p(buf), _stream()), 'conv2d_bsplit_pack')
+    elif pass_ == PASS_BWD_BSPLIT:
+        _L.check(lib.pcgan_conv2d_bsplit_dgrad_pack(ctypes.byref(d), _p(w), _p(buf), _stream()), 'conv2d_bsplit_dgrad_pack')
     else:
         _L.check(lib.pcgan_conv2d_pack_weights(ctypes.byref(d), pass_, _p(w), _p(buf), _stream()), 'conv2d_pack_weights')
     ev = torch.cuda.Event()
@@ -240,6 +249,10 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
     nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_BWD_DATA)
     ws = _ws(nb, dy.device)
     if pack_cache is not None:
+        if BF16X6 and bias is None and C % 128 == 0 and N * H * W >= 16384 and lib.pcgan_conv2d_bsplit_dgrad_supported(ctypes.byref(d)):
+            pk = _packed_weights(lib, d, PASS_BWD_BSPLIT, w, pack_cache)
+            _L.check(lib.pcgan_conv2d_bwd_data_bsplit(ctypes.byref(d), _p(dy), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_bsplit')
+            return dx
         pk = _packed_weights(lib, d, _L.PASS_BWD_DATA, w, pack_cache)
         _L.check(lib.pcgan_conv2d_bwd_data_packed(ctypes.byref(d), _p(dy), _p(pk), _p(bias), _p(dx), _p(ws),
                                                   ws.numel(), _stream()), 'conv2d_bwd_data_packed')

@@ -34,3 +34,26 @@ for name, fn in (('fp32 MFMA', f32), ('bf16x6   ', f6)):
 y32 = ops.conv2d_fwd(x, w, b, 1, 1, 1, pack_cache=cache)
 f6(); torch.cuda.synchronize()
 print('max |bf16x6 - fp32| = %.3e, rel L2 %.3e' % (float((y - y32).abs().max()), float((y - y32).norm() / y32.norm())))
+
+# data gradient
+dy = torch.randn(32, 256, 32, 32, device=dev)
+pkd = torch.empty(lib.pcgan_conv2d_bsplit_dgrad_packed_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+L.check(lib.pcgan_conv2d_bsplit_dgrad_pack(ctypes.byref(d), w.data_ptr(), pkd.data_ptr(), st), 'pack')
+dx = torch.empty(32, 256, 32, 32, device=dev)
+cache2 = {}
+def g6():
+    L.check(lib.pcgan_conv2d_bwd_data_bsplit(ctypes.byref(d), dy.data_ptr(), pkd.data_ptr(), dx.data_ptr(), st), 'dgrad')
+def g32():
+    ops.conv2d_bwd_data(dy, w, (32, 32), 1, 1, 1, pack_cache=cache2)
+for name, fn in (('dgrad fp32 MFMA', g32), ('dgrad bf16x6   ', g6)):
+    for _ in range(5):
+        fn()
+    best = 1e9
+    for _ in range(3):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        for _ in range(50):
+            fn()
+        e_.record(); torch.cuda.synchronize()
+        best = min(best, s_.elapsed_time(e_) / 50)
+    print('%s %.4f ms  %.1f TFLOP/s fp32-equivalent' % (name, best, 38.65 / best))

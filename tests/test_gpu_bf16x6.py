@@ -83,3 +83,33 @@ def test_host_switch_routes_large_convs_and_follows_the_weights(dev, monkeypatch
     small = {}
     ops.conv2d_fwd(x[:1, :, :16, :16].contiguous(), w, None, 1, 1, 1, pack_cache=small)
     assert list(small) == [(0, 1, 1, 1)]
+
+
+@pytest.mark.parametrize('N,C,H,W,K', [
+    (2, 256, 32, 32, 256),      # the residual-block convolution
+    (3, 64, 9, 7, 48),          # ragged tiles, 128-row tile variant, K not a multiple of 32
+    (1, 512, 4, 4, 32),         # smallest grid (rows 0..3: both mirror rows adjacent), two 256-row tiles
+    (2, 128, 6, 20, 16),        # one 16-channel K chunk
+])
+def test_bsplit_reflect_data_gradient(dev, N, C, H, W, K):
+    """dx of ReflectionPad2d(1) + Conv2d(3x3) through the split kernel against autograd in float64 and the fp32 kernel"""
+    from pcgan_amd.hip import lib as L, ops
+    g = torch.Generator().manual_seed(N * 1000 + C + K)
+    dy = torch.randn(N, K, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    x = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
+    R.conv2d(x, w.double(), None, 1, 1, 1).backward(dy.double())
+    ref = x.grad
+    d = ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 1)
+    lib = L.load()
+    assert lib.pcgan_conv2d_bsplit_dgrad_supported(ctypes.byref(d))
+    dyd, wd = dy.to(dev), w.to(dev)
+    pk = torch.empty(lib.pcgan_conv2d_bsplit_dgrad_packed_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.pcgan_conv2d_bsplit_dgrad_pack(ctypes.byref(d), wd.data_ptr(), pk.data_ptr(), st), 'pack')
+    dx = torch.full((N, C, H, W), float('nan'), device=dev)
+    L.check(lib.pcgan_conv2d_bwd_data_bsplit(ctypes.byref(d), dyd.data_ptr(), pk.data_ptr(), dx.data_ptr(), st), 'dgrad')
+    dx32 = ops.conv2d_bwd_data(dyd, wd, (H, W), 1, 1, 1)
+    torch.cuda.synchronize()
+    e = lambda t: float((t.double().cpu() - ref).norm() / ref.norm())
+    assert e(dx) < 3e-6 and e(dx) < 4 * e(dx32) + 5e-7, (e(dx), e(dx32))
