@@ -247,6 +247,13 @@ int pcgan_conv2d_bsplit_dgrad_supported(const pcgan_conv_desc* d);
 size_t pcgan_conv2d_bsplit_dgrad_packed_bytes(const pcgan_conv_desc* d);
 int pcgan_conv2d_bsplit_dgrad_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s);
 int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const float* dy, const void* packed, float* dx, pcgan_stream_t s);
+/* ... and for its weight gradient: the same GEMM with the roles turned (rows = output channels, operand A = dy re-split per
+ * call, columns = (c, r, s), reduction over pixels in splits + a fixed-order reduce); ws holds the reflection-padded copy of x,
+ * the pieces of dy and the partial sums.  accumulate != 0 adds into dw like pcgan_conv2d_bwd_weight. */
+int pcgan_conv2d_bsplit_wgrad_supported(const pcgan_conv_desc* d);
+size_t pcgan_conv2d_bsplit_wgrad_workspace_bytes(const pcgan_conv_desc* d);
+int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate, void* ws,
+                                   size_t ws_bytes, pcgan_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
-// EXPERIMENT (opt-in, PCGAN_BF16X6=1): stride-1 convolution forward -- and the data gradient of the reflection-padded 3x3
-// convolution -- with fp32 accuracy on the bf16 matrix pipe.
+// EXPERIMENT (opt-in, PCGAN_BF16X6=1): stride-1 convolution forward -- and the data and weight gradients of the reflection-padded
+// 3x3 convolution -- with fp32 accuracy on the bf16 matrix pipe.
 //
 // An fp32 value is the exact sum of three bf16 pieces, x = h + m + l (8 + 8 + 8 significand bits).  A product a*b then needs
 // the piece pairs (h,h) | (h,m) (m,h) | (h,l) (m,m) (l,h) to keep every term above 2^-24 |a||b|; everything is accumulated in
@@ -50,9 +50,11 @@ struct BsplitArgs {
     // each with its own packed weights (the row mirror is folded into them) and its own run of pixel tiles in the grid
     int tstart[4];       // first pixel tile of each phase, tstart[3] = total
     unsigned phase_bytes;
+    // weight gradient: blockIdx.y takes stages [y * nst_split, (y + 1) * nst_split) of the pixel reduction and writes a raw partial sum
+    int nst_split;
 };
 
-enum { BS_FWD_ZERO = 0, BS_FWD_REFLECT = 1, BS_DGRAD_REFLECT = 2 };
+enum { BS_FWD_ZERO = 0, BS_FWD_REFLECT = 1, BS_DGRAD_REFLECT = 2, BS_WGRAD = 3 };
 
 // weights w[M][C][R][S] -> [piece][mt][stage][half][BM][8] bf16 (BM = 128 << bm_shift), stage = chunk * T + tap, k in stage =
 // channel in chunk
@@ -72,6 +74,54 @@ __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restri
         A[per_piece + i] = mm;
         A[2 * per_piece + i] = l;
     }
+}
+
+// ---- weight gradient as the same GEMM with the roles turned: rows = output channels k (operand A = dy, re-split per call), columns
+// = (c, r, s), reduction = (n, y, x) in stages of 16 consecutive x.  The reflection padding is materialised once (xpad), so that
+// the gather address is separable: column part (c, r, s) in the lane's offset, reduction part (n, y, x) in the scalar offset.
+__global__ void bsplit_pad_reflect_kernel(const float* __restrict__ x, float* __restrict__ xp, int H, int W, int pad) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const float* src = x + (size_t)blockIdx.y * H * W;
+    float* dst = xp + (size_t)blockIdx.y * Hp * Wp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hp * Wp; i += gridDim.x * blockDim.x) {
+        int y = i / Wp - pad, xx = i % Wp - pad;
+        y = y < 0 ? -y : (y >= H ? 2 * (H - 1) - y : y);
+        xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+        dst[i] = src[y * W + xx];
+    }
+}
+
+// dy[N][K][HW] -> [piece][stage][half][BM][8] bf16 pieces, stage = 16 consecutive elements of the (n, y, x) reduction
+__global__ void bsplit_pack_dy_kernel(const float* __restrict__ dy, __bf16* __restrict__ A, int K, int HW, int nst, int bm_shift) {
+    const int BM = 128 << bm_shift;
+    const size_t per_piece = (size_t)nst * 16 * BM;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_piece; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), row = (int)((i >> 3) & (BM - 1)), half = (int)((i >> (10 + bm_shift)) & 1);
+        const size_t st = i >> (11 + bm_shift);
+        const size_t e = st * 16 + half * 8 + j;
+        const size_t n = e / HW, r = e - n * HW;
+        const float v = row < K ? dy[(n * K + row) * HW + r] : 0.f;
+        __bf16 h, mm, l;
+        split3(v, h, mm, l);
+        A[i] = h;
+        A[per_piece + i] = mm;
+        A[2 * per_piece + i] = l;
+    }
+}
+
+// dw[i] (+)= sum over the splits in a fixed order
+__global__ void bsplit_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, size_t total, int accumulate) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float a0 = 0.f, a1 = 0.f;
+    int sp = 0;
+    for (; sp + 1 < splits; sp += 2) {
+        a0 += part[(size_t)sp * total + i];
+        a1 += part[(size_t)(sp + 1) * total + i];
+    }
+    if (sp < splits) a0 += part[(size_t)sp * total + i];
+    const float v = a0 + a1;
+    dw[i] = accumulate ? dw[i] + v : v;
 }
 
 // BM = 128: 4 waves, two workgroups per CU, each thread gathers 8 channels of its pixel per stage.
@@ -111,6 +161,7 @@ template <int MODE, int BM>
 __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
     constexpr bool REFLECT = MODE == BS_FWD_REFLECT;
     constexpr bool DGRAD = MODE == BS_DGRAD_REFLECT;
+    constexpr bool WGRAD = MODE == BS_WGRAD;
     constexpr int NT = BM * 2;              // threads
     constexpr int KB = 2048 / NT;           // channels of one pixel a thread gathers per stage (8 or 4)
     constexpr unsigned ASTAGE = BM * 32;    // bytes of one stage of one piece of the weights
@@ -130,7 +181,8 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
         pt -= a.tstart[phase];
     }
     const int Hs = DGRAD ? (phase == 0 ? a.H - 2 : 1) : a.P;      // rows per image of this phase's pixel list
-    const int T = a.R * a.S, PQ = Hs * a.Q, Ptot = a.N * PQ;
+    const int T = a.R * a.S, PQ = WGRAD ? a.C * T : Hs * a.Q, Ptot = WGRAD ? PQ : a.N * PQ;
+    const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;          // WGRAD: padded planes of xpad
     const int HW4 = a.H * a.W * 4;
     const int pl = tid & 127;
     const int kq = __builtin_amdgcn_readfirstlane(tid >> 7);      // which KB-channel slice of the 16-channel stage
@@ -145,7 +197,11 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
         const int px = rem - py * a.Q;
         if (DGRAD) py = phase == 0 ? (py == 0 ? 0 : (py == Hs - 1 ? a.H - 1 : py + 1)) : (phase == 1 ? 1 : a.H - 2);
         const unsigned nbase = (unsigned)n * (unsigned)a.C * (unsigned)(a.H * a.W);
-        for (int t = kq; t < T; t += NT / 128) {
+        if (WGRAD) {   // column (c, r, s) -> offset of xpad[0][c][r][s]; the reduction part comes through the scalar offset
+            const int c = pg / T, tap = pg - c * T, r = tap / a.S, sx = tap - r * a.S;
+            if (kq == 0) offT[0][pl] = pv ? (unsigned)((c * Hp + r) * Wp + sx) * 4u : BS_OOB;
+        }
+        for (int t = kq; !WGRAD && t < T; t += NT / 128) {
             const int r = t / a.S, s = t - r * a.S;
             int iy = py - a.pad + r, ix = px - a.pad + s;
             bool ok = pv;
@@ -177,13 +233,25 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
         float b[KB];
         float b2[DGRAD ? KB : 1];     // column-mirror source (two lanes per image row are in range)
     };
+    const int nst_here = WGRAD ? min(a.nst_split, a.nst - (int)blockIdx.y * a.nst_split) : a.nst;
+    const int st0 = WGRAD ? (int)blockIdx.y * a.nst_split : 0;
     auto load = [&](Stage& r, int s) {
-        const bool live = s < a.nst;
-        const int cc = s / T, tap = s - cc * T;
+        const bool live = s < nst_here;
+        const int gs = st0 + (live ? s : 0);
         const unsigned avo = live ? (unsigned)tid * 16u : BS_OOB;
-        const unsigned aso = a_tile + (unsigned)(live ? s : 0) * ASTAGE;
+        const unsigned aso = a_tile + (unsigned)gs * ASTAGE;
 #pragma unroll
         for (int p = 0; p < 3; ++p) r.ap[p] = __builtin_amdgcn_raw_buffer_load_b128(rA, avo, aso + p * piece_bytes, 0);
+        if (WGRAD) {   // 16 consecutive x of image n, row y: scalar offset of xpad[n][0][y][x0], the thread's KB values are consecutive
+            const int e0 = gs * 16, hw = a.H * a.W;
+            const int n = e0 / hw, rem = e0 - n * hw, y = rem / a.W, x0 = rem - y * a.W;
+            const unsigned bvo = live ? offT[0][pl] : BS_OOB;
+            const unsigned bso = (unsigned)(((n * a.C) * Hp + y) * Wp + x0 + kq * KB) * 4u;
+#pragma unroll
+            for (int j = 0; j < KB; ++j) r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, bvo, bso + j * 4, 0));
+            return;
+        }
+        const int cc = gs / T, tap = gs - cc * T;
         const unsigned bvo = live ? offT[tap][pl] : BS_OOB;
         const unsigned bso = live ? (unsigned)(cc * 16 + kq * KB) * (unsigned)HW4 : 0u;
 #pragma unroll
@@ -263,7 +331,7 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
     stash(r1, 1);
     __syncthreads();
     load(r1, 3);
-    const int nst2 = (a.nst + 1) & ~1;
+    const int nst2 = (nst_here + 1) & ~1;
     // issue order inside a stage (a hint the scheduler follows where dependences allow): every MFMA is followed by its share of
     // the other work -- LDS reads of the next stage first, then the split arithmetic and LDS writes of the stage after, then the
     // global loads three stages ahead (0.178 -> 0.171 ms)
@@ -304,8 +372,8 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
             const int y = phase == 0 ? (sy == 0 ? 0 : (sy == Hs - 1 ? a.H - 1 : sy + 1)) : (phase == 1 ? 1 : a.H - 2);
             rem = y * a.Q + x;
         }
-        const int PQo = a.P * a.Q;
-        float* yb = a.Y + (size_t)n * a.M * PQo + rem;
+        const int PQo = WGRAD ? PQ : a.P * a.Q;
+        float* yb = a.Y + (WGRAD ? (size_t)blockIdx.y : (size_t)n) * a.M * PQo + rem;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -373,6 +441,7 @@ extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const float* x,
     a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
     a.tstart[0] = a.tstart[1] = a.tstart[2] = a.tstart[3] = 0;
     a.phase_bytes = 0;
+    a.nst_split = 0;
     const size_t ab = 3 * (size_t)a.nMt * a.nst * 32 * bm;
     PCGAN_CHECK(ab < 0x80000000ull, "conv2d_fwd_bsplit: packed weights beyond 2 GiB");
     a.a_bytes = (unsigned)ab;
@@ -433,6 +502,7 @@ extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const floa
     PCGAN_CHECK(3 * per_phase < 0x80000000ull, "conv2d_bwd_data_bsplit: packed weights beyond 2 GiB");
     a.phase_bytes = (unsigned)per_phase;
     a.a_bytes = (unsigned)(3 * per_phase);
+    a.nst_split = 0;
     const long rows[3] = {(long)d->H - 2, 1, 1};
     long t = 0;
     for (int p = 0; p < 3; ++p) {
@@ -443,6 +513,81 @@ extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const floa
     const dim3 grid((unsigned)(t * a.nMt));
     if (bm == 256) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_DGRAD_REFLECT, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
     else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_DGRAD_REFLECT, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------
+extern "C" int pcgan_conv2d_bsplit_wgrad_supported(const pcgan_conv_desc* d) {
+    return d && d->stride == 1 && d->pad_mode == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && d->W % 16 == 0 && d->K >= 32 &&
+           d->P == d->H && d->Q == d->W && (size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4 < 0x80000000ull &&
+           (size_t)d->N * d->H * d->W * 3 * 2 * (size_t)(d->K % 256 == 0 ? 256 : 128) < 0x80000000ull;
+}
+
+static inline int bsplit_wgrad_splits(const pcgan_conv_desc* d, int bm, int* nst_split) {
+    const int nst = d->N * d->H * d->W / 16;
+    const long tiles = (long)((d->C * 9 + 127) / 128) * ((d->K + bm - 1) / bm);
+    long want = (bm == 256 ? 256 : 512) / tiles;          // one round of resident workgroups
+    if (want < 1) want = 1;
+    if (want > nst / 8) want = nst / 8 > 0 ? nst / 8 : 1;
+    *nst_split = (int)((nst + want - 1) / want);
+    return (nst + *nst_split - 1) / *nst_split;
+}
+
+extern "C" size_t pcgan_conv2d_bsplit_wgrad_workspace_bytes(const pcgan_conv_desc* d) {
+    if (!pcgan_conv2d_bsplit_wgrad_supported(d)) return 0;
+    const int bm = d->K % 256 == 0 ? 256 : 128;
+    int per;
+    const int splits = bsplit_wgrad_splits(d, bm, &per);
+    const size_t xpad = pcgan::align_up((size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4, 256);
+    const size_t nMt = (d->K + bm - 1) / bm;
+    const size_t packed = pcgan::align_up(3 * nMt * (size_t)(d->N * d->H * d->W / 16) * 32 * bm, 256);
+    const size_t part = (size_t)splits * nMt * bm * d->C * 9 * 4;
+    return xpad + packed + part;
+}
+
+extern "C" int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+                                              void* ws, size_t ws_bytes, pcgan_stream_t s) {
+    PCGAN_CHECK(pcgan_conv2d_bsplit_wgrad_supported(d), "conv2d_bwd_weight_bsplit: unsupported shape");
+    PCGAN_CHECK(x && dy && dw && ws && ws_bytes >= pcgan_conv2d_bsplit_wgrad_workspace_bytes(d), "conv2d_bwd_weight_bsplit: null pointer or small workspace");
+    const int bm = d->K % 256 == 0 ? 256 : 128;
+    PCGAN_CHECK(d->K % bm == 0, "conv2d_bwd_weight_bsplit: output channels must fill the %d-row tile", bm);
+    hipStream_t st = (hipStream_t)s;
+    int per;
+    const int splits = bsplit_wgrad_splits(d, bm, &per);
+    const int nst = d->N * d->H * d->W / 16, nMt = d->K / bm;
+    const size_t xpad_bytes = pcgan::align_up((size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4, 256);
+    const size_t packed_bytes = pcgan::align_up(3 * (size_t)nMt * nst * 32 * bm, 256);
+    float* xpad = (float*)ws;
+    __bf16* packed = (__bf16*)((char*)ws + xpad_bytes);
+    float* part = (float*)((char*)ws + xpad_bytes + packed_bytes);
+    PCGAN_CHECK(d->N * d->C <= 65535, "conv2d_bwd_weight_bsplit: more than 65535 planes");
+    const int per_plane = (d->H + 2) * (d->W + 2);
+    hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel, dim3((per_plane + 255) / 256, d->N * d->C), dim3(256), 0, st, x, xpad, d->H, d->W, 1);
+    PCGAN_LAUNCH_CHECK();
+    PCGAN_CHECK(nMt == 1, "conv2d_bwd_weight_bsplit: more than one %d-row tile of output channels is not built", bm);
+    const size_t per_piece = (size_t)nst * 16 * bm;
+    hipLaunchKernelGGL(pcgan::bsplit_pack_dy_kernel, dim3((unsigned)((per_piece + 255) / 256 > 8192 ? 8192 : (per_piece + 255) / 256)), dim3(256), 0, st,
+                       dy, packed, d->K, d->H * d->W, nst, bm == 256 ? 1 : 0);
+    PCGAN_LAUNCH_CHECK();
+    pcgan::BsplitArgs a;
+    a.X = xpad; a.A = packed; a.bias = nullptr; a.Y = part;
+    a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->K; a.R = 3; a.S = 3; a.pad = 1; a.reflect = 1;
+    a.P = 1; a.Q = d->C * 9;
+    a.nMt = nMt;
+    a.nst = nst;
+    a.nst_split = per;
+    a.act = PCGAN_ACT_NONE; a.slope = 0.f;
+    a.x_bytes = (unsigned)((size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4);
+    a.a_bytes = (unsigned)(3 * (size_t)nMt * nst * 32 * bm);
+    a.tstart[0] = a.tstart[1] = a.tstart[2] = a.tstart[3] = 0;
+    a.phase_bytes = 0;
+    const dim3 grid((unsigned)(((d->C * 9 + 127) / 128) * nMt), (unsigned)splits);
+    if (bm == 256) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_WGRAD, 256>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_WGRAD, 128>), grid, dim3(256), 0, st, a);
+    PCGAN_LAUNCH_CHECK();
+    const size_t total = (size_t)d->K * d->C * 9;
+    hipLaunchKernelGGL(pcgan::bsplit_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, dw, splits, total, accumulate);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

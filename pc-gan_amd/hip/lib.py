@@ -81,6 +81,9 @@ SIGNATURES = {
     'pcgan_conv2d_bsplit_dgrad_packed_bytes': (_sz, [_dp]),
     'pcgan_conv2d_bsplit_dgrad_pack': (_i, [_dp, _vp, _vp, _vp]),
     'pcgan_conv2d_bwd_data_bsplit': (_i, [_dp, _vp, _vp, _vp, _vp]),
+    'pcgan_conv2d_bsplit_wgrad_supported': (_i, [_dp]),
+    'pcgan_conv2d_bsplit_wgrad_workspace_bytes': (_sz, [_dp]),
+    'pcgan_conv2d_bwd_weight_bsplit': (_i, [_dp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     'pcgan_image_transform_band': (_i, [_ip, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     'pcgan_image_transform': (_i, [_ip, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }

@@ -276,6 +276,11 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=N
         dw = accumulate_into
     else:
         dw = torch.empty((K, C, R, S), dtype=torch.float32, device=x.device)
+    if BF16X6 and K in (128, 256) and N * H * W >= 16384 and lib.pcgan_conv2d_bsplit_wgrad_supported(ctypes.byref(d)):
+        ws = _ws(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
+        _L.check(lib.pcgan_conv2d_bwd_weight_bsplit(ctypes.byref(d), _p(x), _p(dy), _p(dw), int(accumulate_into is not None),
+                                                    _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight_bsplit')
+        return dw
     nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_BWD_WEIGHT)
     ws = _ws(nb, x.device)
     _L.check(lib.pcgan_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), int(accumulate_into is not None),

@@ -57,3 +57,23 @@ for name, fn in (('dgrad fp32 MFMA', g32), ('dgrad bf16x6   ', g6)):
         e_.record(); torch.cuda.synchronize()
         best = min(best, s_.elapsed_time(e_) / 50)
     print('%s %.4f ms  %.1f TFLOP/s fp32-equivalent' % (name, best, 38.65 / best))
+
+# weight gradient
+wsw = torch.empty(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+dw = torch.empty(256, 256, 3, 3, device=dev)
+def h6():
+    L.check(lib.pcgan_conv2d_bwd_weight_bsplit(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0, wsw.data_ptr(), wsw.numel(), st), 'wgrad')
+def h32():
+    ops.conv2d_bwd_weight(x, dy, (256, 256, 3, 3), 1, 1, 1)
+for name, fn in (('wgrad fp32 MFMA', h32), ('wgrad bf16x6   ', h6)):
+    for _ in range(5):
+        fn()
+    best = 1e9
+    for _ in range(3):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        for _ in range(50):
+            fn()
+        e_.record(); torch.cuda.synchronize()
+        best = min(best, s_.elapsed_time(e_) / 50)
+    print('%s %.4f ms  %.1f TFLOP/s fp32-equivalent' % (name, best, 38.65 / best))

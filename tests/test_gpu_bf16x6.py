@@ -113,3 +113,35 @@ def test_bsplit_reflect_data_gradient(dev, N, C, H, W, K):
     torch.cuda.synchronize()
     e = lambda t: float((t.double().cpu() - ref).norm() / ref.norm())
     assert e(dx) < 3e-6 and e(dx) < 4 * e(dx32) + 5e-7, (e(dx), e(dx32))
+
+
+@pytest.mark.parametrize('N,C,H,W,K,acc', [
+    (2, 256, 32, 32, 256, False),     # the residual-block convolution
+    (3, 40, 6, 16, 128, True),        # 128-row tile, ragged column tile (360 columns), accumulate into an existing gradient
+    (1, 16, 4, 16, 256, False),       # smallest grid
+])
+def test_bsplit_weight_gradient(dev, N, C, H, W, K, acc):
+    """dW of ReflectionPad2d(1) + Conv2d(3x3) through the split kernel (roles turned, reduction over pixels) against autograd in
+    float64 and the fp32 kernel"""
+    from pcgan_amd.hip import lib as L, ops
+    g = torch.Generator().manual_seed(N * 100 + C + K)
+    x = torch.randn(N, C, H, W, generator=g)
+    dy = torch.randn(N, K, H, W, generator=g)
+    w = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    R.conv2d(x.double(), w, None, 1, 1, 1).backward(dy.double())
+    ref = w.grad
+    d = ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 1)
+    lib = L.load()
+    assert lib.pcgan_conv2d_bsplit_wgrad_supported(ctypes.byref(d))
+    xd, dyd = x.to(dev), dy.to(dev)
+    ws = torch.empty(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    base = torch.randn(K, C, 3, 3, generator=g) if acc else None
+    dw = base.to(dev).clone() if acc else torch.full((K, C, 3, 3), float('nan'), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.pcgan_conv2d_bwd_weight_bsplit(ctypes.byref(d), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), int(acc), ws.data_ptr(),
+                                               ws.numel(), st), 'wgrad')
+    dw32 = ops.conv2d_bwd_weight(xd, dyd, (K, C, 3, 3), 1, 1, 1)
+    torch.cuda.synchronize()
+    got = dw.double().cpu() - (base.double() if acc else 0)
+    e = lambda t: float((t - ref).norm() / ref.norm())
+    assert e(got) < 3e-6 and e(got) < 4 * e(dw32.double().cpu()) + 5e-7, (e(got), e(dw32.double().cpu()))
