@@ -30,5 +30,7 @@ def test_committed_line_has_the_contract_fields():
     r = line['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic'] > 0
     assert abs(r['achieved'] - r['flop_per_launch'] / (r['ms_per_launch'] * 1e-3) / 1e12) < 0.05 and r['launches_timed'] == 36 * line['steps']
+    if 'experiment_bf16x6' in line:      # labelled as not the default path; the headline stays the fp32 MFMA measurement
+        assert line['experiment_bf16x6']['default'] is False and line['experiment_bf16x6']['value'] > 0
     c = line['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
