@@ -34,6 +34,8 @@ def get_transform(opt):
             raise NotImplementedError('pcgan_amd: --transforms %s is outside the hot path' % opt.transforms)
         w, h = img.size
         fs = opt.fineSize
+        if w < fs or h < fs:    # torchvision's RandomCrop refuses too (no pad_if_needed in the reference's pipeline)
+            raise ValueError('Required crop size %s is larger than input image size %s' % ((fs, fs), (h, w)))
         x0 = random.randint(0, w - fs) if w > fs else 0
         y0 = random.randint(0, h - fs) if h > fs else 0
         img = img.crop((x0, y0, x0 + fs, y0 + fs))

@@ -90,6 +90,14 @@ def test_pil_transform_matches_oracle(tmp_path):
         assert got.shape == (3, 32, 32) and got.dtype == torch.float32 and -1.0 <= float(got.min()) and float(got.max()) <= 1.0
 
 
+def test_crop_larger_than_image_is_refused(tmp_path):
+    from pcgan_amd.data.base_dataset import get_transform
+    _make_images(tmp_path)
+    tf = get_transform(_opt(tmp_path, ['--transforms', 'crop', '--fineSize', '64']))
+    with pytest.raises(ValueError, match='larger than input image'):
+        tf(Image.open(tmp_path / 'img_0.png').convert('RGB'))
+
+
 def test_pair_dataset_layout(tmp_path):
     from pcgan_amd.data import CreateDataLoader
     names = _make_images(tmp_path)
