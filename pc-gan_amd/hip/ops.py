@@ -157,9 +157,10 @@ def invalidate_packed_weights():
     _PACK_EPOCH[0] += 1
 
 
-# EXPERIMENT (default off): stride-1 convolutions with C % 16 == 0 forward on the bf16 matrix pipe, every fp32 operand
-# split exactly into three bf16 pieces, six piece products per term (csrc/bf16x6_conv.hip): fp32-level error.
-BF16X6 = os.environ.get('PCGAN_BF16X6', '0') == '1'
+# The residual-block convolutions (forward, data gradient, weight gradient) run on the bf16 matrix pipe with every fp32
+# operand split exactly into three bf16 pieces, six piece products per term (csrc/bf16x6_conv.hip): fp32-level error at
+# 1.5x the speed of the fp32 MFMA kernels.  PCGAN_BF16X6=0 routes them back to the fp32 MFMA implicit GEMM (A/B runs).
+BF16X6 = os.environ.get('PCGAN_BF16X6', '1') == '1'
 PASS_FWD_BSPLIT = 100    # cache keys only
 PASS_BWD_BSPLIT = 101
 

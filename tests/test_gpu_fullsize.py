@@ -22,12 +22,17 @@ from util_cmp import assert_close
 
 pytestmark = pytest.mark.gpu
 
-# the layers that carry the step: name, C, H, K, R, stride, pad, pad_mode
+# the layers that carry the step: name, C, H, K, R, stride, pad, pad_mode, batch
 FULL = [
-    ('G.res 256->256 3x3 reflect @32', 256, 32, 256, 3, 1, 1, 1),
-    ('G.down2 128->256 3x3 s2 @64', 128, 64, 256, 3, 2, 1, 0),
-    ('D.c3 256->512 4x4 @16', 256, 16, 512, 4, 1, 1, 0),
-    ('G.head 64->3 7x7 reflect @128', 64, 128, 3, 7, 1, 3, 1),
+    ('G.res 256->256 3x3 reflect @32', 256, 32, 256, 3, 1, 1, 1, 32),
+    ('G.down2 128->256 3x3 s2 @64', 128, 64, 256, 3, 2, 1, 0, 32),
+    ('D.c3 256->512 4x4 @16', 256, 16, 512, 4, 1, 1, 0, 32),
+    ('G.head 64->3 7x7 reflect @128', 64, 128, 3, 7, 1, 3, 1, 32),
+    # the shapes BASELINE configs 4 / 5 (256x256 images, batch 8 / 16 per GPU) put on the same kernels
+    ('G.res 256->256 3x3 reflect @64 bs8 (256x256)', 256, 64, 256, 3, 1, 1, 1, 8),
+    ('G.down2 128->256 3x3 s2 @128 bs8 (256x256)', 128, 128, 256, 3, 2, 1, 0, 8),
+    ('G.down1 64->128 3x3 s2 @256 bs8 (256x256)', 64, 256, 128, 3, 2, 1, 0, 8),
+    ('D.c3 256->512 4x4 @32 bs16 (256x256)', 256, 32, 512, 4, 1, 1, 0, 16),
 ]
 
 
@@ -38,8 +43,8 @@ def _dot(a, b):
 @pytest.mark.parametrize('case', FULL, ids=[c[0] for c in FULL])
 def test_fullsize_conv_properties(case, dev):
     from pcgan_amd.hip import ops
-    name, C, H, K, Rk, stride, pad, pm = case
-    N = 32
+    name, C, H, K, Rk, stride, pad, pm, N = case
+    lo, hi = N // 4, N // 2          # the batch slice re-run on its own
     g = torch.Generator().manual_seed(sum(map(ord, name)))
     x = (torch.rand(N, C, H, H, generator=g) * 2 - 1).to(dev)
     x2 = (torch.rand(N, C, H, H, generator=g) * 2 - 1).to(dev)
@@ -64,10 +69,10 @@ def test_fullsize_conv_properties(case, dev):
     assert_close(ylin, (0.5 * y.double() - 2.0 * y2.double()).cpu(), 2e-5, name + ' linearity')
 
     # batch-slice consistency (forward, data gradient)
-    y8 = ops.conv2d_fwd(x[8:16].contiguous(), w, None, stride, pad, pm)
-    assert_close(y8, y[8:16].double().cpu(), 1e-5, name + ' forward of a batch slice')
-    dx8 = ops.conv2d_bwd_data(dy[8:16].contiguous(), w, (H, H), stride, pad, pm)
-    assert_close(dx8, dx[8:16].double().cpu(), 1e-5, name + ' data gradient of a batch slice')
+    y8 = ops.conv2d_fwd(x[lo:hi].contiguous(), w, None, stride, pad, pm)
+    assert_close(y8, y[lo:hi].double().cpu(), 1e-5, name + ' forward of a batch slice')
+    dx8 = ops.conv2d_bwd_data(dy[lo:hi].contiguous(), w, (H, H), stride, pad, pm)
+    assert_close(dx8, dx[lo:hi].double().cpu(), 1e-5, name + ' data gradient of a batch slice')
 
     # one image against the oracle (float64 twin on the CPU)
     xc = x[5:6].double().cpu().requires_grad_(True)
@@ -76,12 +81,12 @@ def test_fullsize_conv_properties(case, dev):
     yr.backward(dy[5:6].double().cpu())
     assert_close(y[5:6], yr.detach(), 2e-5, name + ' image 5 forward vs oracle')
     assert_close(dx[5:6], xc.grad, 2e-5, name + ' image 5 data gradient vs oracle')
-    # weight gradient of a bs-8 slice against the oracle
-    x8 = x[:8].double().cpu()
+    # weight gradient of a quarter of the batch against the oracle
+    x8 = x[:lo].double().cpu()
     w8 = w.double().cpu().requires_grad_(True)
-    R.conv2d(x8, w8, None, stride, pad, pm).backward(dy[:8].double().cpu())
-    dw8 = ops.conv2d_bwd_weight(x[:8].contiguous(), dy[:8].contiguous(), tuple(w.shape), stride, pad, pm)
-    assert_close(dw8, w8.grad, 1e-4, name + ' weight gradient (8 images) vs oracle')
+    R.conv2d(x8, w8, None, stride, pad, pm).backward(dy[:lo].double().cpu())
+    dw8 = ops.conv2d_bwd_weight(x[:lo].contiguous(), dy[:lo].contiguous(), tuple(w.shape), stride, pad, pm)
+    assert_close(dw8, w8.grad, 1e-4, name + ' weight gradient (%d images) vs oracle' % lo)
 
 
 def test_fullsize_step_vs_oracle(tmp_path, dev):
