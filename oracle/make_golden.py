@@ -119,15 +119,38 @@ STEP_VARIANTS = {
     'lambda_A_GAN': ['--lambda_A_GAN', '0.3', '--lambda_L1', '0.7'],
     'detach_fake_B': ['--detach_fake_B'],
     'no_ip_no_z': ['--lambda_IP', '0', '--lambda_z', '0'],
+    # one label for the whole batch, drawn with np.random.choice; per-label input keys (models/wsgan_emb_model.py:199-207)
+    'no_mixed_label_D': ['--no_mixed_label_D'],
+    # InstanceNorm discriminator: its convolutions gain biases, the norm entries become buffers only (models/networks.py:740-743)
+    'norm_D_instance': ['--norm_D', 'instance'],
 }
 
 
-def golden_steps(rn, outdir):
+def step_batch(name, it):
+    """the seeded input dict of iteration `it` of a step variant (shared with the tests)"""
+    A = W.seeded_tensor((4, 3, 32, 32), 500 + it)
+    B = W.seeded_tensor((4, 3, 32, 32), 600 + it)
+    if name == 'no_mixed_label_D':
+        # what WSGANEmbDataset yields under --no_mixed_label_D: one pair set per label that has lines (0 and 2 here)
+        A2 = W.seeded_tensor((4, 3, 32, 32), 520 + it)
+        B2 = W.seeded_tensor((4, 3, 32, 32), 620 + it)
+        return {'0_A': A, '0_B': B, '0_A_paths': ['a0'] * 4, '0_B_paths': ['b0'] * 4,
+                '2_A': A2, '2_B': B2, '2_A_paths': ['a2'] * 4, '2_B_paths': ['b2'] * 4}
+    label = torch.tensor([0, 2, 2, 0] if it == 0 else [2, 0, 1, 0], dtype=torch.int64)
+    return {'A': A, 'B': B, 'label': label, 'A_paths': ['a'] * 4, 'B_paths': ['b'] * 4}
+
+
+NP_SEED = 4242      # numpy's global generator is seeded with NP_SEED + it before set_input (np.random.choice of the label)
+
+
+def golden_steps(rn, outdir, only=None):
     """Full optimize_parameters() x2 through the reference's own option parser and model class."""
     from options.train_options import TrainOptions
     from models import create_model
     tmp = tempfile.mkdtemp(prefix='pcgan_golden_')
     for name, extra in STEP_VARIANTS.items():
+        if only and name not in only:
+            continue
         noisy = 'true' in [a for i, a in enumerate(extra) if i > 0 and extra[i - 1] == '--noisy']
         drop = 0.2 if '--bnn_dropout' in extra else 0.0
         # fabricated "pretrained" checkpoints with deterministic weights
@@ -152,10 +175,8 @@ def golden_steps(rn, outdir):
         model.netD.load_state_dict(W.fill_state_dict(model.netD.state_dict(), 20))
         out = {}
         for it in range(2):
-            A = W.seeded_tensor((4, 3, 32, 32), 500 + it)
-            B = W.seeded_tensor((4, 3, 32, 32), 600 + it)
-            label = torch.tensor([0, 2, 2, 0] if it == 0 else [2, 0, 1, 0], dtype=torch.int64)
             torch.manual_seed(1234 + it)
+            np.random.seed(NP_SEED + it)
             # capture grads at the moment of each optimizer step
             grabbed, origs = {}, {}
             for tag, optim, net in (('G', model.optimizer_G, model.netG), ('D', model.optimizer_D, model.netD)):
@@ -166,10 +187,11 @@ def golden_steps(rn, outdir):
                                     for k, p in net.named_parameters()]
                     return orig()
                 optim.step = stepper
-            model.set_input({'A': A, 'B': B, 'label': label, 'A_paths': ['a'] * 4, 'B_paths': ['b'] * 4})
+            model.set_input(step_batch(name, it))
             model.optimize_parameters()
             model.optimizer_G.step, model.optimizer_D.step = origs['G'], origs['D']
             p = 'it%d' % it
+            out[p + '/label_AB'] = np.array([int(v) for v in model.label_AB], dtype=np.int64)
             losses = model.get_current_losses()
             out[p + '/losses'] = np.array([losses[k] for k in model.loss_names], dtype=np.float64)
             for k in ('fake_B', 'rec_A', 'embedding_A', 'embedding_B', 'y_A', 'y_B'):
@@ -200,6 +222,49 @@ def golden_steps(rn, outdir):
                     s.step()
             np.savez(os.path.join(outdir, 'lr_schedule.npz'), lr=np.array(lrs), niter=opt.niter,
                      niter_decay=opt.niter_decay, epoch_count=opt.epoch_count, base_lr=opt.lr)
+
+
+def golden_visuals(rn, outdir):
+    """get_current_visuals() of wsgan_emb (models/wsgan_emb_model.py:486-497): after one training step the model runs G on
+    real_A[0:1] once per fixed rating bin IN TRAIN MODE, which moves the InstanceNorm running statistics; recorded: the
+    attr_<i> images and G's buffers before / after the call."""
+    from options.train_options import TrainOptions
+    from models import create_model
+    tmp = tempfile.mkdtemp(prefix='pcgan_golden_vis_')
+    e = rn.SiameseFeature(rn.ResNetFeature(3, 'resnet18', dropout=0.0), pooling='avg', cnn_dim=[32, 1], cnn_pad=1,
+                          cnn_relu_slope=0.7, noisy=False, drop_layer=rn.get_dropout_layer(0.0))
+    e_path = os.path.join(tmp, 'E.pth')
+    torch.save(W.fill_state_dict(e.state_dict(), 30), e_path)
+    ip = rn.AlexNetFeature(input_nc=3, pooling='None')
+    ip_path = os.path.join(tmp, 'IP.pth')
+    torch.save(W.fill_state_dict(ip.state_dict(), 40), ip_path)
+    sys.argv = ['train.py', '--dataroot', tmp, '--model', 'wsgan_emb', '--name', 'g_vis', '--checkpoints_dir', tmp, '--gpu_ids', '-1',
+                '--which_model_netG', 'resnet_9blocks', '--which_model_netD', 'n_layers', '--n_layers_D', '3', '--ngf', '8',
+                '--ndf', '8', '--fineSize', '32', '--loadSize', '32', '--fineSize_E', '64', '--fineSize_IP', '64', '--batchSize', '4',
+                '--pretrained_model_path_E', e_path, '--pretrained_model_path_IP', ip_path, '--display_id', '-1',
+                '--embedding_bins', '[-1.0, 0.0, 1.5]', '--embedding_mean', '0.1', '--embedding_std', '0.8']
+    opt = TrainOptions().parse()
+    model = create_model(opt)
+    model.setup(opt)
+    model.netG.load_state_dict(W.damp_generator_head(W.fill_state_dict(model.netG.state_dict(), 19)))
+    model.netD.load_state_dict(W.fill_state_dict(model.netD.state_dict(), 20))
+    torch.manual_seed(1234)
+    model.set_input(step_batch('default', 0))
+    model.optimize_parameters()
+    out = {}
+    for k, v in model.netG.state_dict().items():
+        if 'running' in k:
+            out['before/' + k] = t2n(v).copy()
+    vis = model.get_current_visuals()
+    out['names'] = np.array(list(vis.keys()))
+    for k, v in vis.items():
+        out['vis/' + k] = t2n(v)
+    for k, v in model.netG.state_dict().items():
+        if 'running' in k:
+            out['after/' + k] = t2n(v).copy()
+    out['requires_grad_after'] = np.array([p.requires_grad for p in model.netG.parameters()])
+    np.savez_compressed(os.path.join(outdir, 'visuals.npz'), **out)
+    print('visuals.npz: %d arrays, visuals %s' % (len(out), list(vis.keys())))
 
 
 def golden_cycle_step(rn, outdir):
@@ -349,6 +414,7 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
     ap.add_argument('--only', default='')
+    ap.add_argument('--variants', default='', help='comma-separated step variants (with --only steps); default: all')
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     rn = import_reference()
@@ -358,7 +424,9 @@ if __name__ == '__main__':
     if a.only in ('', 'ints'):
         golden_ints(a.out)
     if a.only in ('', 'steps'):
-        golden_steps(rn, a.out)
+        golden_steps(rn, a.out, [v for v in a.variants.split(',') if v] or None)
+    if a.only in ('', 'visuals'):
+        golden_visuals(rn, a.out)
     if a.only in ('', 'cycle'):
         golden_cycle_step(rn, a.out)
     if a.only in ('', 'siamese'):

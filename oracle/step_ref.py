@@ -132,6 +132,28 @@ class WSGANEmbStepRef:
         """models/wsgan_emb_model.py:193-212 (mixed-label branch)"""
         self.real_A, self.real_B, self.label_AB = real_A, real_B, label_AB
 
+    def set_input_no_mixed(self, batch, weight_label_D=(0.5, 0.0, 0.5)):
+        """models/wsgan_emb_model.py:199-207 (`--no_mixed_label_D`): ONE label for the whole batch, drawn from numpy's
+        global generator with the normalised --weight_label_D; the batch dict carries one pair set per label."""
+        total = float(sum(weight_label_D))
+        p = [w / total for w in weight_label_D]
+        L = np.random.choice(range(len(self.opt.relabel_D)), p=p)
+        self.label_AB = [L]
+        self.real_A, self.real_B = batch[str(L) + '_A'], batch[str(L) + '_B']
+
+    def get_current_visuals(self, fixed_ratings):
+        """models/wsgan_emb_model.py:486-497 with --display_visuals: G on real_A[0:1] once per fixed rating, in whatever
+        mode G is in (train mode during training: InstanceNorm running statistics move)."""
+        for p in self.netG.parameters():
+            p.requires_grad = False
+        ret = {'real_A': self.real_A, 'fake_B': self.fake_B, 'real_B': self.real_B, 'rec_A': self.rec_A}
+        for i, r in enumerate(fixed_ratings):
+            emb = self.embedding_normalize(torch.tensor([float(r)], dtype=self.real_A.dtype).reshape(1, 1, 1, 1))
+            ret['attr_%d' % i] = self.netG(self.real_A[0:1, ...], emb)
+        for p in self.netG.parameters():
+            p.requires_grad = True
+        return ret
+
     def forward(self):
         """models/wsgan_emb_model.py:214-259 (transform_E / transform_IP are identities)"""
         o = self.opt

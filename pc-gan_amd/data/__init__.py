@@ -2,9 +2,16 @@
 `--dataset_mode`, `CreateDataLoader(opt).load_data()` yielding dict batches with the keys the
 model's set_input reads ('A', 'B', 'label', 'A_paths', 'B_paths').
 
-Under torch.distributed every rank draws the same global batch order and keeps its contiguous
-slice (DataParallel's scatter), see pcgan_amd.hip.parallel.shard_batch.
+Under torch.distributed (one process per GPU) the loader is sharded at the SAMPLER: all ranks walk one
+permutation of the data set per epoch (shared seed: `--seed`, else drawn on rank 0 and broadcast), cut it into
+global batches of `--batchSize`, and rank r decodes / transforms / uploads only samples [r*B/n, (r+1)*B/n) of each
+global batch -- the contiguous slice DataParallel's scatter would hand to device r (reference
+models/networks.py:96-102).  The last partial global batch of an epoch is dropped when there is more than one rank
+(a ragged batch cannot be split evenly; a single process keeps it, like the reference's DataLoader).
 """
+import random
+
+import torch
 import torch.utils.data
 
 from .base_dataset import BaseDataset
@@ -34,22 +41,78 @@ def _collate_keep_raw(samples):
     return rest
 
 
+class RankShardedBatchSampler(torch.utils.data.Sampler):
+    """Batch sampler of one rank: a seeded per-epoch permutation shared by all ranks, cut into global batches of
+    `global_batch`; yields this rank's contiguous slice of every FULL global batch."""
+
+    def __init__(self, n_samples, global_batch, world, rank, shuffle, seed):
+        assert global_batch % world == 0, '--batchSize %d (the global batch) must be divisible by the %d ranks' % (global_batch, world)
+        self.n, self.B, self.world, self.rank = int(n_samples), int(global_batch), int(world), int(rank)
+        self.per = self.B // self.world
+        self.shuffle, self.seed, self.epoch = bool(shuffle), int(seed), 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def order(self):
+        if not self.shuffle:
+            return list(range(self.n))
+        g = torch.Generator().manual_seed(self.seed + 7919 * self.epoch)
+        return torch.randperm(self.n, generator=g).tolist()
+
+    def __len__(self):
+        return self.n // self.B
+
+    def __iter__(self):
+        order = self.order()
+        for b in range(self.n // self.B):
+            lo = b * self.B + self.rank * self.per
+            yield order[lo:lo + self.per]
+
+
+def shared_seed(opt):
+    """`--seed` if given, else one number drawn on rank 0 and broadcast (every rank must shuffle alike)."""
+    from ..hip import parallel
+    if getattr(opt, 'seed', None) is not None:
+        return int(opt.seed)
+    box = [random.SystemRandom().randrange(1 << 31)]
+    if parallel.is_distributed():
+        torch.distributed.broadcast_object_list(box, src=0)
+    return int(box[0])
+
+
 class CustomDatasetDataLoader(object):
     """Iterable over dict batches, capped at --max_dataset_size samples (reference data/__init__.py:42-69)."""
 
     def name(self):
         return 'CustomDatasetDataLoader'
 
-    def initialize(self, opt):
+    def initialize(self, opt, world=None, rank=None):
+        from ..hip import parallel
         self.opt = opt
+        if world is None:
+            world, rank = (torch.distributed.get_world_size(), torch.distributed.get_rank()) if parallel.is_distributed() else (1, 0)
+        self.world, self.rank = world, rank
         self.dataset = create_dataset(opt)
         self.gpu_transform = None
         if getattr(opt, 'gpu_transform', False) and opt.dataroot != 'synthetic':
             from .gpu_transform import GpuTransform
             self.gpu_transform = GpuTransform(opt, 'cuda:%d' % opt.gpu_ids[0] if opt.gpu_ids else 'cpu')
-        self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=opt.batchSize, num_workers=int(opt.nThreads),
-                                                      shuffle=not opt.serial_batches,
-                                                      collate_fn=_collate_keep_raw if self.gpu_transform else None)
+        collate = _collate_keep_raw if self.gpu_transform else None
+        self.sampler = None
+        if world > 1:
+            seed = shared_seed(opt)
+            # the data set reshuffles its pair list whenever its length is taken (reference quirk kept): with a shared
+            # generator every rank holds the same list order, so index i means the same pair everywhere
+            self.dataset.shuffle_rng = random.Random(seed)
+            self.sampler = RankShardedBatchSampler(min(len(self.dataset), opt.max_dataset_size), opt.batchSize, world, rank,
+                                                   not opt.serial_batches, seed)
+            self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_sampler=self.sampler, num_workers=int(opt.nThreads),
+                                                          collate_fn=collate)
+        else:
+            self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=opt.batchSize, num_workers=int(opt.nThreads),
+                                                          shuffle=not opt.serial_batches, collate_fn=collate)
+        self._epochs = 0
         return self
 
     def _finish_on_gpu(self, batch):
@@ -68,13 +131,19 @@ class CustomDatasetDataLoader(object):
         return min(len(self.dataset), self.opt.max_dataset_size)
 
     def __iter__(self):
+        if self.sampler is not None:
+            # one reshuffle of the pair list per epoch, in the parent and BEFORE the workers fork: identical on every rank
+            len(self.dataset)
+            self.sampler.set_epoch(self._epochs)
+            self._epochs += 1
         seen = 0
         for batch in self.dataloader:
             if seen >= self.opt.max_dataset_size:
                 return
-            seen += self.opt.batchSize
+            seen += self.opt.batchSize          # (the global batch: every rank stops at the same point)
             yield self._finish_on_gpu(batch) if self.gpu_transform else batch
 
 
-def CreateDataLoader(opt):
-    return CustomDatasetDataLoader().initialize(opt)
+def CreateDataLoader(opt, world=None, rank=None):
+    """world / rank default to the torch.distributed group (1 / 0 without one)."""
+    return CustomDatasetDataLoader().initialize(opt, world, rank)

@@ -61,6 +61,7 @@ class WSGANCycleDataset(BaseDataset):
 
     def __len__(self):
         if not self.synthetic:      # the reference reshuffles both lists every time len() is taken (:53-59)
-            random.shuffle(self.A_paths)
-            random.shuffle(self.B_paths)
+            shuffle = (getattr(self, 'shuffle_rng', None) or random).shuffle    # shared generator under torch.distributed
+            shuffle(self.A_paths)
+            shuffle(self.B_paths)
         return max(self.A_size, self.B_size)

@@ -83,11 +83,13 @@ class WSGANEmbDataset(BaseDataset):
         return ret
 
     def __len__(self):
-        # the reference reshuffles its pair list every time len() is taken (wsgan_emb_dataset.py:72-79)
+        # the reference reshuffles its pair list every time len() is taken (wsgan_emb_dataset.py:72-79); under
+        # torch.distributed the loader installs a generator shared by all ranks (data/__init__.py)
         if not self.synthetic:
+            shuffle = (getattr(self, 'shuffle_rng', None) or random).shuffle
             if not self.opt.no_mixed_label_D:
-                random.shuffle(self.sourcefile)
+                shuffle(self.sourcefile)
             else:
                 for L in self.sourcefiles:
-                    random.shuffle(self.sourcefiles[L])
+                    shuffle(self.sourcefiles[L])
         return self.size

@@ -1,0 +1,51 @@
+"""Child process of tests/test_gpu_ddp.py (not a test module): one rank of a data-parallel step of the PRODUCT model.
+
+    RANK / WORLD_SIZE / MASTER_* in the environment, PCGAN_DIST_BACKEND=gloo (several ranks share the one GPU of the box).
+    argv: <out.pt> <lo> <hi>   -- this rank steps samples [lo, hi) of the fixed 4-sample batch
+
+Writes the flat G / D gradient buffers as they are when each optimizer steps (i.e. after the all-reduce), the flat
+parameter buffers after the step and the losses."""
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def main():
+    out, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    from pcgan_amd.hip import parallel
+    import bench
+    world, rank, _ = parallel.init_process_group()
+    torch.cuda.set_device(0)
+    tmp = tempfile.mkdtemp(prefix='pcgan_ddp_%d_' % rank)
+    # every rank builds from its own seed: broadcast_parameters must then install rank 0's weights everywhere
+    model, opt = bench.build_model(0, hi - lo, 32, tmp, seed=7 + (rank if world > 1 else 0), ngf=8, ndf=8, fine_e=64, n_blocks=2)
+    grabbed = {}
+    for tag, optim in (('G', model.optimizer_G), ('D', model.optimizer_D)):
+        orig = optim.step
+
+        def stepper(orig=orig, tag=tag, optim=optim):
+            grabbed['g' + tag] = optim.gflat.detach().clone().cpu()
+            return orig()
+        optim.step = stepper
+    b = bench.synthetic_batch(4, 32, 0)
+    batch = {k: v[lo:hi] for k, v in b.items()}
+    model.set_input(batch)
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+    grabbed['pG'] = model.optimizer_G.flat.detach().clone().cpu()
+    grabbed['pD'] = model.optimizer_D.flat.detach().clone().cpu()
+    grabbed['losses'] = dict(model.get_current_losses())
+    grabbed['distributed'] = parallel.is_distributed()
+    torch.save(grabbed, out)
+    if parallel.is_distributed():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

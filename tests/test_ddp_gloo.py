@@ -86,6 +86,11 @@ def _worker(rank, world, port, out):
     label = [0, 2, 2, 0]
     sl = slice(rank * 2, rank * 2 + 2)
     gG, gD = _half_step(m, A[sl], B[sl], label[sl], parallel.sync_gradients)
+    # replicas must hold identical weights after the step (same averaged gradients into the same Adam state)
+    flat = torch.cat([p.detach().reshape(-1) for net in (m.netG, m.netD) for p in net.parameters()])
+    both = [torch.zeros_like(flat), torch.zeros_like(flat)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1]), 'replicas diverged after one step'
     if rank == 0:
         torch.save({'gG': gG, 'gD': gD, 'pG': {k: v.detach() for k, v in m.netG.named_parameters()}}, out)
     dist.barrier()
@@ -110,6 +115,9 @@ def test_two_rank_step_equals_single_process_reference(tmp_path):
     for k, g in got['gG'].items():
         want = 0.5 * (halves[0][0][k] + halves[1][0][k])
         assert torch.allclose(g, want, rtol=1e-4, atol=1e-6), 'G grad ' + k
-    # the D gradients of the 2-rank run come after a G step made with AVERAGED gradients, whereas each
-    # single-process half stepped G with its own gradients; only the G side is comparable term by term.
+    # backward_D runs on fake_B from forward() (made BEFORE the G step, models/wsgan_emb_model.py:478-484) and on D's own
+    # weights, so the D gradients do not depend on how G was stepped in between: they are comparable term by term too
     assert set(got['gD']) == set(halves[0][1])
+    for k, g in got['gD'].items():
+        want = 0.5 * (halves[0][1][k] + halves[1][1][k])
+        assert torch.allclose(g, want, rtol=1e-4, atol=1e-6), 'D grad ' + k

@@ -17,8 +17,8 @@ import torch
 
 from oracle import networks_ref as N
 from oracle import weights as W
-from oracle.make_golden import STEP_VARIANTS
-from test_oracle_golden import build_oracle_step, step_inputs
+from oracle.make_golden import STEP_VARIANTS, step_batch, NP_SEED
+from test_oracle_golden import build_oracle_step, step_inputs, oracle_set_input
 from util_cmp import assert_close
 
 pytestmark = pytest.mark.gpu
@@ -76,7 +76,7 @@ def _rel_l2(a, b):
 
 
 @pytest.mark.parametrize('variant', ['default', 'use_real_A', 'lambda_A_GAN', 'detach_fake_B', 'no_ip_no_z',
-                                     'noisy_a', 'bayesian_e', 'bayesian_noisy_ae'])
+                                     'noisy_a', 'bayesian_e', 'bayesian_noisy_ae', 'no_mixed_label_D', 'norm_D_instance'])
 def test_step_matches_reference_and_oracle(variant, tmp_path, dev):
     from pcgan_amd.hip import nn as hnn
     from pcgan_amd.util import util as hutil
@@ -90,14 +90,13 @@ def test_step_matches_reference_and_oracle(variant, tmp_path, dev):
         net.double()
     grabbed = _grab_grads(model)
     for it in range(2):
-        A, B, label = step_inputs(it)
         oracle_prev = {'G': {k: v.detach().clone() for k, v in oracle.netG.named_parameters()},
                        'D': {k: v.detach().clone() for k, v in oracle.netD.named_parameters()}}
         # 1. oracle on CPU under the reference's seed; record every random draw
         N.Dropout2dRec.record = []
         oracle.draws = []
         torch.manual_seed(1234 + it)
-        oracle.set_input(A, B, label)
+        oracle_set_input(oracle, variant, it)
         oracle.optimize_parameters()
         masks, N.Dropout2dRec.record = N.Dropout2dRec.record, None
         # 1b. the fp64 twin replays the same draws from the same weights
@@ -108,7 +107,7 @@ def test_step_matches_reference_and_oracle(variant, tmp_path, dev):
         N.Dropout2dRec.inject = iter(masks) if masks else None
         twin.inject = iter(oracle.draws) if oracle.draws else None
         try:
-            twin.set_input(A.double(), B.double(), label)
+            oracle_set_input(twin, variant, it, torch.float64)
             twin.optimize_parameters()
         finally:
             N.Dropout2dRec.inject = None
@@ -116,11 +115,14 @@ def test_step_matches_reference_and_oracle(variant, tmp_path, dev):
         hnn.Dropout2d.mask_source = iter(masks) if masks else None
         hutil.inject_noise(iter(oracle.draws) if oracle.draws else None)
         try:
-            model.set_input({'A': A, 'B': B, 'label': torch.tensor(label), 'A_paths': ['a'] * 4, 'B_paths': ['b'] * 4})
+            np.random.seed(NP_SEED + it)          # --no_mixed_label_D draws the batch's label from numpy's global generator
+            model.set_input(step_batch(variant, it))
             model.optimize_parameters()
         finally:
             hnn.Dropout2d.mask_source = None
             hutil.inject_noise(None)
+        if ('it%d/label_AB' % it) in gold.files:
+            assert [int(v) for v in model.label_AB] == [int(v) for v in gold['it%d/label_AB' % it]] == [int(v) for v in oracle.label_AB]
         p = 'it%d' % it
         got = model.get_current_losses()
         ol = oracle.losses()
@@ -150,6 +152,11 @@ def test_step_matches_reference_and_oracle(variant, tmp_path, dev):
                 if og is None:
                     continue
                 hg = grabbed[tag][k]
+                if tag == 'D' and variant == 'norm_D_instance' and k in ('model.2.bias', 'model.5.bias', 'model.8.bias'):
+                    # InstanceNorm discriminator: these biases sit in front of an affine-less InstanceNorm (true gradient 0)
+                    wmax = float(ograds[k[:-4] + 'weight'].abs().max())
+                    assert float(hg.abs().max()) <= 1e-3 * wmax + 1e-6, '%s grad%s %s should be ~0' % (variant, tag, k)
+                    continue
                 if tag == 'G' and k.endswith('.bias') and k != 'model.26.bias':
                     # bias in front of an affine-less InstanceNorm: true gradient 0, fp32 noise only;
                     # bound the noise relative to the weight gradient of the same layer
@@ -254,3 +261,39 @@ def test_step_is_deterministic_with_streams(tmp_path, dev):
                     | {'fake_B': model.fake_B.detach().clone()})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), 'run-to-run difference in ' + k
+
+
+def test_get_current_visuals_matches_reference(tmp_path, dev):
+    """a16 (reference models/wsgan_emb_model.py:486-497): after a training step get_current_visuals() runs G on
+    real_A[0:1] once per fixed rating bin IN TRAIN MODE -- the attr_<i> images and the InstanceNorm running statistics
+    it moves are held to the vectors captured from the reference (tests/golden/visuals.npz); G's parameters require
+    gradients again afterwards and the call leaves no gradient behind."""
+    gold = np.load(os.path.join(GOLD, 'visuals.npz'))
+    model, opt = build_hip_model('default', tmp_path, ['--display_visuals'])
+    torch.manual_seed(1234)
+    model.set_input(step_batch('default', 0))
+    model.optimize_parameters()
+    sd = model.netG.state_dict()
+    for k in sd:
+        if 'running' in k:
+            assert_close(sd[k], torch.from_numpy(gold['before/' + k]), 2e-4, 'before the visuals: ' + k, atol=1e-6)
+    gflat_before = model.optimizer_G.gflat.detach().clone()
+    vis = model.get_current_visuals()
+    assert list(vis.keys()) == [str(n) for n in gold['names']]
+    for k, v in vis.items():
+        assert_close(v, torch.from_numpy(gold['vis/' + k]), 2e-4, 'visual ' + k)
+    moved = 0
+    sd = model.netG.state_dict()
+    for k in sd:
+        if 'running' in k:
+            assert_close(sd[k], torch.from_numpy(gold['after/' + k]), 2e-4, 'after the visuals: ' + k, atol=1e-6)
+            moved += int(not np.allclose(gold['after/' + k], gold['before/' + k]))
+        elif k.endswith('num_batches_tracked'):
+            assert int(sd[k]) == 0          # InstanceNorm never counts batches (SURVEY appendix B)
+    assert moved > 0
+    assert all(p.requires_grad for p in model.netG.parameters())
+    assert torch.equal(model.optimizer_G.gflat, gflat_before), 'the visuals pass must not touch the gradient buffer'
+    # the next training step still works and the statistics keep moving from where the visuals left them
+    model.set_input(step_batch('default', 1))
+    model.optimize_parameters()
+    assert all(v == v for v in model.get_current_losses().values())

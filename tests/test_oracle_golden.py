@@ -103,7 +103,7 @@ def build_oracle_step(variant):
     drop = float(kv.get('bnn_dropout', 0.0))
     G = N.ResnetGeneratorRef(3, 3, 1, 8, 'instance', 9)
     G.load_state_dict(W.damp_generator_head(W.fill_state_dict(G.state_dict(), 19)))
-    D = N.NLayerDiscriminatorRef(3, 1, 8, 3, 'batch', True)
+    D = N.NLayerDiscriminatorRef(3, 1, 8, 3, kv.get('norm_D', 'batch'), True)
     D.load_state_dict(W.fill_state_dict(D.state_dict(), 20))
     E = N.SiameseFeatureRef(N.ResNetFeatureRef('resnet18', drop), 'avg', (32, 1), 1, 0.7, noisy, drop)
     E.load_state_dict(W.fill_state_dict(E.state_dict(), 30))
@@ -124,19 +124,31 @@ def step_inputs(it):
     return A, B, label
 
 
+def oracle_set_input(m, variant, it, dtype=torch.float32):
+    """feed iteration `it` of a step variant to an oracle step object the way make_golden fed the reference"""
+    from oracle.make_golden import step_batch, NP_SEED
+    b = step_batch(variant, it)
+    if variant == 'no_mixed_label_D':
+        np.random.seed(NP_SEED + it)     # the label is drawn from numpy's global generator
+        m.set_input_no_mixed({k: (v.to(dtype) if isinstance(v, torch.Tensor) else v) for k, v in b.items()})
+    else:
+        m.set_input(b['A'].to(dtype), b['B'].to(dtype), [int(v) for v in b['label']])
+
+
 @pytest.mark.parametrize('variant', ['default', 'noisy_a', 'bayesian_e', 'bayesian_noisy_ae', 'use_real_A',
-                                     'lambda_A_GAN', 'detach_fake_B', 'no_ip_no_z'])
+                                     'lambda_A_GAN', 'detach_fake_B', 'no_ip_no_z', 'no_mixed_label_D', 'norm_D_instance'])
 def test_step_matches_reference(variant):
     torch.set_num_threads(4)
     gold = _load('step_%s.npz' % variant)
     m = build_oracle_step(variant)
     names = list(gold['loss_names'])
     for it in range(2):
-        A, B, label = step_inputs(it)
         torch.manual_seed(1234 + it)     # same CPU random stream as the reference run
-        m.set_input(A, B, label)
+        oracle_set_input(m, variant, it)
         m.optimize_parameters()
         p = 'it%d' % it
+        if 'it0/label_AB' in gold.files:
+            assert [int(v) for v in m.label_AB] == [int(v) for v in gold[p + '/label_AB']], 'label of the batch'
         got = m.losses()
         for i, n in enumerate(names):
             ref = gold[p + '/losses'][i]
@@ -160,6 +172,30 @@ def test_step_matches_reference(variant):
                 ref = gold['%s/after%s/%s' % (p, tag, k)]
                 a = v.double()
                 assert abs(float(a.abs().sum()) - ref[1]) <= 1e-4 * (ref[1] + 1e-3), 'after-step %s %s' % (tag, k)
+
+
+def test_get_current_visuals_matches_reference():
+    """a16: G on real_A[0:1] per fixed rating bin in TRAIN mode -- images and the moved InstanceNorm running statistics"""
+    torch.set_num_threads(4)
+    gold = _load('visuals.npz')
+    m = build_oracle_step('default')
+    torch.manual_seed(1234)
+    oracle_set_input(m, 'default', 0)
+    m.optimize_parameters()
+    for k, v in m.netG.state_dict().items():
+        if 'running' in k:
+            assert_close(v, torch.from_numpy(gold['before/' + k]), 1e-5, 'before ' + k, atol=1e-7)
+    vis = m.get_current_visuals([-1.0, 0.0, 1.5])
+    assert list(vis.keys()) == [str(n) for n in gold['names']]
+    for k, v in vis.items():
+        assert_close(v, torch.from_numpy(gold['vis/' + k]), 2e-5, 'visual ' + k)
+    moved = 0
+    for k, v in m.netG.state_dict().items():
+        if 'running' in k:
+            assert_close(v, torch.from_numpy(gold['after/' + k]), 1e-5, 'after ' + k, atol=1e-7)
+            moved += int(not np.allclose(gold['after/' + k], gold['before/' + k]))
+    assert moved > 0, 'the visuals pass must move the running statistics (train mode)'
+    assert all(p.requires_grad for p in m.netG.parameters()) and bool(gold['requires_grad_after'].all())
 
 
 def test_integer_helpers_bit_exact():

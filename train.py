@@ -41,7 +41,7 @@ def train_epoch(epoch, batches, model, opt, log, counters, world, rank):
     for batch in batches:
         t_iter = time.time()
         t_data = t_iter - t_after_prev                    # time spent waiting for the loader
-        model.set_input(parallel.shard_dict(batch, world, rank))
+        model.set_input(batch)                            # (already this rank's slice of the global batch: data/__init__.py)
         model.optimize_parameters()
         counters['total'] += 1
         in_epoch += 1
