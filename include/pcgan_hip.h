@@ -162,8 +162,15 @@ int pcgan_bn_bwd_fused(const float* dy, const float* x, const float* y, const fl
 int pcgan_instnorm_fwd(const float* x, const float* residual, float* y, float* mean_nc, float* m2_nc, int N, int C,
                        int HW, float eps, int act, float slope, pcgan_stream_t s);
 int pcgan_instnorm_bwd(const float* dy, const float* x, const float* y, const float* mean_nc, const float* m2_nc,
-                       float* dx, float* ws_s1s2, int N, int C, int HW, float eps, int act, float slope,
+                       float* dx, float* dx_psum, float* ws_s1s2, int N, int C, int HW, float eps, int act, float slope,
                        pcgan_stream_t s);
+/* 1 when a plane of HW elements runs in the register-resident kernels.  Only then may pcgan_instnorm_bwd be given
+ * dx_psum[N*C]: the sum of dx over each plane, taken from the registers that store dx.  The convolution in front of the
+ * norm has its bias gradient = sum over n of these (reference: autograd of nn.Conv2d(bias=True) + nn.InstanceNorm2d,
+ * models/networks.py:580-601, 621-648; true value 0, fp32 noise) -- pcgan_sum_planes finishes it without re-reading dx. */
+int pcgan_instnorm_fused(int HW);
+/* out[c] (+)= sum over n of part_nc[n*C + c]: second stage of pcgan_channel_sum on plane sums that already exist. */
+int pcgan_sum_planes(const float* part_nc, float* out, int N, int C, int accumulate, pcgan_stream_t s);
 
 /* ---- pooling / resize ------------------------------------------------------------
  * MaxPool2d(k, stride, pad)   models/resnet.py:138 ; models/networks.py:1225-1235

@@ -86,7 +86,15 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
     __shared__ float scratch[16];
     const float* xp = x + (size_t)blockIdx.x * HW;
     float s = 0.f;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += xp[i];
+    if ((HW & 3) == 0) {       // 128-bit loads (planes are 16-byte aligned then)
+        const float4* x4 = reinterpret_cast<const float4*>(xp);
+        for (int i = threadIdx.x; i < (HW >> 2); i += blockDim.x) {
+            const float4 v = x4[i];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += xp[i];
+    }
     s = block_sum(s, scratch);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
@@ -164,6 +172,13 @@ extern "C" int pcgan_channel_sum(const float* x, float* out, float* scratch_nc, 
                        HW);
     PCGAN_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_over_n_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)s, scratch_nc, out, N, C, accumulate);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_sum_planes(const float* part_nc, float* out, int N, int C, int accumulate, pcgan_stream_t s) {
+    PCGAN_CHECK(part_nc && out && N > 0 && C > 0, "sum_planes: bad arguments");
+    hipLaunchKernelGGL(sum_over_n_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)s, part_nc, out, N, C, accumulate);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

@@ -60,7 +60,9 @@ SIGNATURES = {
     'pcgan_bn_fwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _vp]),
     'pcgan_bn_bwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
     'pcgan_instnorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
-    'pcgan_instnorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
+    'pcgan_instnorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
+    'pcgan_instnorm_fused': (_i, [_i]),
+    'pcgan_sum_planes': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'pcgan_maxpool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'pcgan_maxpool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'pcgan_global_pool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

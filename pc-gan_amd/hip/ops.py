@@ -295,6 +295,14 @@ def channel_sum(x, accumulate_into=None):
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     out = accumulate_into if accumulate_into is not None else torch.empty(C, dtype=torch.float32, device=x.device)
+    psum = getattr(x, '_pcgan_plane_sums', None)
+    if psum is not None and psum.numel() == N * C and psum.device == x.device:
+        # x is the dx an instance-norm backward just produced: its plane sums exist already (instnorm_bwd)
+        PLANE_SUM_STATS['fused'] += 1
+        psum.record_stream(torch.cuda.current_stream())     # (may be the parameter-gradient side stream)
+        _L.check(_L.load().pcgan_sum_planes(_p(psum), _p(out), N, C, int(accumulate_into is not None), _stream()), 'sum_planes')
+        return out
+    PLANE_SUM_STATS['full'] += 1
     scratch = torch.empty(N * C, dtype=torch.float32, device=x.device)
     _L.check(_L.load().pcgan_channel_sum(_p(x), _p(out), _p(scratch), N, C, HW, int(accumulate_into is not None),
                                          _stream()), 'channel_sum')
@@ -462,14 +470,24 @@ def instnorm_fwd(x, residual, eps, act, slope):
     return y, mean, m2
 
 
+PLANE_SUM_STATS = {'fused': 0, 'full': 0}     # bias gradients finished from plane sums / by a full channel_sum pass
+
+
 def instnorm_bwd(dy, x, y, mean, m2, eps, act, slope):
+    """dx; where the plane runs in the register-resident kernel dx also carries `_pcgan_plane_sums` ([N*C] sums of dx over
+    each plane, free there): the convolution in front of the norm finishes its bias gradient from them (channel_sum)."""
     _chk(dy, x, y, mean, m2)
+    lib = _L.load()
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     dx = torch.empty_like(x)
-    ws = torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
-    _L.check(_L.load().pcgan_instnorm_bwd(_p(dy), _p(x), _p(y), _p(mean), _p(m2), _p(dx), _p(ws), N, C, HW, float(eps),
-                                          act, float(slope), _stream()), 'instnorm_bwd')
+    fused = bool(lib.pcgan_instnorm_fused(HW))
+    psum = torch.empty(N * C, dtype=torch.float32, device=x.device) if fused else None
+    ws = None if fused else torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
+    _L.check(lib.pcgan_instnorm_bwd(_p(dy), _p(x), _p(y), _p(mean), _p(m2), _p(dx), _p(psum), _p(ws), N, C, HW, float(eps),
+                                    act, float(slope), _stream()), 'instnorm_bwd')
+    if psum is not None:
+        dx._pcgan_plane_sums = psum
     return dx
 
 

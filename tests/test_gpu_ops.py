@@ -243,6 +243,24 @@ def test_instance_norm_fused(shape, act, res, dev):
     assert_close(m2, m2_ref, 1e-5, 'fused M2')
     dx = ops.instnorm_bwd(dy.to(dev), xd, y, mean, m2, 1e-5, act, 0.0)
     assert_close(dx, x64.grad, 5e-5, 'fused instnorm bwd')
+    # the register-resident backward also hands out the per-plane sums of dx; channel_sum (the bias gradient of the
+    # convolution in front of the norm) finishes from them instead of re-reading dx -- same value as the full pass
+    HW = shape[2] * shape[3]
+    psum = getattr(dx, '_pcgan_plane_sums', None)
+    assert (psum is not None) == (HW % 4 == 0)
+    full = dx.double().sum(dim=(2, 3)).reshape(-1)
+    scale = float(dx.double().abs().sum(dim=(2, 3)).max())
+    if psum is not None:
+        assert float((psum.double() - full).abs().max()) <= 1e-6 * scale + 1e-7, 'plane sums of dx'
+        before = dict(ops.PLANE_SUM_STATS)
+        acc = torch.ones(shape[1], device=dev)
+        ops.channel_sum(dx, accumulate_into=acc)
+        assert ops.PLANE_SUM_STATS['fused'] == before['fused'] + 1 and ops.PLANE_SUM_STATS['full'] == before['full']
+        want = 1.0 + dx.double().sum(dim=(0, 2, 3))
+        assert float((acc.double() - want).abs().max()) <= 1e-6 * scale * shape[0] + 1e-6
+        plain = ops.channel_sum(dx.clone())
+        assert ops.PLANE_SUM_STATS['full'] == before['full'] + 1
+        assert float((plain.double() - dx.double().sum(dim=(0, 2, 3))).abs().max()) <= 1e-6 * scale * shape[0] + 1e-6
 
 
 @pytest.mark.parametrize('shape', [(4, 8, 16, 16), (3, 5, 7, 7), (2, 16, 64, 64), (40, 3, 4, 4), (70, 5, 2, 2)])

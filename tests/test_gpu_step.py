@@ -249,7 +249,9 @@ def test_checkpoint_roundtrip_and_lr_schedule(tmp_path, dev):
 def test_step_is_deterministic_with_streams(tmp_path, dev):
     """Side stream (parameter gradients) and branch streams (D / IP / E in backward_G) must not change results: two
     models built the same way and stepped three times end bit-identical."""
+    from pcgan_amd.hip import ops
     outs = []
+    fused0 = ops.PLANE_SUM_STATS['fused']
     for run in range(2):
         model, opt = build_hip_model('default', tmp_path)
         for it in range(3):
@@ -261,6 +263,9 @@ def test_step_is_deterministic_with_streams(tmp_path, dev):
                     | {'fake_B': model.fake_B.detach().clone()})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), 'run-to-run difference in ' + k
+    # the generator's conv -> InstanceNorm pairs take their bias gradients from the plane sums the norm backward leaves on
+    # its dx (no separate pass over dx): 23 norm sites x 2 generator passes x 3 steps x 2 runs
+    assert ops.PLANE_SUM_STATS['fused'] - fused0 >= 2 * 3 * 2 * 20, ops.PLANE_SUM_STATS
 
 
 def test_get_current_visuals_matches_reference(tmp_path, dev):
