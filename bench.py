@@ -12,8 +12,8 @@ Workload (BASELINE.json configs[1]): 9-block ResnetGenerator + 3-layer PatchGAN 
 "pretrained" E/IP weights (no checkpoints ship offline).
 
 One JSON line on rank 0: value = whole-job images/s; `roofline` = the dominant kernel (the 256->256
-3x3 residual convolution, implicit GEMM on fp32 MFMA): every one of its forward launches inside the timed region
-is bracketed by HIP events on the launch stream;
+3x3 residual convolution: fp32 contraction as an exact 3-piece bf16 split on the bf16 matrix pipe): every one of its
+forward launches inside the timed region is bracketed by HIP events on the launch stream;
 `cpu_baseline` = the oracle's PyTorch-CPU step on this host's cores, bounded sample.
 """
 import argparse
@@ -30,9 +30,23 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMG_FULL = 183.95      # 2 G + 4 D + 3 E + 2 IP fwd and all backward terms @128^2
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+BF16_SPLIT_PRODUCTS = 6          # bf16 piece products that stand for one fp32 product (csrc/bf16x6_conv.hip)
 PER_GPU_BATCH = 32
 SIZE = 128
-HBM_TRAFFIC_PER_LAUNCH = (53572 + 32768) * 1024   # FETCH_SIZE + WRITE_SIZE (KiB) of the forward kernel, profiles/README.md
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_dominant_kernel_traffic.json')   # written from the --pmc passes of this round
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from this round's separate rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE cannot share a pass), committed under profiles/; None when the file is absent."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        return {'bytes_per_launch': int(t['fetch_bytes'] + t['write_bytes']), 'fetch_bytes': int(t['fetch_bytes']),
+                'write_bytes': int(t['write_bytes']), 'algorithmic_bytes': int(t['algorithmic_bytes']), 'source': t['source']}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def build_model(device_index, batch, size, tmpdir, seed=0, ngf=64, ndf=64, fine_e=224, n_blocks=9):
@@ -75,7 +89,7 @@ RES_CONV_KEY = (PER_GPU_BATCH, 256, 32, 32, 256, 3, 3, 1, 1, 1)   # the residual
 RES_CONV_FLOP = 2.0 * PER_GPU_BATCH * 32 * 32 * 256 * 256 * 9
 
 
-def cpu_baseline(steps=2, batch=8):
+def cpu_baseline(steps=5, batch=8):
     """The oracle's CPU step (reference-equivalent PyTorch-CPU path) on a bounded sample."""
     from oracle import networks_ref as N
     from oracle import step_ref as S
@@ -90,13 +104,18 @@ def cpu_baseline(steps=2, batch=8):
     m = S.WSGANEmbStepRef(G, D, E, IP)
     b = synthetic_batch(batch, SIZE, 0)
     m.set_input(b['A'], b['B'], [int(v) for v in b['label']])
-    m.optimize_parameters()                    # warm-up (oneDNN primitive creation)
-    t0 = time.time()
-    for _ in range(steps):
+    for _ in range(2):                         # warm-up (oneDNN primitive creation, allocator)
         m.optimize_parameters()
-    dt = (time.time() - t0) / steps
-    return {'value': batch / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': '%d timed steps (1 warm-up) of the oracle CPU step, batch %d, 128x128, same nets/flags' % (
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        m.optimize_parameters()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': round(batch / med, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'best': round(batch / times[0], 3), 'worst': round(batch / times[-1], 3),
+            'sample': '%d timed steps (2 warm-up) of the oracle CPU step, batch %d, 128x128, same nets/flags; value = median step' % (
                 steps, batch)}
 
 
@@ -106,7 +125,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-experiment', action='store_true', help='skip the extra (not headline) run with the bf16-split kernels on')
+    ap.add_argument('--no-experiment', action='store_true',
+                    help='skip the extra (not headline) run with the residual convolutions routed back to the fp32 MFMA kernels')
     args = ap.parse_args()
 
     from pcgan_amd.hip import parallel
@@ -159,6 +179,17 @@ def main():
     value = PER_GPU_BATCH * world * args.steps / dt
     assert conv_launches > 0, 'the residual convolution was not launched inside the timed region'
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+    split = ops.BF16X6
+    if split:
+        # the dominant kernel runs the fp32 contraction as 6 bf16 piece products per term on the bf16 matrix pipe: its MFMA
+        # roofline in ALGORITHMIC (fp32) FLOP is the dense bf16 peak / 6
+        peak = BF16_MFMA_PEAK_TFLOPS / BF16_SPLIT_PRODUCTS
+        kname = ('bsplit_conv_fwd_kernel<BS_FWD_REFLECT,256> (exact 3-piece bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per K=16 step, '
+                 '256 x 128 tile) 256->256 3x3 reflect @32x32, bs32')
+    else:
+        peak = FP32_MFMA_PEAK_TFLOPS
+        kname = 'igemm2_kernel<1,128,128,16> (FWD_REFLECT, 128x128 tile, 16-channel K stages) 256->256 3x3 reflect @32x32, bs32'
+    traffic = measured_traffic() if split else None
     out = {
         'metric': 'images/sec (G+D step) 128x128 bs32 per GPU', 'value': round(value, 3), 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
@@ -167,19 +198,22 @@ def main():
                                'PatchGAN + ResNet-18 Elo encoder@224 + AlexNet IP@224, full optimize_parameters()',
                    'global_batch': PER_GPU_BATCH * world, 'parallelism': 'dp%d' % world},
         'step_flop_fraction': round(GFLOP_PER_IMG_FULL * 1e9 * value / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4),
-        'roofline': {'bound': 'mfma', 'kernel': 'igemm2_kernel<1,128,128,16> (FWD_REFLECT, 128x128 tile, 16-channel K stages) 256->256 3x3 reflect @32x32, bs32',
-                     'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'ms_per_launch': round(conv_ms, 4),
+        'roofline': {'bound': 'mfma', 'kernel': kname,
+                     'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                     'frac': round(achieved / peak, 4), 'ms_per_launch': round(conv_ms, 4),
                      'launches_timed': conv_launches, 'flop_per_launch': conv_flop,
-                     # memory-side bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md: why the
-                     # gfx950 x2 FETCH_SIZE correction cannot apply to these 4-byte gathers); algorithmic bytes 69.5e6
-                     'traffic': HBM_TRAFFIC_PER_LAUNCH},
+                     'peak_basis': ('dense bf16 MFMA %.0f TFLOP/s / %d piece products per fp32 product' % (BF16_MFMA_PEAK_TFLOPS, BF16_SPLIT_PRODUCTS))
+                     if split else 'fp32 MFMA v_mfma_f32_32x32x2_f32',
+                     'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                     # memory-side bytes per launch from this round's separate rocprofv3 --pmc passes (profiles/README.md);
+                     # null when no counter file of this round is committed
+                     'traffic': traffic['bytes_per_launch'] if traffic else None, 'traffic_detail': traffic},
         'losses': {k: round(v, 5) for k, v in losses.items()},
     }
-    if world == 1 and not args.no_experiment and not ops.BF16X6:
-        # NOT the headline: the same K steps once more with the opt-in bf16-split kernels (fp32 operands split
-        # exactly into three bf16 pieces, six piece products per term, fp32 accumulators) for the residual-block convolutions
-        ops.BF16X6 = True
+    if world == 1 and not args.no_experiment and ops.BF16X6:
+        # NOT the headline: the same K steps once more with the 108 residual-convolution launches routed back to the fp32 MFMA
+        # implicit GEMM (PCGAN_BF16X6=0), i.e. round 1's default path -- the A/B behind the default
+        ops.BF16X6 = False
         try:
             for i in range(args.warmup):
                 step(i)
@@ -190,15 +224,13 @@ def main():
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
             l2 = model.get_current_losses()
-            assert all(v == v and abs(v) < 1e6 for v in l2.values()), 'non-finite loss with the bf16-split kernels: %r' % l2
-            out['experiment_bf16x6'] = {
+            assert all(v == v and abs(v) < 1e6 for v in l2.values()), 'non-finite loss on the fp32 MFMA route: %r' % l2
+            out['route_fp32_mfma'] = {
                 'value': round(PER_GPU_BATCH * args.steps / dt2, 3), 'unit': 'images/sec', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
-                'default': False, 'switch': 'PCGAN_BF16X6=1',
-                'what': 'forward, data gradient and weight gradient of the 256->256 3x3 residual convolutions (108 launches per step) on '
-                        'v_mfma_f32_32x32x16_bf16: exact 3-piece bf16 split of every fp32 operand, 6 piece products, fp32 accumulate; '
-                        'rel. L2 error vs float64 9e-7 (fp32 MFMA kernel 6e-7); the whole GPU parity suite passes with it on'}
+                'default': False, 'switch': 'PCGAN_BF16X6=0',
+                'what': 'the residual convolutions on v_mfma_f32_32x32x2_f32 (round-1 default) instead of the exact bf16 split'}
         finally:
-            ops.BF16X6 = False
+            ops.BF16X6 = True
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

@@ -225,7 +225,7 @@ def golden_steps(rn, outdir, only=None):
 
 
 def golden_visuals(rn, outdir):
-    """get_current_visuals() of wsgan_emb (models/wsgan_emb_model.py:486-497): after one training step the model runs G on
+    """get_current_visuals() of wsgan_emb (models/wsgan_emb_model.py:486-497): after set_input + forward() the model runs G on
     real_A[0:1] once per fixed rating bin IN TRAIN MODE, which moves the InstanceNorm running statistics; recorded: the
     attr_<i> images and G's buffers before / after the call."""
     from options.train_options import TrainOptions
@@ -248,9 +248,12 @@ def golden_visuals(rn, outdir):
     model.setup(opt)
     model.netG.load_state_dict(W.damp_generator_head(W.fill_state_dict(model.netG.state_dict(), 19)))
     model.netD.load_state_dict(W.fill_state_dict(model.netD.state_dict(), 20))
+    # forward() only, no optimizer step in front: Adam moves the parameters whose true gradient is 0 (biases, the rating
+    # channel's filter slice) by +-lr according to the SIGN of fp32 noise, and exactly those parameters shift the plane
+    # means that the running statistics record -- after a step two correct implementations differ there by construction
     torch.manual_seed(1234)
     model.set_input(step_batch('default', 0))
-    model.optimize_parameters()
+    model.forward()
     out = {}
     for k, v in model.netG.state_dict().items():
         if 'running' in k:

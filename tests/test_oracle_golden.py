@@ -181,7 +181,7 @@ def test_get_current_visuals_matches_reference():
     m = build_oracle_step('default')
     torch.manual_seed(1234)
     oracle_set_input(m, 'default', 0)
-    m.optimize_parameters()
+    m.forward()          # (no optimizer step in front: see make_golden.golden_visuals)
     for k, v in m.netG.state_dict().items():
         if 'running' in k:
             assert_close(v, torch.from_numpy(gold['before/' + k]), 1e-5, 'before ' + k, atol=1e-7)
