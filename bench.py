@@ -49,7 +49,7 @@ def measured_traffic():
         return None
 
 
-def build_model(device_index, batch, size, tmpdir, seed=0, ngf=64, ndf=64, fine_e=224, n_blocks=9):
+def build_model(device_index, batch, size, tmpdir, seed=0, ngf=64, ndf=64, fine_e=224, n_blocks=9, dtype='fp32'):
     from pcgan_amd.options.train_options import TrainOptions
     from pcgan_amd.models import create_model, networks
     torch.manual_seed(seed)
@@ -64,7 +64,8 @@ def build_model(device_index, batch, size, tmpdir, seed=0, ngf=64, ndf=64, fine_
             '--which_model_netG', 'resnet_%dblocks' % n_blocks, '--which_model_netD', 'n_layers', '--n_layers_D', '3',
             '--ngf', str(ngf), '--ndf', str(ndf), '--fineSize', str(size), '--loadSize', str(size),
             '--fineSize_E', str(fine_e), '--fineSize_IP', str(fine_e), '--batchSize', str(batch),
-            '--pretrained_model_path_E', e_path, '--pretrained_model_path_IP', ip_path, '--display_id', '-1']
+            '--pretrained_model_path_E', e_path, '--pretrained_model_path_IP', ip_path, '--display_id', '-1',
+            '--dtype', dtype]
     old, sys.argv = sys.argv, argv
     stdout, sys.stdout = sys.stdout, open(os.devnull, 'w')
     try:
@@ -125,6 +126,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help='activation storage type; the headline (BASELINE configs[1]) is fp32, bf16 is BASELINE configs[2] per GPU')
     ap.add_argument('--no-experiment', action='store_true',
                     help='skip the extra (not headline) run with the residual convolutions routed back to the fp32 MFMA kernels')
     args = ap.parse_args()
@@ -138,7 +141,7 @@ def main():
     device = torch.device('cuda', dev_index)
 
     tmpdir = tempfile.mkdtemp(prefix='pcgan_bench_')
-    model, opt = build_model(dev_index, PER_GPU_BATCH, SIZE, tmpdir)
+    model, opt = build_model(dev_index, PER_GPU_BATCH, SIZE, tmpdir, dtype=args.dtype)
     batches = [synthetic_batch(PER_GPU_BATCH, SIZE, rank, it) for it in range(2)]
     # inputs resident in HBM before the timed region (set_input's .to(device) is then a no-op copy)
     batches = [{k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in b.items()} for b in batches]
@@ -180,7 +183,12 @@ def main():
     assert conv_launches > 0, 'the residual convolution was not launched inside the timed region'
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12
     split = ops.BF16X6
-    if split:
+    bf16 = args.dtype == 'bf16'
+    if bf16:
+        # bf16 storage, one bf16 product per term: 16x the fp32 MFMA rate makes the kernel HBM / gather bound -> HBM roofline
+        kname = ('bsplit_conv_fwd_kernel<BS_FWD_REFLECT,256,1,bf16> (bf16 activations and weights, v_mfma_f32_32x32x16_bf16, fp32 accumulate) '
+                 '256->256 3x3 reflect @32x32, bs32')
+    elif split:
         # the dominant kernel runs the fp32 contraction as 6 bf16 piece products per term on the bf16 matrix pipe: its MFMA
         # roofline in ALGORITHMIC (fp32) FLOP is the dense bf16 peak / 6
         peak = BF16_MFMA_PEAK_TFLOPS / BF16_SPLIT_PRODUCTS
@@ -189,16 +197,23 @@ def main():
     else:
         peak = FP32_MFMA_PEAK_TFLOPS
         kname = 'igemm2_kernel<1,128,128,16> (FWD_REFLECT, 128x128 tile, 16-channel K stages) 256->256 3x3 reflect @32x32, bs32'
-    traffic = measured_traffic() if split else None
+    traffic = measured_traffic() if (split and not bf16) else None
+    if bf16:
+        alg_bytes = 2 * PER_GPU_BATCH * 256 * 32 * 32 * 2 + 256 * 256 * 9 * 2     # x + y as bf16, bf16 weights
+        roof = {'bound': 'hbm', 'kernel': kname, 'achieved': round(alg_bytes / (conv_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                'frac': round(alg_bytes / (conv_ms * 1e-3) / 1e9 / 8000.0, 4), 'ms_per_launch': round(conv_ms, 4),
+                'launches_timed': conv_launches, 'algorithmic_bytes_per_launch': alg_bytes, 'flop_per_launch': conv_flop,
+                'mfma_tflops': round(achieved, 1), 'traffic': None}
     out = {
         'metric': 'images/sec (G+D step) 128x128 bs32 per GPU', 'value': round(value, 3), 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'wsgan_emb UTKFace-shaped 128x128 bs32/GPU fp32: 9-block ResnetGenerator + 3-layer '
-                               'PatchGAN + ResNet-18 Elo encoder@224 + AlexNet IP@224, full optimize_parameters()',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
+        'config': {'workload': 'wsgan_emb UTKFace-shaped 128x128 bs32/GPU %s: 9-block ResnetGenerator + 3-layer '
+                               'PatchGAN + ResNet-18 Elo encoder@224 + AlexNet IP@224, full optimize_parameters()' % (
+                                   'bf16 activations (fp32 master weights, accumulation, statistics, losses, Adam)' if bf16 else 'fp32'),
                    'global_batch': PER_GPU_BATCH * world, 'parallelism': 'dp%d' % world},
         'step_flop_fraction': round(GFLOP_PER_IMG_FULL * 1e9 * value / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4),
-        'roofline': {'bound': 'mfma', 'kernel': kname,
+        'roofline': roof if bf16 else {'bound': 'mfma', 'kernel': kname,
                      'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                      'frac': round(achieved / peak, 4), 'ms_per_launch': round(conv_ms, 4),
                      'launches_timed': conv_launches, 'flop_per_launch': conv_flop,
@@ -210,7 +225,7 @@ def main():
                      'traffic': traffic['bytes_per_launch'] if traffic else None, 'traffic_detail': traffic},
         'losses': {k: round(v, 5) for k, v in losses.items()},
     }
-    if world == 1 and not args.no_experiment and ops.BF16X6:
+    if world == 1 and not args.no_experiment and ops.BF16X6 and not bf16:
         # NOT the headline: the same K steps once more with the 108 residual-convolution launches routed back to the fp32 MFMA
         # implicit GEMM (PCGAN_BF16X6=0), i.e. round 1's default path -- the A/B behind the default
         ops.BF16X6 = False

@@ -10,7 +10,10 @@
  * define_E/define_IP modules.
  *
  * Conventions
- *   - all tensors are fp32, NCHW, contiguous, device pointers (tensor.data_ptr()).
+ *   - tensors are NCHW, contiguous, device pointers (tensor.data_ptr()).  ACTIVATION tensors (and their gradients) are
+ *     `void*` of the storage type named by the call's `dtype` argument / the descriptor's `dtype` field (PCGAN_F32 or
+ *     PCGAN_BF16); everything typed `float*` -- parameters, parameter gradients, biases, statistics, losses, optimizer
+ *     state -- is fp32 in either mode, and all arithmetic accumulates in fp32.
  *   - no hidden allocation, no device synchronisation, no global mutable state:
  *     the caller provides the workspace (query *_workspace_bytes first) and the
  *     hipStream_t (torch.cuda.current_stream().cuda_stream); every launch is
@@ -53,20 +56,24 @@ typedef struct {
     int K, R, S;    /* weight [K][C][R][S]            */
     int stride, pad, pad_mode;
     int P, Q;       /* output [N][K][P][Q]            */
+    int dtype;      /* storage type of x / y / dy / dx: PCGAN_F32 or PCGAN_BF16 (w, bias, dw are fp32)   */
 } pcgan_conv_desc;
 
 enum { PCGAN_ACT_NONE = 0, PCGAN_ACT_RELU = 1, PCGAN_ACT_LRELU = 2, PCGAN_ACT_TANH = 3, PCGAN_ACT_SIGMOID = 4 };
 enum { PCGAN_PASS_FWD = 0, PCGAN_PASS_BWD_DATA = 1, PCGAN_PASS_BWD_WEIGHT = 2 };
+/* storage type of ACTIVATION tensors (and of their gradients); parameters, parameter gradients, statistics, losses and
+ * optimizer state are always fp32, accumulation is always fp32 */
+enum { PCGAN_F32 = 0, PCGAN_BF16 = 1 };
 
 size_t pcgan_conv2d_workspace_bytes(const pcgan_conv_desc* d, int pass);
 
 /* y = act(conv(x, w) + bias); bias may be NULL. */
-int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const float* w, const float* bias,
-                     float* y, int act, float slope, void* ws, size_t ws_bytes, pcgan_stream_t s);
+int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const void* x, const float* w, const float* bias,
+                     void* y, int act, float slope, void* ws, size_t ws_bytes, pcgan_stream_t s);
 /* dx = conv^T(dy, w) (+ bias per dx-channel, used when this entry serves as the
  * forward of nn.ConvTranspose2d, models/networks.py:597-600). */
-int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, const float* w, const float* bias,
-                          float* dx, void* ws, size_t ws_bytes, pcgan_stream_t s);
+int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const void* dy, const float* w, const float* bias,
+                          void* dx, void* ws, size_t ws_bytes, pcgan_stream_t s);
 /* Weight packing split out of the two calls above.  fwd/bwd_data re-tile w into the implicit-GEMM A
  * operand on every call (a few us, ~2 % of a step); weights only change once per optimizer step while the
  * reference's step runs each net 2-4 times (models/wsgan_emb_model.py:277-330), so the host can pack once
@@ -75,33 +82,36 @@ int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, const float
 size_t pcgan_conv2d_packed_bytes(const pcgan_conv_desc* d, int pass);
 int pcgan_conv2d_pack_weights(const pcgan_conv_desc* d, int pass, const float* w, float* packed,
                               pcgan_stream_t s);
-int pcgan_conv2d_fwd_packed(const pcgan_conv_desc* d, const float* x, const float* packed, const float* bias,
-                            float* y, int act, float slope, void* ws, size_t ws_bytes, pcgan_stream_t s);
-int pcgan_conv2d_bwd_data_packed(const pcgan_conv_desc* d, const float* dy, const float* packed,
-                                 const float* bias, float* dx, void* ws, size_t ws_bytes, pcgan_stream_t s);
+int pcgan_conv2d_fwd_packed(const pcgan_conv_desc* d, const void* x, const float* packed, const float* bias,
+                            void* y, int act, float slope, void* ws, size_t ws_bytes, pcgan_stream_t s);
+int pcgan_conv2d_bwd_data_packed(const pcgan_conv_desc* d, const void* dy, const float* packed,
+                                 const float* bias, void* dx, void* ws, size_t ws_bytes, pcgan_stream_t s);
 /* dw[K][C][R][S] (+)= sum_{n,p,q} dy * gather(x).  accumulate != 0 adds into dw -- used with dw = the
  * parameter's slice of the optimizer's flat gradient buffer, which fuses autograd's "grad += dw" pass. */
-int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                             void* ws, size_t ws_bytes, pcgan_stream_t s);
 
 /* ---- per-channel reductions / pointwise ---------------------------------------- */
 /* out[c] (+)= sum over n,h,w of x[n][c][h][w]  (bias gradients); scratch_nc: N*C floats. */
-int pcgan_channel_sum(const float* x, float* out, float* scratch_nc, int N, int C, int HW, int accumulate,
+int pcgan_channel_sum(const void* x, float* out, float* scratch_nc, int N, int C, int HW, int accumulate, int dtype,
                       pcgan_stream_t s);
 /* dx = dy * act'(y)  where y is the activation OUTPUT (relu/lrelu/tanh/sigmoid). */
-int pcgan_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float slope, pcgan_stream_t s);
+int pcgan_act_bwd(const void* dy, const void* y, void* dx, size_t n, int act, float slope, int dtype, pcgan_stream_t s);
 /* y = act(x) standalone (nn.ReLU in AlexNetFeature, models/networks.py:1224-1234). */
-int pcgan_act_fwd(const float* x, float* y, size_t n, int act, float slope, pcgan_stream_t s);
+int pcgan_act_fwd(const void* x, void* y, size_t n, int act, float slope, int dtype, pcgan_stream_t s);
 /* out[n][0..C)[hw] = img, out[n][C..C+nz)[hw] = z[n or 0][j] broadcast
  * (torch.cat((input, z_img), 1), models/networks.py:610-611, 781-782).  z_batch is 1 or N. */
-int pcgan_concat_z(const float* img, const float* z, float* out, int N, int C, int nz, int HW, int z_batch,
+int pcgan_concat_z(const void* img, const float* z, void* out, int N, int C, int nz, int HW, int z_batch, int dtype,
                    pcgan_stream_t s);
 /* y = a + b; y = alpha * scalar_dev[0] * x (scalar_dev may be NULL): the upstream
  * gradient of a scalar loss stays on the device -- helpers for the autograd glue. */
-int pcgan_add(const float* a, const float* b, float* y, size_t n, pcgan_stream_t s);
-int pcgan_scale(const float* x, const float* scalar_dev, float alpha, float* y, size_t n, pcgan_stream_t s);
+int pcgan_add(const void* a, const void* b, void* y, size_t n, int dtype, pcgan_stream_t s);
+int pcgan_scale(const void* x, const float* scalar_dev, float alpha, void* y, size_t n, int dtype, pcgan_stream_t s);
+/* y = x converted between storage types (fp32 -> bf16: round to nearest even; the bf16 path's boundary: images in,
+ * parity checks out). */
+int pcgan_cast(const void* x, int dtype_x, void* y, int dtype_y, size_t n, pcgan_stream_t s);
 /* Dropout2d with an explicit keep mask per (n,c) (models/resnet.py:38-51): y = x*mask[nc]*scale. */
-int pcgan_channel_scale(const float* x, const float* mask_nc, float* y, int NC, int HW, float scale,
+int pcgan_channel_scale(const void* x, const float* mask_nc, void* y, int NC, int HW, float scale, int dtype,
                         pcgan_stream_t s);
 
 /* ---- normalisation (+ fused activation / residual) -----------------------------
@@ -109,7 +119,7 @@ int pcgan_channel_scale(const float* x, const float* mask_nc, float* y, int NC, 
  * BatchNorm2d(affine=True) in train mode                   models/networks.py:24,
  *                                                          models/resnet.py:47-51,136
  * plane_stats: per (n,c) plane mean and M2 = sum (x-mean)^2 (exact two-pass). */
-int pcgan_plane_stats(const float* x, float* mean_nc, float* m2_nc, int NC, int HW, pcgan_stream_t s);
+int pcgan_plane_stats(const void* x, float* mean_nc, float* m2_nc, int NC, int HW, int dtype, pcgan_stream_t s);
 /* merge the N per-plane (mean,M2) of each channel (Chan's formula) into batch
  * statistics: mean_c, var_c (biased) and update running stats
  * (momentum m: r = (1-m) r + m stat, unbiased variance), either pointer may be NULL. */
@@ -124,22 +134,22 @@ int pcgan_in_running_update(const float* mean_nc, const float* m2_nc, float* run
  * with i = n*C+c (per_plane=1, instance norm: `var` then holds the plane M2 from
  * pcgan_plane_stats and the kernel divides by HW) or i = c (per_plane=0, batch norm or
  * eval-mode running statistics: `var` is the variance).  gamma/beta/residual may be NULL. */
-int pcgan_norm_act_fwd(const float* x, const float* mean, const float* var, const float* gamma,
-                       const float* beta, const float* residual, float* y, int N, int C, int HW,
-                       int per_plane, float eps, int act, float slope, pcgan_stream_t s);
+int pcgan_norm_act_fwd(const void* x, const float* mean, const float* var, const float* gamma,
+                       const float* beta, const void* residual, void* y, int N, int C, int HW,
+                       int per_plane, float eps, int act, float slope, int dtype, pcgan_stream_t s);
 /* backward statistics per plane: s1[nc] = sum g, s2[nc] = sum g*xhat where
  * g = dy * act'(y) (y = forward output, used only for the activation mask; may be NULL
  * when act == NONE). */
-int pcgan_norm_bwd_stats(const float* dy, const float* x, const float* y, const float* mean,
+int pcgan_norm_bwd_stats(const void* dy, const void* x, const void* y, const float* mean,
                          const float* var, float* s1_nc, float* s2_nc, int N, int C, int HW,
-                         int per_plane, float eps, int act, float slope, pcgan_stream_t s);
+                         int per_plane, float eps, int act, float slope, int dtype, pcgan_stream_t s);
 /* dx = rstd*gamma*( g - s1/cnt - xhat*s2/cnt ); s1/s2 indexed like mean;
  * d_residual (optional) = g.  For batch norm the caller first sums s1/s2 over n
  * (pcgan_bn_bwd_reduce) which also yields dgamma, dbeta. */
-int pcgan_norm_bwd_apply(const float* dy, const float* x, const float* y, const float* mean,
+int pcgan_norm_bwd_apply(const void* dy, const void* x, const void* y, const float* mean,
                          const float* var, const float* gamma, const float* s1, const float* s2,
-                         float* dx, float* d_residual, int N, int C, int HW, int per_plane, float eps,
-                         int act, float slope, pcgan_stream_t s);
+                         void* dx, void* d_residual, int N, int C, int HW, int per_plane, float eps,
+                         int act, float slope, int dtype, pcgan_stream_t s);
 int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, float* s2_c, int N, int C,
                         pcgan_stream_t s);
 /* BatchNorm2d in training mode for small tensors (used up to N * HW = 8192 per channel), ONE launch per pass: batch statistics,
@@ -147,23 +157,23 @@ int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, flo
  * -- replaces nn.BatchNorm2d (+ the following ReLU / LeakyReLU) of the PatchGAN and of the Elo encoder's late stages
  * (models/networks.py:24-26, 756-771; models/resnet.py:58-71).  mean_c / var_c (biased) are kept for the backward pass;
  * backward returns s1_c = d(beta), s2_c = d(gamma) and dx (dx / dres may be NULL). */
-int pcgan_bn_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+int pcgan_bn_fwd_fused(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
                        float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches, int N,
-                       int C, int HW, float momentum, float eps, int act, float slope, pcgan_stream_t s);
-int pcgan_bn_bwd_fused(const float* dy, const float* x, const float* y, const float* mean_c, const float* var_c,
-                       const float* gamma, float* dx, float* dres, float* s1_c, float* s2_c, int N, int C, int HW, float eps,
-                       int act, float slope, pcgan_stream_t s);
+                       int C, int HW, float momentum, float eps, int act, float slope, int dtype, pcgan_stream_t s);
+int pcgan_bn_bwd_fused(const void* dy, const void* x, const void* y, const float* mean_c, const float* var_c,
+                       const float* gamma, void* dx, void* dres, float* s1_c, float* s2_c, int N, int C, int HW, float eps,
+                       int act, float slope, int dtype, pcgan_stream_t s);
 
 /* Fused instance norm (the generator's 23 norm sites per pass, models/networks.py:580-601,633,646): the
  * (n,c) plane stays in registers, so forward = one read + one write (statistics + normalise + residual +
  * activation; mean / M2 are also returned for the backward and the running-stat update) and backward = one
  * read of dy, x (and y for the activation mask) + one write.  Planes that do not fit (HW % 4 != 0 or
  * HW > 65536) fall back to the two-pass kernels above; ws_s1s2 (2*N*C floats) is only used then. */
-int pcgan_instnorm_fwd(const float* x, const float* residual, float* y, float* mean_nc, float* m2_nc, int N, int C,
-                       int HW, float eps, int act, float slope, pcgan_stream_t s);
-int pcgan_instnorm_bwd(const float* dy, const float* x, const float* y, const float* mean_nc, const float* m2_nc,
-                       float* dx, float* dx_psum, float* ws_s1s2, int N, int C, int HW, float eps, int act, float slope,
-                       pcgan_stream_t s);
+int pcgan_instnorm_fwd(const void* x, const void* residual, void* y, float* mean_nc, float* m2_nc, int N, int C,
+                       int HW, float eps, int act, float slope, int dtype, pcgan_stream_t s);
+int pcgan_instnorm_bwd(const void* dy, const void* x, const void* y, const float* mean_nc, const float* m2_nc,
+                       void* dx, float* dx_psum, float* ws_s1s2, int N, int C, int HW, float eps, int act, float slope,
+                       int dtype, pcgan_stream_t s);
 /* 1 when a plane of HW elements runs in the register-resident kernels.  Only then may pcgan_instnorm_bwd be given
  * dx_psum[N*C]: the sum of dx over each plane, taken from the registers that store dx.  The convolution in front of the
  * norm has its bias gradient = sum over n of these (reference: autograd of nn.Conv2d(bias=True) + nn.InstanceNorm2d,
@@ -176,28 +186,28 @@ int pcgan_sum_planes(const float* part_nc, float* out, int N, int C, int accumul
  * MaxPool2d(k, stride, pad)   models/resnet.py:138 ; models/networks.py:1225-1235
  * AvgPool2d(H) / MaxPool2d(H) global pooling  models/networks.py:1056-1059
  * F.interpolate(bilinear, align_corners=True)  util/util.py:111-117 */
-int pcgan_maxpool_fwd(const float* x, float* y, int32_t* argmax, int NC, int H, int W, int k, int stride,
-                      int pad, int P, int Q, pcgan_stream_t s);
-int pcgan_maxpool_bwd(const float* dy, const int32_t* argmax, float* dx, int NC, int H, int W, int k, int stride,
-                      int pad, int P, int Q, pcgan_stream_t s);
-int pcgan_global_pool_fwd(const float* x, float* y, int32_t* argmax, int NC, int HW, int is_max,
+int pcgan_maxpool_fwd(const void* x, void* y, int32_t* argmax, int NC, int H, int W, int k, int stride,
+                      int pad, int P, int Q, int dtype, pcgan_stream_t s);
+int pcgan_maxpool_bwd(const void* dy, const int32_t* argmax, void* dx, int NC, int H, int W, int k, int stride,
+                      int pad, int P, int Q, int dtype, pcgan_stream_t s);
+int pcgan_global_pool_fwd(const void* x, void* y, int32_t* argmax, int NC, int HW, int is_max, int dtype,
                           pcgan_stream_t s);
-int pcgan_global_pool_bwd(const float* dy, const int32_t* argmax, float* dx, int NC, int HW, int is_max,
+int pcgan_global_pool_bwd(const void* dy, const int32_t* argmax, void* dx, int NC, int HW, int is_max, int dtype,
                           pcgan_stream_t s);
-int pcgan_bilinear_fwd(const float* x, float* y, int NC, int H, int W, int P, int Q, pcgan_stream_t s);
-int pcgan_bilinear_bwd(const float* dy, float* dx, int NC, int H, int W, int P, int Q, pcgan_stream_t s);
+int pcgan_bilinear_fwd(const void* x, void* y, int NC, int H, int W, int P, int Q, int dtype, pcgan_stream_t s);
+int pcgan_bilinear_bwd(const void* dy, void* dx, int NC, int H, int W, int P, int Q, int dtype, pcgan_stream_t s);
 
 /* ---- losses ----------------------------------------------------------------------
  * nn.BCELoss(mean) against a per-sample target broadcast over the patch map
  * (GANLoss, models/networks.py:386-420; log clamped at -100 like torch);
  * nn.L1Loss / nn.MSELoss (models/wsgan_emb_model.py:141-149).
  * Each writes the scalar loss to loss[0] and, when grad != NULL, dloss/dpred * gscale. */
-int pcgan_bce_loss(const float* pred, const float* target_n, float* loss, float* grad, int N, int per_n,
-                   float gscale, void* ws, size_t ws_bytes, pcgan_stream_t s);
-int pcgan_l1_loss(const float* a, const float* b, float* loss, float* grad_a, size_t n, float gscale,
-                  void* ws, size_t ws_bytes, pcgan_stream_t s);
-int pcgan_mse_loss(const float* a, const float* b, float* loss, float* grad_a, size_t n, float gscale,
-                   void* ws, size_t ws_bytes, pcgan_stream_t s);
+int pcgan_bce_loss(const void* pred, const float* target_n, float* loss, void* grad, int N, int per_n,
+                   float gscale, void* ws, size_t ws_bytes, int dtype, pcgan_stream_t s);
+int pcgan_l1_loss(const void* a, const void* b, float* loss, void* grad_a, size_t n, float gscale,
+                  void* ws, size_t ws_bytes, int dtype, pcgan_stream_t s);
+int pcgan_mse_loss(const void* a, const void* b, float* loss, void* grad_a, size_t n, float gscale,
+                   void* ws, size_t ws_bytes, int dtype, pcgan_stream_t s);
 size_t pcgan_loss_workspace_bytes(size_t n);
 
 /* ---- optimizer -------------------------------------------------------------------
@@ -238,28 +248,31 @@ int pcgan_image_transform(const pcgan_image_desc* d, const uint8_t* src, const i
                           const int32_t* kv, const int32_t* bv, const int32_t* aug, float* out, int n, int band,
                           int max_rows, pcgan_stream_t s);
 
-/* ---- experiment: fp32-accurate convolution forward on the bf16 matrix pipe -----------
+/* ---- convolution on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulators) -----------
  * Same call sites as pcgan_conv2d_fwd_packed for stride-1 convolutions with C % 16 == 0, K >= 32, at most 25 taps
- * (the ResnetBlock convolutions, models/networks.py:621-648).  Every fp32 operand is split exactly into three bf16
- * pieces and the six piece products that matter are accumulated in fp32 (v_mfma_f32_32x32x16_bf16): error as the fp32
- * MFMA path (scripts/micro/bf16_split.hip).  Opt-in on the host side (PCGAN_BF16X6=1); pack once per weight version. */
+ * (the ResnetBlock convolutions, models/networks.py:621-648).
+ *   desc.dtype = PCGAN_F32:  every fp32 operand is split exactly into three bf16 pieces and the six piece products that
+ *                            matter are accumulated in fp32: error as the fp32 MFMA path (scripts/micro/bf16_split.hip).
+ *                            The host routes the residual-block convolutions here by default (PCGAN_BF16X6=0: fp32 MFMA).
+ *   desc.dtype = PCGAN_BF16: the bf16 path: bf16 activations as stored, weights rounded to bf16 by the pack call, one product.
+ * Pack once per weight version. */
 int pcgan_conv2d_bsplit_supported(const pcgan_conv_desc* d);
 size_t pcgan_conv2d_bsplit_packed_bytes(const pcgan_conv_desc* d);
 int pcgan_conv2d_bsplit_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s);
-int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y,
+int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
                             int act, float slope, pcgan_stream_t s);
 /* the same for the data gradient of nn.ReflectionPad2d(1) + nn.Conv2d(k=3, stride 1) (the ResnetBlock convolutions): row
  * mirrors folded into three per-row-class weight sets by the pack call, column mirrors gathered as a second source. */
 int pcgan_conv2d_bsplit_dgrad_supported(const pcgan_conv_desc* d);
 size_t pcgan_conv2d_bsplit_dgrad_packed_bytes(const pcgan_conv_desc* d);
 int pcgan_conv2d_bsplit_dgrad_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s);
-int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const float* dy, const void* packed, float* dx, pcgan_stream_t s);
+int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const void* dy, const void* packed, void* dx, pcgan_stream_t s);
 /* ... and for its weight gradient: the same GEMM with the roles turned (rows = output channels, operand A = dy re-split per
  * call, columns = (c, r, s), reduction over pixels in splits + a fixed-order reduce); ws holds the reflection-padded copy of x,
  * the pieces of dy and the partial sums.  accumulate != 0 adds into dw like pcgan_conv2d_bwd_weight. */
 int pcgan_conv2d_bsplit_wgrad_supported(const pcgan_conv_desc* d);
 size_t pcgan_conv2d_bsplit_wgrad_workspace_bytes(const pcgan_conv_desc* d);
-int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate, void* ws,
+int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* ws,
                                    size_t ws_bytes, pcgan_stream_t s);
 
 #ifdef __cplusplus

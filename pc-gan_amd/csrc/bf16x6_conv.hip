@@ -1,5 +1,8 @@
-// EXPERIMENT (opt-in, PCGAN_BF16X6=1): stride-1 convolution forward -- and the data and weight gradients of the reflection-padded
-// 3x3 convolution -- with fp32 accuracy on the bf16 matrix pipe.
+// Stride-1 convolution forward -- and the data and weight gradients of the reflection-padded 3x3 convolution -- on the bf16
+// matrix pipe, in two precisions that share one kernel skeleton (template parameters NP = pieces per operand, TA = storage):
+//   NP = 3, TA = float  fp32 tensors, fp32-level accuracy (the default route of the residual-block convolutions, below);
+//   NP = 1, TA = bf16   the bf16 path (desc.dtype = PCGAN_BF16): activations stored as bf16, weights rounded to bf16 by the
+//                       pack kernel, ONE product per term, fp32 accumulators -- plain mixed precision, 6x fewer MFMAs.
 //
 // An fp32 value is the exact sum of three bf16 pieces, x = h + m + l (8 + 8 + 8 significand bits).  A product a*b then needs
 // the piece pairs (h,h) | (h,m) (m,h) | (h,l) (m,m) (l,h) to keep every term above 2^-24 |a||b|; everything is accumulated in
@@ -38,10 +41,10 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 }
 
 struct BsplitArgs {
-    const float* X;      // [N][C][H][W]
+    const void* X;       // [N][C][H][W], storage type TA
     const void* A;       // packed weights, see above
     const float* bias;   // [M] or null
-    float* Y;            // [N][M][P][Q]
+    void* Y;             // [N][M][P][Q], storage type TA (weight gradient: fp32 partial sums)
     int N, C, H, W, M, R, S, pad, reflect, P, Q;
     int nMt, nst, act;
     float slope;
@@ -59,7 +62,7 @@ enum { BS_FWD_ZERO = 0, BS_FWD_REFLECT = 1, BS_DGRAD_REFLECT = 2, BS_WGRAD = 3 }
 // weights w[M][C][R][S] -> [piece][mt][stage][half][BM][8] bf16 (BM = 128 << bm_shift), stage = chunk * T + tap, k in stage =
 // channel in chunk
 __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int M, int C, int T, int nMt, int nst,
-                                   int bm_shift) {
+                                   int bm_shift, int np) {
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nMt * nst * 16 * BM;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_piece; i += (size_t)gridDim.x * blockDim.x) {
@@ -70,19 +73,22 @@ __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restri
         const float v = m < M ? w[((size_t)m * C + c) * T + tap] : 0.f;
         __bf16 h, mm, l;
         split3(v, h, mm, l);
-        A[i] = h;
-        A[per_piece + i] = mm;
-        A[2 * per_piece + i] = l;
+        A[i] = h;                      // (np == 1: the weight rounded to nearest-even bf16)
+        if (np == 3) {
+            A[per_piece + i] = mm;
+            A[2 * per_piece + i] = l;
+        }
     }
 }
 
 // ---- weight gradient as the same GEMM with the roles turned: rows = output channels k (operand A = dy, re-split per call), columns
 // = (c, r, s), reduction = (n, y, x) in stages of 16 consecutive x.  The reflection padding is materialised once (xpad), so that
 // the gather address is separable: column part (c, r, s) in the lane's offset, reduction part (n, y, x) in the scalar offset.
-__global__ void bsplit_pad_reflect_kernel(const float* __restrict__ x, float* __restrict__ xp, int H, int W, int pad) {
+template <typename TA>
+__global__ void bsplit_pad_reflect_kernel(const TA* __restrict__ x, TA* __restrict__ xp, int H, int W, int pad) {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    const float* src = x + (size_t)blockIdx.y * H * W;
-    float* dst = xp + (size_t)blockIdx.y * Hp * Wp;
+    const TA* src = x + (size_t)blockIdx.y * H * W;
+    TA* dst = xp + (size_t)blockIdx.y * Hp * Wp;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hp * Wp; i += gridDim.x * blockDim.x) {
         int y = i / Wp - pad, xx = i % Wp - pad;
         y = y < 0 ? -y : (y >= H ? 2 * (H - 1) - y : y);
@@ -92,7 +98,8 @@ __global__ void bsplit_pad_reflect_kernel(const float* __restrict__ x, float* __
 }
 
 // dy[N][K][HW] -> [piece][stage][half][BM][8] bf16 pieces, stage = 16 consecutive elements of the (n, y, x) reduction
-__global__ void bsplit_pack_dy_kernel(const float* __restrict__ dy, __bf16* __restrict__ A, int K, int HW, int nst, int bm_shift) {
+template <typename TA>
+__global__ void bsplit_pack_dy_kernel(const TA* __restrict__ dy, __bf16* __restrict__ A, int K, int HW, int nst, int bm_shift, int np) {
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nst * 16 * BM;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_piece; i += (size_t)gridDim.x * blockDim.x) {
@@ -100,12 +107,14 @@ __global__ void bsplit_pack_dy_kernel(const float* __restrict__ dy, __bf16* __re
         const size_t st = i >> (11 + bm_shift);
         const size_t e = st * 16 + half * 8 + j;
         const size_t n = e / HW, r = e - n * HW;
-        const float v = row < K ? dy[(n * K + row) * HW + r] : 0.f;
+        const float v = row < K ? ld1(dy + (n * K + row) * HW + r) : 0.f;
         __bf16 h, mm, l;
         split3(v, h, mm, l);
         A[i] = h;
-        A[per_piece + i] = mm;
-        A[2 * per_piece + i] = l;
+        if (np == 3) {
+            A[per_piece + i] = mm;
+            A[2 * per_piece + i] = l;
+        }
     }
 }
 
@@ -131,10 +140,12 @@ __global__ void bsplit_wgrad_reduce_kernel(const float* __restrict__ part, float
 // k = (16-chunk of output channels, tap (r', s'), channel), value = wf[c][k][r'][s'] = w[k][c][2-r'][2-s'] with the row mirror
 // folded in: row class 1 (row 1) reads row 0 through tap r'=0 for itself AND for padded row -1: wf'[0] = wf[0] + wf[2];
 // row class 2 (row H-2): wf'[2] = wf[2] + wf[0].
-__global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int K, int C, int nMt, int nst, int bm_shift) {
+__global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int K, int C, int nMt, int nst, int bm_shift,
+                                         int np) {
     const int BM = 128 << bm_shift;
-    const size_t per_piece = (size_t)nMt * nst * 16 * BM, per_phase = 3 * per_piece;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_phase; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t per_piece = (size_t)nMt * nst * 16 * BM, per_phase = (size_t)np * per_piece;
+    // (3 row classes x per_piece entries; each entry writes its np pieces)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 3 * per_piece; i += (size_t)gridDim.x * blockDim.x) {
         const int phase = (int)(i / per_piece);
         const size_t e = i - (size_t)phase * per_piece;
         const int j = (int)(e & 7), row = (int)((e >> 3) & (BM - 1)), half = (int)((e >> (10 + bm_shift)) & 1);
@@ -152,21 +163,25 @@ __global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __
         split3(v, h, mm, l);
         __bf16* out = A + (size_t)phase * per_phase;
         out[e] = h;
-        out[per_piece + e] = mm;
-        out[2 * per_piece + e] = l;
+        if (np == 3) {
+            out[per_piece + e] = mm;
+            out[2 * per_piece + e] = l;
+        }
     }
 }
 
-template <int MODE, int BM>
+template <int MODE, int BM, int NP, typename TA>
 __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
+    static_assert((NP == 3 && sizeof(TA) == 4) || (NP == 1 && sizeof(TA) == 2), "3 pieces of fp32 tensors, or bf16 tensors as they are");
+    constexpr unsigned ES = sizeof(TA);
     constexpr bool REFLECT = MODE == BS_FWD_REFLECT;
     constexpr bool DGRAD = MODE == BS_DGRAD_REFLECT;
     constexpr bool WGRAD = MODE == BS_WGRAD;
     constexpr int NT = BM * 2;              // threads
     constexpr int KB = 2048 / NT;           // channels of one pixel a thread gathers per stage (8 or 4)
     constexpr unsigned ASTAGE = BM * 32;    // bytes of one stage of one piece of the weights
-    __shared__ __attribute__((aligned(16))) bf16x8 As[2][3][2 * BM];   // [buffer][piece][half * BM + row]
-    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][3][256];      // [buffer][piece][half * 128 + pixel]
+    __shared__ __attribute__((aligned(16))) bf16x8 As[2][NP][2 * BM];   // [buffer][piece][half * BM + row]
+    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][NP][256];      // [buffer][piece][half * 128 + pixel]
     __shared__ unsigned offT[BS_MAXTAP][128];
 
     const int tid = threadIdx.x;
@@ -183,7 +198,7 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
     const int Hs = DGRAD ? (phase == 0 ? a.H - 2 : 1) : a.P;      // rows per image of this phase's pixel list
     const int T = a.R * a.S, PQ = WGRAD ? a.C * T : Hs * a.Q, Ptot = WGRAD ? PQ : a.N * PQ;
     const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;          // WGRAD: padded planes of xpad
-    const int HW4 = a.H * a.W * 4;
+    const int HW4 = a.H * a.W * (int)ES;      // bytes of one channel plane
     const int pl = tid & 127;
     const int kq = __builtin_amdgcn_readfirstlane(tid >> 7);      // which KB-channel slice of the 16-channel stage
     const int half = (kq * KB) >> 3;
@@ -199,7 +214,7 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
         const unsigned nbase = (unsigned)n * (unsigned)a.C * (unsigned)(a.H * a.W);
         if (WGRAD) {   // column (c, r, s) -> offset of xpad[0][c][r][s]; the reduction part comes through the scalar offset
             const int c = pg / T, tap = pg - c * T, r = tap / a.S, sx = tap - r * a.S;
-            if (kq == 0) offT[0][pl] = pv ? (unsigned)((c * Hp + r) * Wp + sx) * 4u : BS_OOB;
+            if (kq == 0) offT[0][pl] = pv ? (unsigned)((c * Hp + r) * Wp + sx) * ES : BS_OOB;
         }
         for (int t = kq; !WGRAD && t < T; t += NT / 128) {
             const int r = t / a.S, s = t - r * a.S;
@@ -213,23 +228,27 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
             } else {
                 ok = ok & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
             }
-            offT[t][pl] = ok ? (nbase + (unsigned)(iy * a.W + ix)) * 4u : BS_OOB;
+            offT[t][pl] = ok ? (nbase + (unsigned)(iy * a.W + ix)) * ES : BS_OOB;
             if (DGRAD) {   // column mirror: column 1 also receives padded column -1 (source column 0 through tap s'=2), column W-2 padded column W
                 const int ix2 = (px == 1 && s == 2) ? 0 : ((px == a.W - 2 && s == 0) ? a.W - 1 : -1);
                 const bool ok2 = pv & (ix2 >= 0) & ((unsigned)iy < (unsigned)a.H);
-                offT[9 + t][pl] = ok2 ? (nbase + (unsigned)(iy * a.W + ix2)) * 4u : BS_OOB;
+                offT[9 + t][pl] = ok2 ? (nbase + (unsigned)(iy * a.W + ix2)) * ES : BS_OOB;
             }
         }
     }
     __syncthreads();
 
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, (int)a.x_bytes, 0x00020000);
+    auto ldx = [&](unsigned voff, unsigned soff) -> float {      // one activation element as fp32
+        if constexpr (ES == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, voff, soff, 0));
+        else return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rX, voff, soff, 0) << 16);
+    };
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)a.a_bytes, 0x00020000);
     const unsigned piece_bytes = (unsigned)a.nMt * (unsigned)a.nst * ASTAGE;
     const unsigned a_tile = (DGRAD ? (unsigned)phase * a.phase_bytes : 0u) + (unsigned)mt * (unsigned)a.nst * ASTAGE;
 
     struct Stage {
-        u32x4 ap[3];
+        u32x4 ap[NP];
         float b[KB];
         float b2[DGRAD ? KB : 1];     // column-mirror source (two lanes per image row are in range)
     };
@@ -241,45 +260,52 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
         const unsigned avo = live ? (unsigned)tid * 16u : BS_OOB;
         const unsigned aso = a_tile + (unsigned)gs * ASTAGE;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) r.ap[p] = __builtin_amdgcn_raw_buffer_load_b128(rA, avo, aso + p * piece_bytes, 0);
+        for (int p = 0; p < NP; ++p) r.ap[p] = __builtin_amdgcn_raw_buffer_load_b128(rA, avo, aso + p * piece_bytes, 0);
         if (WGRAD) {   // 16 consecutive x of image n, row y: scalar offset of xpad[n][0][y][x0], the thread's KB values are consecutive
             const int e0 = gs * 16, hw = a.H * a.W;
             const int n = e0 / hw, rem = e0 - n * hw, y = rem / a.W, x0 = rem - y * a.W;
             const unsigned bvo = live ? offT[0][pl] : BS_OOB;
-            const unsigned bso = (unsigned)(((n * a.C) * Hp + y) * Wp + x0 + kq * KB) * 4u;
+            const unsigned bso = (unsigned)(((n * a.C) * Hp + y) * Wp + x0 + kq * KB) * ES;
 #pragma unroll
-            for (int j = 0; j < KB; ++j) r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, bvo, bso + j * 4, 0));
+            for (int j = 0; j < KB; ++j) r.b[j] = ldx(bvo, bso + j * ES);
             return;
         }
         const int cc = gs / T, tap = gs - cc * T;
         const unsigned bvo = live ? offT[tap][pl] : BS_OOB;
         const unsigned bso = live ? (unsigned)(cc * 16 + kq * KB) * (unsigned)HW4 : 0u;
 #pragma unroll
-        for (int j = 0; j < KB; ++j) r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, bvo, bso + j * HW4, 0));
+        for (int j = 0; j < KB; ++j) r.b[j] = ldx(bvo, bso + j * HW4);
         if (DGRAD) {
             const unsigned bvo2 = live ? offT[9 + tap][pl] : BS_OOB;
 #pragma unroll
-            for (int j = 0; j < KB; ++j) r.b2[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, bvo2, bso + j * HW4, 0));
+            for (int j = 0; j < KB; ++j) r.b2[j] = ldx(bvo2, bso + j * HW4);
         }
     };
     auto stash = [&](const Stage& r, int buf) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&As[buf][p][tid]) = r.ap[p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(&As[buf][p][tid]) = r.ap[p];
         typedef __bf16 bfv __attribute__((ext_vector_type(KB)));
         bfv h, m, l;
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-            __bf16 x, y, z;
-            split3(DGRAD ? r.b[j] + r.b2[j] : r.b[j], x, y, z);
-            h[j] = x;
-            m[j] = y;
-            l[j] = z;
+            const float v = DGRAD ? r.b[j] + r.b2[j] : r.b[j];
+            if constexpr (NP == 3) {
+                __bf16 x, y, z;
+                split3(v, x, y, z);
+                h[j] = x;
+                m[j] = y;
+                l[j] = z;
+            } else {
+                h[j] = (__bf16)v;      // a stored bf16 value comes back unchanged; the mirror sum of the data gradient is rounded once
+            }
         }
         // this thread's KB consecutive k of pixel pl: offset (kq * KB) % 8 inside the pixel's 8-wide half
         const int sub = (kq * KB) & 7;
         *reinterpret_cast<bfv*>(reinterpret_cast<__bf16*>(&Bs[buf][0][half * 128 + pl]) + sub) = h;
-        *reinterpret_cast<bfv*>(reinterpret_cast<__bf16*>(&Bs[buf][1][half * 128 + pl]) + sub) = m;
-        *reinterpret_cast<bfv*>(reinterpret_cast<__bf16*>(&Bs[buf][2][half * 128 + pl]) + sub) = l;
+        if constexpr (NP == 3) {
+            *reinterpret_cast<bfv*>(reinterpret_cast<__bf16*>(&Bs[buf][1][half * 128 + pl]) + sub) = m;
+            *reinterpret_cast<bfv*>(reinterpret_cast<__bf16*>(&Bs[buf][2][half * 128 + pl]) + sub) = l;
+        }
     };
 
     f32x16 acc[2][2];
@@ -291,11 +317,11 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     struct Operands {
-        bf16x8 A[3][2], B[3][2];
+        bf16x8 A[NP][2], B[NP][2];
     };
     auto fetch = [&](Operands& o, int buf) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 o.A[p][i] = As[buf][p][hi * BM + wm * 64 + i * 32 + lo];
@@ -307,7 +333,7 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
         // MFMAs are independent
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = (NP == 3 ? 0 : 5); q < 6; ++q)       // one piece: only the (h, h) product
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -336,13 +362,24 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
     // the other work -- LDS reads of the next stage first, then the split arithmetic and LDS writes of the stage after, then the
     // global loads three stages ahead (0.178 -> 0.171 ms)
     auto interleave = [&]() {
+        if constexpr (NP == 3) {
 #pragma unroll
-        for (int q = 0; q < 24; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
-            if (q < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // two VALU
-            if (q >= 12 && q < 18) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // one LDS write
-            if (q >= 14 && q < 14 + 3 + KB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one global load
+            for (int q = 0; q < 24; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+                if (q < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // two VALU
+                if (q >= 12 && q < 18) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // one LDS write
+                if (q >= 14 && q < 14 + 3 + KB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one global load
+            }
+        } else {   // 4 MFMAs per stage: one LDS read, then the two LDS writes / the global loads behind each of them
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                if (q < 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, (1 + KB * (DGRAD ? 2 : 1) + 3) / 4, 0);
+            }
         }
     };
     for (int s = 0; s < nst2; s += 2) {
@@ -373,15 +410,16 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
             rem = y * a.Q + x;
         }
         const int PQo = WGRAD ? PQ : a.P * a.Q;
-        float* yb = a.Y + (WGRAD ? (size_t)blockIdx.y : (size_t)n) * a.M * PQo + rem;
+        const size_t yo = (WGRAD ? (size_t)blockIdx.y : (size_t)n) * a.M * PQo + rem;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mt * BM + wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
                 if (m < a.M) {
-                    float v = acc[i][j][r] + (a.bias ? a.bias[m] : 0.f);
-                    yb[(size_t)m * PQo] = act_apply(v, a.act, a.slope);
+                    const float v = act_apply(acc[i][j][r] + (a.bias ? a.bias[m] : 0.f), a.act, a.slope);
+                    if constexpr (WGRAD) ((float*)a.Y)[yo + (size_t)m * PQo] = v;      // fp32 partial sums
+                    else st1((TA*)a.Y + yo + (size_t)m * PQo, v);
                 }
             }
     }
@@ -389,11 +427,28 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
 
 static int bsplit_check(const pcgan_conv_desc* d) {
     PCGAN_CHECK(d, "conv2d_bsplit: null descriptor");
+    PCGAN_CHECK(d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16, "conv2d_bsplit: dtype %d", d->dtype);
     PCGAN_CHECK(d->stride == 1 && d->C % 16 == 0 && d->R * d->S <= BS_MAXTAP && d->K >= 32, "conv2d_bsplit: unsupported shape");
     PCGAN_CHECK(d->P == d->H + 2 * d->pad - d->R + 1 && d->Q == d->W + 2 * d->pad - d->S + 1, "conv2d_bsplit: output dims");
     PCGAN_CHECK(d->pad_mode == 0 || (d->pad < d->H && d->pad < d->W), "conv2d_bsplit: reflection pad too large");
     PCGAN_CHECK((size_t)d->N * d->C * d->H * d->W * 4 < 0x80000000ull, "conv2d_bsplit: input beyond 2 GiB");
     return 0;
+}
+
+// pieces per operand / bytes per activation element of the descriptor's storage type
+static inline int np_of(const pcgan_conv_desc* d) { return d->dtype == PCGAN_BF16 ? 1 : 3; }
+static inline size_t es_of(const pcgan_conv_desc* d) { return d->dtype == PCGAN_BF16 ? 2 : 4; }
+
+// launch bsplit_conv_fwd_kernel<MODE, BM, NP, TA> for the tile / storage type at hand
+template <int MODE>
+static void launch_bsplit(const pcgan_conv_desc* d, int bm, dim3 grid, hipStream_t st, const BsplitArgs& a) {
+    if (d->dtype == PCGAN_BF16) {
+        if (bm == 256) hipLaunchKernelGGL((bsplit_conv_fwd_kernel<MODE, 256, 1, bf16>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((bsplit_conv_fwd_kernel<MODE, 128, 1, bf16>), grid, dim3(256), 0, st, a);
+    } else {
+        if (bm == 256) hipLaunchKernelGGL((bsplit_conv_fwd_kernel<MODE, 256, 3, float>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((bsplit_conv_fwd_kernel<MODE, 128, 3, float>), grid, dim3(256), 0, st, a);
+    }
 }
 
 }  // namespace pcgan
@@ -410,7 +465,7 @@ extern "C" size_t pcgan_conv2d_bsplit_packed_bytes(const pcgan_conv_desc* d) {
     if (!pcgan_conv2d_bsplit_supported(d)) return 0;
     const int bm = bsplit_bm(d);
     const size_t nMt = (d->K + bm - 1) / bm, nst = (size_t)(d->C / 16) * d->R * d->S;
-    return 3 * nMt * nst * 32 * bm;
+    return (size_t)pcgan::np_of(d) * nMt * nst * 32 * bm;
 }
 
 extern "C" int pcgan_conv2d_bsplit_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s) {
@@ -421,12 +476,12 @@ extern "C" int pcgan_conv2d_bsplit_pack(const pcgan_conv_desc* d, const float* w
     const size_t per_piece = (size_t)nMt * nst * 16 * bm;
     const int blocks = (int)((per_piece + 255) / 256 > 4096 ? 4096 : (per_piece + 255) / 256);
     hipLaunchKernelGGL(pcgan::bsplit_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (__bf16*)packed, d->K, d->C, T, nMt, nst,
-                       bm == 256 ? 1 : 0);
+                       bm == 256 ? 1 : 0, pcgan::np_of(d));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y,
+extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
                                        int act, float slope, pcgan_stream_t s) {
     if (pcgan::bsplit_check(d)) return 1;
     PCGAN_CHECK(x && packed && y, "conv2d_fwd_bsplit: null pointer");
@@ -438,22 +493,17 @@ extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const float* x,
     a.nMt = (d->K + bm - 1) / bm;
     a.nst = (d->C / 16) * d->R * d->S;
     a.act = act; a.slope = slope;
-    a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
+    a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * pcgan::es_of(d));
     a.tstart[0] = a.tstart[1] = a.tstart[2] = a.tstart[3] = 0;
     a.phase_bytes = 0;
     a.nst_split = 0;
-    const size_t ab = 3 * (size_t)a.nMt * a.nst * 32 * bm;
+    const size_t ab = (size_t)pcgan::np_of(d) * a.nMt * a.nst * 32 * bm;
     PCGAN_CHECK(ab < 0x80000000ull, "conv2d_fwd_bsplit: packed weights beyond 2 GiB");
     a.a_bytes = (unsigned)ab;
     const long ptiles = ((long)d->N * d->P * d->Q + 127) / 128;
     const dim3 grid((unsigned)(ptiles * a.nMt));
-    if (bm == 256) {
-        if (d->pad_mode == 1) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_FWD_REFLECT, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
-        else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_FWD_ZERO, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
-    } else {
-        if (d->pad_mode == 1) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_FWD_REFLECT, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
-        else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_FWD_ZERO, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
-    }
+    if (d->pad_mode == 1) pcgan::launch_bsplit<pcgan::BS_FWD_REFLECT>(d, bm, grid, (hipStream_t)s, a);
+    else pcgan::launch_bsplit<pcgan::BS_FWD_ZERO>(d, bm, grid, (hipStream_t)s, a);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -470,7 +520,7 @@ extern "C" size_t pcgan_conv2d_bsplit_dgrad_packed_bytes(const pcgan_conv_desc* 
     if (!pcgan_conv2d_bsplit_dgrad_supported(d)) return 0;
     const int bm = bsplit_dgrad_bm(d);
     const size_t nMt = (d->C + bm - 1) / bm, nst = (size_t)(d->K / 16) * 9;
-    return 3 * 3 * nMt * nst * 32 * bm;
+    return 3 * (size_t)pcgan::np_of(d) * nMt * nst * 32 * bm;
 }
 
 extern "C" int pcgan_conv2d_bsplit_dgrad_pack(const pcgan_conv_desc* d, const float* w, void* packed, pcgan_stream_t s) {
@@ -481,13 +531,14 @@ extern "C" int pcgan_conv2d_bsplit_dgrad_pack(const pcgan_conv_desc* d, const fl
     const size_t total = 3 * (size_t)nMt * nst * 16 * bm;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(pcgan::bsplit_pack_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (__bf16*)packed, d->K, d->C, nMt, nst,
-                       bm == 256 ? 1 : 0);
+                       bm == 256 ? 1 : 0, pcgan::np_of(d));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const float* dy, const void* packed, float* dx, pcgan_stream_t s) {
+extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const void* dy, const void* packed, void* dx, pcgan_stream_t s) {
     PCGAN_CHECK(pcgan_conv2d_bsplit_dgrad_supported(d), "conv2d_bwd_data_bsplit: unsupported shape");
+    PCGAN_CHECK(d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16, "conv2d_bwd_data_bsplit: dtype %d", d->dtype);
     PCGAN_CHECK(dy && packed && dx, "conv2d_bwd_data_bsplit: null pointer");
     pcgan::BsplitArgs a;
     a.X = dy; a.A = packed; a.bias = nullptr; a.Y = dx;
@@ -497,8 +548,8 @@ extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const floa
     a.nMt = (d->C + bm - 1) / bm;
     a.nst = (d->K / 16) * 9;
     a.act = PCGAN_ACT_NONE; a.slope = 0.f;
-    a.x_bytes = (unsigned)((size_t)d->N * d->K * d->H * d->W * 4);
-    const size_t per_phase = 3 * (size_t)a.nMt * a.nst * 32 * bm;
+    a.x_bytes = (unsigned)((size_t)d->N * d->K * d->H * d->W * pcgan::es_of(d));
+    const size_t per_phase = (size_t)pcgan::np_of(d) * a.nMt * a.nst * 32 * bm;
     PCGAN_CHECK(3 * per_phase < 0x80000000ull, "conv2d_bwd_data_bsplit: packed weights beyond 2 GiB");
     a.phase_bytes = (unsigned)per_phase;
     a.a_bytes = (unsigned)(3 * per_phase);
@@ -511,8 +562,7 @@ extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const floa
     }
     a.tstart[3] = (int)t;
     const dim3 grid((unsigned)(t * a.nMt));
-    if (bm == 256) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_DGRAD_REFLECT, 256>), grid, dim3(512), 0, (hipStream_t)s, a);
-    else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_DGRAD_REFLECT, 128>), grid, dim3(256), 0, (hipStream_t)s, a);
+    pcgan::launch_bsplit<pcgan::BS_DGRAD_REFLECT>(d, bm, grid, (hipStream_t)s, a);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -543,32 +593,40 @@ extern "C" size_t pcgan_conv2d_bsplit_wgrad_workspace_bytes(const pcgan_conv_des
     const size_t nMt = (d->K + bm - 1) / bm;
     const size_t packed = pcgan::align_up(3 * nMt * (size_t)(d->N * d->H * d->W / 16) * 32 * bm, 256);
     const size_t part = (size_t)splits * nMt * bm * d->C * 9 * 4;
-    return xpad + packed + part;
+    return xpad + packed + part;       // (sized for the fp32 / 3-piece case; the bf16 path uses less of it)
 }
 
-extern "C" int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+extern "C" int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                                               void* ws, size_t ws_bytes, pcgan_stream_t s) {
     PCGAN_CHECK(pcgan_conv2d_bsplit_wgrad_supported(d), "conv2d_bwd_weight_bsplit: unsupported shape");
+    PCGAN_CHECK(d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16, "conv2d_bwd_weight_bsplit: dtype %d", d->dtype);
     PCGAN_CHECK(x && dy && dw && ws && ws_bytes >= pcgan_conv2d_bsplit_wgrad_workspace_bytes(d), "conv2d_bwd_weight_bsplit: null pointer or small workspace");
     const int bm = d->K % 256 == 0 ? 256 : 128;
     PCGAN_CHECK(d->K % bm == 0, "conv2d_bwd_weight_bsplit: output channels must fill the %d-row tile", bm);
     hipStream_t st = (hipStream_t)s;
+    const bool half = d->dtype == PCGAN_BF16;
+    const int np = pcgan::np_of(d);
     int per;
     const int splits = bsplit_wgrad_splits(d, bm, &per);
     const int nst = d->N * d->H * d->W / 16, nMt = d->K / bm;
     const size_t xpad_bytes = pcgan::align_up((size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4, 256);
     const size_t packed_bytes = pcgan::align_up(3 * (size_t)nMt * nst * 32 * bm, 256);
-    float* xpad = (float*)ws;
+    void* xpad = ws;
     __bf16* packed = (__bf16*)((char*)ws + xpad_bytes);
     float* part = (float*)((char*)ws + xpad_bytes + packed_bytes);
     PCGAN_CHECK(d->N * d->C <= 65535, "conv2d_bwd_weight_bsplit: more than 65535 planes");
     const int per_plane = (d->H + 2) * (d->W + 2);
-    hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel, dim3((per_plane + 255) / 256, d->N * d->C), dim3(256), 0, st, x, xpad, d->H, d->W, 1);
+    const dim3 pgrid((per_plane + 255) / 256, d->N * d->C);
+    if (half) hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel<pcgan::bf16>, pgrid, dim3(256), 0, st, (const pcgan::bf16*)x, (pcgan::bf16*)xpad, d->H, d->W, 1);
+    else hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel<float>, pgrid, dim3(256), 0, st, (const float*)x, (float*)xpad, d->H, d->W, 1);
     PCGAN_LAUNCH_CHECK();
     PCGAN_CHECK(nMt == 1, "conv2d_bwd_weight_bsplit: more than one %d-row tile of output channels is not built", bm);
     const size_t per_piece = (size_t)nst * 16 * bm;
-    hipLaunchKernelGGL(pcgan::bsplit_pack_dy_kernel, dim3((unsigned)((per_piece + 255) / 256 > 8192 ? 8192 : (per_piece + 255) / 256)), dim3(256), 0, st,
-                       dy, packed, d->K, d->H * d->W, nst, bm == 256 ? 1 : 0);
+    const dim3 ygrid((unsigned)((per_piece + 255) / 256 > 8192 ? 8192 : (per_piece + 255) / 256));
+    if (half) hipLaunchKernelGGL(pcgan::bsplit_pack_dy_kernel<pcgan::bf16>, ygrid, dim3(256), 0, st, (const pcgan::bf16*)dy, packed, d->K, d->H * d->W, nst,
+                                 bm == 256 ? 1 : 0, np);
+    else hipLaunchKernelGGL(pcgan::bsplit_pack_dy_kernel<float>, ygrid, dim3(256), 0, st, (const float*)dy, packed, d->K, d->H * d->W, nst,
+                            bm == 256 ? 1 : 0, np);
     PCGAN_LAUNCH_CHECK();
     pcgan::BsplitArgs a;
     a.X = xpad; a.A = packed; a.bias = nullptr; a.Y = part;
@@ -578,13 +636,12 @@ extern "C" int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const fl
     a.nst = nst;
     a.nst_split = per;
     a.act = PCGAN_ACT_NONE; a.slope = 0.f;
-    a.x_bytes = (unsigned)((size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4);
-    a.a_bytes = (unsigned)(3 * (size_t)nMt * nst * 32 * bm);
+    a.x_bytes = (unsigned)((size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * pcgan::es_of(d));
+    a.a_bytes = (unsigned)((size_t)np * nMt * nst * 32 * bm);
     a.tstart[0] = a.tstart[1] = a.tstart[2] = a.tstart[3] = 0;
     a.phase_bytes = 0;
     const dim3 grid((unsigned)(((d->C * 9 + 127) / 128) * nMt), (unsigned)splits);
-    if (bm == 256) hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_WGRAD, 256>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((pcgan::bsplit_conv_fwd_kernel<pcgan::BS_WGRAD, 128>), grid, dim3(256), 0, st, a);
+    pcgan::launch_bsplit<pcgan::BS_WGRAD>(d, bm, grid, st, a);
     PCGAN_LAUNCH_CHECK();
     const size_t total = (size_t)d->K * d->C * 9;
     hipLaunchKernelGGL(pcgan::bsplit_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, dw, splits, total, accumulate);

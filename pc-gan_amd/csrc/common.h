@@ -56,6 +56,47 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope
     }
 }
 
+// ---- activation storage types ------------------------------------------------------------------------------------
+// PCGAN_F32: fp32 tensors.  PCGAN_BF16: activations and their gradients are stored as bf16 in HBM (half the bytes of the
+// HBM-bound kernels) while every kernel computes in fp32 registers; statistics, losses, parameters, parameter gradients and
+// optimizer state stay fp32.  ld1 / ld4 / st1 / st4 are the only places that know the storage width: 4 consecutive elements
+// are one 16-byte (fp32) or one 8-byte (bf16) access.  fp32 -> bf16 is round-to-nearest-even (a plain cast: v_cvt_pk_bf16_f32,
+// NaN stays NaN).
+typedef __bf16 bf16;
+
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16* p, float v) { *p = (bf16)v; }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16* p, const float4& v) {
+    typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 o;
+    o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// run `...` with T = the storage type of `dtype` (host side of every entry point that takes a dtype)
+#define PCGAN_DTYPE_SWITCH(dtype, T, ...)                                   \
+    do {                                                                    \
+        if ((dtype) == PCGAN_F32) {                                         \
+            typedef float T;                                                \
+            __VA_ARGS__;                                                    \
+        } else if ((dtype) == PCGAN_BF16) {                                 \
+            typedef pcgan::bf16 T;                                          \
+            __VA_ARGS__;                                                    \
+        } else {                                                            \
+            pcgan::set_error("unknown dtype %d (PCGAN_F32 / PCGAN_BF16)", (int)(dtype)); \
+            return 1;                                                       \
+        }                                                                   \
+    } while (0)
+
 // wave64 all-reduce sum via DPP-free shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

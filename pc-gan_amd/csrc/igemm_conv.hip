@@ -44,6 +44,33 @@ __device__ __forceinline__ float4 ld_b128(__amdgpu_buffer_rsrc_t r, unsigned vof
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// Activation tensors (x, y, dy, dx) are stored as TA = float or bf16 (common.h); the gathers go through range-checked buffer
+// loads with BYTE offsets, so every offset of an activation tensor is scaled by ES = sizeof(TA).  Weights (packed A operands),
+// partial sums and weight gradients are always fp32.
+template <typename TA>
+__device__ __forceinline__ float ldx(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ float ldx<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return ld_b32(r, voff, soff); }
+template <>
+__device__ __forceinline__ float ldx<bf16>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0) << 16);
+}
+// four consecutive elements
+template <typename TA>
+__device__ __forceinline__ float4 ldx4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ float4 ldx4<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+template <>
+__device__ __forceinline__ float4 ldx4<bf16>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+}
+
 struct PhaseArgs {
     const float* A;  // [M][Kp], k = (tap_index * Cgp + c)
     int Kp;
@@ -56,8 +83,9 @@ struct PhaseArgs {
 };
 
 struct IgemmArgs {
-    const float* X;     // gathered tensor [N][Cg][Hg][Wg]
-    float* Y;           // output tensor   [N][M][Yh][Yw]
+    const void* X;      // gathered tensor [N][Cg][Hg][Wg], storage type TA
+    void* Y;            // output tensor   [N][M][Yh][Yw], storage type TA
+    int dtype;          // PCGAN_F32 / PCGAN_BF16: which TA instantiation runs
     const float* bias;  // [M] or null
     int M, N, Cg, Cgp, Hg, Wg;
     int Yh, Yw;
@@ -125,9 +153,10 @@ struct KIter {
 //   Bs[k/4][pix][4]  : 4 consecutive k of one pixel per 16-byte slot
 // The MFMA consumes K in a permuted order (half-wave h takes k = 4*(2q+h)+j in step (q,j)); A and B use the same
 // permutation so the sum is unchanged.  The layers that matter for the step time use igemm2_kernel below.
-template <int MODE, int BM, int BP>
+template <int MODE, int BM, int BP, typename TA>
 __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     static_assert(MODE != MODE_BWD_REFLECT, "the mirror-gather data gradient exists only in the chunked-K kernel");
+    constexpr unsigned ES = sizeof(TA);
     constexpr int WM = (BM == 128 || (BM == 64 && BP == 64)) ? 2 : 1;  // waves along M
     constexpr int WP = 4 / WM;                                         // waves along pixels
     constexpr int WMT = BM / WM, WPT = BP / WP;
@@ -208,10 +237,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
                 if (e.ri < ph_nR) {
                     int off;
                     const bool ok = tap_offset<MODE>(g, py, px, ph_r0 + e.ri * a.tstep, ph_s0 + e.sj * a.tstep, off);
-                    voff = (ok && pvalid) ? (unsigned)(vbase + off) * 4u : OOB;
+                    voff = (ok && pvalid) ? (unsigned)(vbase + off) * ES : OOB;
                 }
             }
-            breg[i] = (e.c < a.Cg) ? ld_b32(rX, voff, (unsigned)(e.c * HgWg) * 4u) : 0.f;
+            breg[i] = (e.c < a.Cg) ? ldx<TA>(rX, voff, (unsigned)(e.c * HgWg) * ES) : 0.f;
             e.advance(1, a.Cgp, ph_nS);
         }
         it.advance(16, a.Cgp, ph_nS);
@@ -300,7 +329,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
             }
             continue;
         }
-        float* Yp = a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
+        TA* Yp = (TA*)a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -310,7 +339,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
                     float v = acc[i][j][r];
                     if (a.bias) v += a.bias[m];
                     v = act_apply(v, a.act, a.slope);
-                    Yp[(size_t)m * YhYw] = v;
+                    st1(Yp + (size_t)m * YhYw, v);
                 }
             }
         }
@@ -394,8 +423,9 @@ __device__ __forceinline__ void pix_coord(const IgemmArgs& a, const PhaseArgs& P
 
 // CPS = channels per K stage: 16 (chunked order, channel count a multiple of 16) or 4 (image-like tensors of 3-4 channels,
 // K order (tap, channel) with the channels padded to 4: one stage = 4 filter taps x 4 channels, up to 7x7 taps).
-template <int MODE, int BM, int BP, int CPS = 16>
+template <int MODE, int BM, int BP, int CPS, typename TA>
 __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
+    constexpr unsigned ES = sizeof(TA);
     constexpr int WM = (BM == 128 || (BM == 64 && BP == 64)) ? 2 : 1;
     constexpr int WP = 4 / WM;
     constexpr int WMT = BM / WM, WPT = BP / WP;
@@ -428,7 +458,7 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
     const int ph_nS = P.nS, ph_Ws = P.Ws, ph_fy = P.fy, ph_fx = P.fx;
     const int T = P.nR * ph_nS;
     const int HsWs = P.Hs * ph_Ws;
-    const int HgWg4 = a.Hg * a.Wg * 4;
+    const int HgWg4 = a.Hg * a.Wg * (int)ES;     // bytes of one channel plane
     const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(P.A, (unsigned)a.M * (unsigned)Kp * 4u);
 
@@ -454,13 +484,13 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
             const bool live = pvalid && t < T;
             const unsigned y = axis_entry<MODE>(py, py + a.pad, true, r, a.Hg, a.sl, a.pad);
             const unsigned x = axis_entry<MODE>(px, px + a.pad, true, sx, a.Wg, a.sl, a.pad);
-            offT[0][t][pl] = (live && y != 0xffffffffu && x != 0xffffffffu) ? (vbase + y * (unsigned)a.Wg + x) * 4u : OOB;
+            offT[0][t][pl] = (live && y != 0xffffffffu && x != 0xffffffffu) ? (vbase + y * (unsigned)a.Wg + x) * ES : OOB;
             if (MIR) {
                 const unsigned yb = axis_entry<MODE>(py, myr, myr >= 0, r, a.Hg, a.sl, a.pad);
                 const unsigned xb = axis_entry<MODE>(px, mxr, mxr >= 0, sx, a.Wg, a.sl, a.pad);
-                offT[NCOMB > 1 ? 1 : 0][t][pl] = (live && y != 0xffffffffu && xb != 0xffffffffu) ? (vbase + y * (unsigned)a.Wg + xb) * 4u : OOB;
-                offT[NCOMB > 1 ? 2 : 0][t][pl] = (live && yb != 0xffffffffu && x != 0xffffffffu) ? (vbase + yb * (unsigned)a.Wg + x) * 4u : OOB;
-                offT[NCOMB > 1 ? 3 : 0][t][pl] = (live && yb != 0xffffffffu && xb != 0xffffffffu) ? (vbase + yb * (unsigned)a.Wg + xb) * 4u : OOB;
+                offT[NCOMB > 1 ? 1 : 0][t][pl] = (live && y != 0xffffffffu && xb != 0xffffffffu) ? (vbase + y * (unsigned)a.Wg + xb) * ES : OOB;
+                offT[NCOMB > 1 ? 2 : 0][t][pl] = (live && yb != 0xffffffffu && x != 0xffffffffu) ? (vbase + yb * (unsigned)a.Wg + x) * ES : OOB;
+                offT[NCOMB > 1 ? 3 : 0][t][pl] = (live && yb != 0xffffffffu && xb != 0xffffffffu) ? (vbase + yb * (unsigned)a.Wg + xb) * ES : OOB;
             }
         }
         if (tid < BM) biasS[tid] = (a.bias != nullptr && m0 + tid < a.M) ? a.bias[m0 + tid] : 0.f;
@@ -531,15 +561,15 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
         constexpr int NM = decltype(nm_tag)::value;
         if constexpr (CPS == 4) {
             const unsigned v = (i & 3) < a.Cg ? (i < 4 ? vo[0] : vo_b) : OOB;   // 3-channel tensors: the pad channel reads 0
-            breg[i] = ld_b32(rX, v, (unsigned)((i & 3) * HgWg4));
+            breg[i] = ldx<TA>(rX, v, (unsigned)((i & 3) * HgWg4));
             return;
         }
         const unsigned so = (unsigned)((vo_c + ksub * KPT + i) * HgWg4);
-        breg[i] = ld_b32(rX, vo[0], so);
-        if constexpr (NM >= 1) bmir[0][i] = ld_b32(rX, vo[NCOMB > 1 ? 1 : 0], so);
+        breg[i] = ldx<TA>(rX, vo[0], so);
+        if constexpr (NM >= 1) bmir[0][i] = ldx<TA>(rX, vo[NCOMB > 1 ? 1 : 0], so);
         if constexpr (NM >= 3) {
-            bmir[1][i] = ld_b32(rX, vo[NCOMB > 1 ? 2 : 0], so);
-            bmir[2][i] = ld_b32(rX, vo[NCOMB > 1 ? 3 : 0], so);
+            bmir[1][i] = ldx<TA>(rX, vo[NCOMB > 1 ? 2 : 0], so);
+            bmir[2][i] = ldx<TA>(rX, vo[NCOMB > 1 ? 3 : 0], so);
         }
     };
     auto store_a = [&](int buf, int j) {
@@ -681,7 +711,7 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
             }
             continue;
         }
-        float* Yp = a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
+        TA* Yp = (TA*)a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -692,7 +722,7 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int m = m0 + ml + e;
-                    if (m < a.M) Yp[(size_t)m * YhYw] = act_apply(acc[i][j][rq * 4 + e] + bb[e], a.act, a.slope);
+                    if (m < a.M) st1(Yp + (size_t)m * YhYw, act_apply(acc[i][j][rq * 4 + e] + bb[e], a.act, a.slope));
                 }
             }
         }
@@ -700,8 +730,9 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
 }
 
 struct WgradArgs {
-    const float* dY;  // [N][M][Ho][Wo]
-    const float* X;   // [N][Cg][Hg][Wg]
+    const void* dY;   // [N][M][Ho][Wo], storage type TA
+    const void* X;    // [N][Cg][Hg][Wg], storage type TA
+    int dtype;
     float* Wp;        // [splits][M][Kp]   (k = tap*Cgp + c)
     int M, Kp, N, Cg, Cgp, Hg, Wg, Ho, Wo;
     int sl, pad, S;
@@ -741,8 +772,9 @@ static constexpr unsigned SM_INV = 0x40000000u;  // row/column marker: any sum w
 // 64 pixels per workgroup; the 4 waves split the channels of the gathered tensor and are summed through
 // LDS.  Loop order channel -> tap keeps one channel's (R x S) neighbourhood L1-resident across its taps;
 // the separable gather offsets (row part, column part) are tabulated per pixel in LDS once per workgroup.
-template <int MODE>
+template <int MODE, typename TA>
 __global__ void __launch_bounds__(256) smallm_conv_kernel(IgemmArgs a) {
+    constexpr unsigned ES = sizeof(TA);
     __shared__ unsigned rowoff[12][64], coloff[12][64];
     __shared__ float red[3][4][64];
     const PhaseArgs& P = a.ph[blockIdx.y];
@@ -781,7 +813,7 @@ __global__ void __launch_bounds__(256) smallm_conv_kernel(IgemmArgs a) {
                 ok = (unsigned)iy < (unsigned)a.Hg;
             }
         }
-        rowoff[i][pl] = ok ? (unsigned)(iy * a.Wg) * 4u : SM_INV;
+        rowoff[i][pl] = ok ? (unsigned)(iy * a.Wg) * ES : SM_INV;
     }
     for (int j = wave; j < P.nS; j += 4) {
         const int s = P.s0 + j * a.tstep;
@@ -800,10 +832,10 @@ __global__ void __launch_bounds__(256) smallm_conv_kernel(IgemmArgs a) {
                 ok = (unsigned)ix < (unsigned)a.Wg;
             }
         }
-        coloff[j][pl] = ok ? (unsigned)ix * 4u : SM_INV;
+        coloff[j][pl] = ok ? (unsigned)ix * ES : SM_INV;
     }
     __syncthreads();
-    const unsigned vbase = pvalid ? (unsigned)(n * a.Cg * HgWg) * 4u : SM_INV;
+    const unsigned vbase = pvalid ? (unsigned)(n * a.Cg * HgWg) * ES : SM_INV;
     const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
     const float4* __restrict__ At = reinterpret_cast<const float4*>(P.A);  // [Kp][4]
     const int cpw = (a.Cg + 3) >> 2;
@@ -811,13 +843,13 @@ __global__ void __launch_bounds__(256) smallm_conv_kernel(IgemmArgs a) {
     const int c_hi = (c_lo + cpw < a.Cg) ? c_lo + cpw : a.Cg;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (int c = c_lo; c < c_hi; ++c) {
-        const unsigned soff = (unsigned)(c * HgWg) * 4u;
+        const unsigned soff = (unsigned)(c * HgWg) * ES;
         for (int ri = 0; ri < P.nR; ++ri) {
             const unsigned ro = vbase + rowoff[ri][pl];
             const float4* __restrict__ wrow = At + (ri * P.nS) * a.Cgp + c;
 #pragma unroll 4
             for (int sj = 0; sj < P.nS; ++sj) {
-                const float x = ld_b32(rX, ro + coloff[sj][pl], soff);
+                const float x = ldx<TA>(rX, ro + coloff[sj][pl], soff);
                 const float4 w = wrow[sj * a.Cgp];  // wave-uniform address -> scalar load
                 acc0 += x * w.x; acc1 += x * w.y; acc2 += x * w.z; acc3 += x * w.w;
             }
@@ -831,13 +863,13 @@ __global__ void __launch_bounds__(256) smallm_conv_kernel(IgemmArgs a) {
     const float out[4] = {acc0 + (red[0][0][pl] + red[1][0][pl]) + red[2][0][pl], acc1 + (red[0][1][pl] + red[1][1][pl]) + red[2][1][pl],
                           acc2 + (red[0][2][pl] + red[1][2][pl]) + red[2][2][pl], acc3 + (red[0][3][pl] + red[1][3][pl]) + red[2][3][pl]};
     const int YhYw = a.Yh * a.Yw;
-    float* Yp = a.Y + (size_t)n * a.M * YhYw + py * a.Yw + px;
+    TA* Yp = (TA*)a.Y + (size_t)n * a.M * YhYw + py * a.Yw + px;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         if (m < a.M) {
             float v = out[m];
             if (a.bias) v += a.bias[m];
-            Yp[(size_t)m * YhYw] = act_apply(v, a.act, a.slope);
+            st1(Yp + (size_t)m * YhYw, act_apply(v, a.act, a.slope));
         }
     }
 }
@@ -849,8 +881,9 @@ __global__ void __launch_bounds__(256) smallm_conv_kernel(IgemmArgs a) {
 // from the L1/TA bound of smallm_conv_kernel towards the vector-ALU bound.  Weights come in through the scalar cache
 // ([c][sj][8][4], wave-uniform addresses, no branches).  The 4 waves split the channels and are summed through LDS.
 // Needs unit pixel stride along the column in the gathered tensor: forward with stride 1, or any data-gradient phase.
-template <int MODE, int NR, int MO>
+template <int MODE, int NR, int MO, typename TA>
 __global__ void __launch_bounds__(256) smallm_strip_kernel(IgemmArgs a) {
+    constexpr unsigned ES = sizeof(TA);
     constexpr int PX = 8, NW = PX + NR - 1;
     constexpr bool BWD = MODE == MODE_BWD;
     __shared__ unsigned coltab[12][64];
@@ -891,7 +924,7 @@ __global__ void __launch_bounds__(256) smallm_strip_kernel(IgemmArgs a) {
                 ok = ok && (unsigned)ix < (unsigned)a.Wg;
             }
         }
-        coltab[j][pl] = ok ? (unsigned)ix * 4u : SM_INV;
+        coltab[j][pl] = ok ? (unsigned)ix * ES : SM_INV;
     }
     // row part (+ image base): window position k holds input row y0 + k; pixel j and row tap ri meet at k = j + ri
     // (forward) or k = j - ri + NR - 1 (data gradient: source row = sub-grid row + q0 - ri)
@@ -906,7 +939,7 @@ __global__ void __launch_bounds__(256) smallm_strip_kernel(IgemmArgs a) {
                 iy = iy >= a.Hg ? 2 * (a.Hg - 1) - iy : iy;
             }
             const bool ok = (unsigned)iy < (unsigned)a.Hg;   // (reflect: strips past the last row are never stored)
-            rowoff[k] = ok ? (unsigned)(n * a.Cg * HgWg + iy * a.Wg) * 4u : SM_INV;
+            rowoff[k] = ok ? (unsigned)(n * a.Cg * HgWg + iy * a.Wg) * ES : SM_INV;
         }
     }
     __syncthreads();
@@ -928,9 +961,9 @@ __global__ void __launch_bounds__(256) smallm_strip_kernel(IgemmArgs a) {
     const float4* __restrict__ Ws4 = reinterpret_cast<const float4*>(P.As);   // [c][sj][8] float4
     auto issue = [&](float (&buf)[NW], float4 (&wb)[NR], int c, int sj) {
         const unsigned co = coltab[sj][pl];
-        const unsigned so = (unsigned)(c * HgWg) * 4u;
+        const unsigned so = (unsigned)(c * HgWg) * ES;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) buf[k] = ld_b32(rX, rowoff[k] + co, so);
+        for (int k = 0; k < NW; ++k) buf[k] = ldx<TA>(rX, rowoff[k] + co, so);
         const float4* __restrict__ wr = Ws4 + (size_t)(c * nS + sj) * 8;   // wave-uniform -> scalar loads, no branches
 #pragma unroll
         for (int ri = 0; ri < NR; ++ri) wb[ri] = wr[ri];
@@ -988,17 +1021,17 @@ __global__ void __launch_bounds__(256) smallm_strip_kernel(IgemmArgs a) {
     for (int j = 0; j < PX; ++j) {
         if (sy0 + j >= P.Hs) break;
         const int py = (sy0 + j) * a.ostep + P.fy;
-        float* Yp = (a.ksplit > 1 ? a.Ypart + (size_t)blockIdx.z * a.N * a.M * YhYw : a.Y) + (size_t)n * a.M * YhYw + py * a.Yw + px;
+        const size_t yo = (size_t)n * a.M * YhYw + py * a.Yw + px;
 #pragma unroll
         for (int m = 0; m < MO; ++m) {
             if (m < a.M) {
                 float v = acc[m][j] + (red[0][m * PX + j][pl] + red[1][m * PX + j][pl]) + red[2][m * PX + j][pl];
-                if (a.ksplit > 1) {   // raw partial sum; bias / activation happen in splitk_reduce_kernel
-                    Yp[(size_t)m * YhYw] = v;
+                if (a.ksplit > 1) {   // raw fp32 partial sum; bias / activation happen in splitk_reduce_kernel
+                    a.Ypart[(size_t)blockIdx.z * a.N * a.M * YhYw + yo + (size_t)m * YhYw] = v;
                     continue;
                 }
                 if (a.bias) v += a.bias[m];
-                Yp[(size_t)m * YhYw] = act_apply(v, a.act, a.slope);
+                st1((TA*)a.Y + yo + (size_t)m * YhYw, act_apply(v, a.act, a.slope));
             }
         }
     }
@@ -1006,8 +1039,9 @@ __global__ void __launch_bounds__(256) smallm_strip_kernel(IgemmArgs a) {
 
 // Variant for phases with few taps (<= 9, e.g. the stride phases of 4x4/s2 and 11x11/s4 data gradients): one
 // thread per pixel, tap-outer loop; no tables, no cross-wave reduction.
-template <int MODE>
+template <int MODE, typename TA>
 __global__ void __launch_bounds__(256) smallm_conv_fewtaps_kernel(IgemmArgs a) {
+    constexpr unsigned ES = sizeof(TA);
     const PhaseArgs& P = a.ph[blockIdx.y];
     const int Ptot = P.Ptot;
     if ((int)(blockIdx.x * 256) >= Ptot) return;
@@ -1031,13 +1065,13 @@ __global__ void __launch_bounds__(256) smallm_conv_fewtaps_kernel(IgemmArgs a) {
         for (int sj = 0; sj < P.nS; ++sj) {
             int off;
             const bool ok = tap_offset<MODE>(g, py, px, P.r0 + ri * a.tstep, P.s0 + sj * a.tstep, off) && pvalid;
-            const unsigned voff = ok ? (unsigned)(vbase + off) * 4u : OOB;
+            const unsigned voff = ok ? (unsigned)(vbase + off) * ES : OOB;
             const int kbase = (ri * P.nS + sj) * a.Cgp;
             int c = 0;
             for (; c + 8 <= a.Cg; c += 8) {
                 float x[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = ld_b32(rX, voff, (unsigned)((c + u) * HgWg) * 4u);
+                for (int u = 0; u < 8; ++u) x[u] = ldx<TA>(rX, voff, (unsigned)((c + u) * HgWg) * ES);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const float4 w = At[kbase + c + u];  // wave-uniform address -> scalar load
@@ -1045,7 +1079,7 @@ __global__ void __launch_bounds__(256) smallm_conv_fewtaps_kernel(IgemmArgs a) {
                 }
             }
             for (; c < a.Cg; ++c) {
-                const float x = ld_b32(rX, voff, (unsigned)(c * HgWg) * 4u);
+                const float x = ldx<TA>(rX, voff, (unsigned)(c * HgWg) * ES);
                 const float4 w = At[kbase + c];
                 acc0 += x * w.x; acc1 += x * w.y; acc2 += x * w.z; acc3 += x * w.w;
             }
@@ -1053,14 +1087,14 @@ __global__ void __launch_bounds__(256) smallm_conv_fewtaps_kernel(IgemmArgs a) {
     }
     if (!pvalid) return;
     const int YhYw = a.Yh * a.Yw;
-    float* Yp = a.Y + (size_t)n * a.M * YhYw + py * a.Yw + px;
+    TA* Yp = (TA*)a.Y + (size_t)n * a.M * YhYw + py * a.Yw + px;
     const float out[4] = {acc0, acc1, acc2, acc3};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         if (m < a.M) {
             float v = out[m];
             if (a.bias) v += a.bias[m];
-            Yp[(size_t)m * YhYw] = act_apply(v, a.act, a.slope);
+            st1(Yp + (size_t)m * YhYw, act_apply(v, a.act, a.slope));
         }
     }
 }
@@ -1068,8 +1102,9 @@ __global__ void __launch_bounds__(256) smallm_conv_fewtaps_kernel(IgemmArgs a) {
 // Weight gradient for M <= 4: Wp[split][m][kb..kb+15] = sum_pix dY[m][pix] * G(k; pix).  One workgroup per
 // 16-column slab of K (one tap, 16 channels: needs Cgp % 16 == 0) and pixel split; every thread keeps the
 // 4x16 partial sums of its pixels in registers and the workgroup reduces them once at the end.
-template <int MODE>
+template <int MODE, typename TA>
 __global__ void __launch_bounds__(256) smallm_wgrad_kernel(WgradArgs a) {
+    constexpr unsigned ES = sizeof(TA);
     __shared__ float red[4][64];
     const int tid = threadIdx.x;
     const int kb = blockIdx.x * 16;
@@ -1093,13 +1128,13 @@ __global__ void __launch_bounds__(256) smallm_wgrad_kernel(WgradArgs a) {
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
         int off;
         const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off);
-        const unsigned voff = ok ? (unsigned)(n * a.Cg * HgWg + off) * 4u : OOB;
-        const unsigned yoff = (unsigned)(n * a.M * HoWo + rem) * 4u;
+        const unsigned voff = ok ? (unsigned)(n * a.Cg * HgWg + off) * ES : OOB;
+        const unsigned yoff = (unsigned)(n * a.M * HoWo + rem) * ES;
         float dy[4], x[16];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) dy[m] = ld_b32(rY, m < a.M ? yoff : OOB, (unsigned)(m * HoWo) * 4u);
+        for (int m = 0; m < 4; ++m) dy[m] = ldx<TA>(rY, m < a.M ? yoff : OOB, (unsigned)(m * HoWo) * ES);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) x[j] = ld_b32(rX, (c0 + j < a.Cg) ? voff : OOB, (unsigned)((c0 + j) * HgWg) * 4u);
+        for (int j = 0; j < 16; ++j) x[j] = ldx<TA>(rX, (c0 + j < a.Cg) ? voff : OOB, (unsigned)((c0 + j) * HgWg) * ES);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1122,7 +1157,8 @@ __global__ void __launch_bounds__(256) smallm_wgrad_kernel(WgradArgs a) {
 }
 
 // y = act( sum_s part[s] + bias[channel] ) over the split-K partial sums
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ y, const float* __restrict__ bias,
+template <typename TA>
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, TA* __restrict__ y, const float* __restrict__ bias,
                                      int ks, size_t n, int M, int HW, int act, float slope) {
     const size_t n4 = (n & 3) ? 0 : (n >> 2);  // 16-byte path only when every split's base stays aligned
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1139,13 +1175,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
             if (bias) o[u] += bias[(e / HW) % M];
             o[u] = act_apply(o[u], act, slope);
         }
-        reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        st4(y + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
     }
     for (size_t e = (n4 << 2) + blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += stride) {
         float acc = 0.f;
         for (int s = 0; s < ks; ++s) acc += part[(size_t)s * n + e];
         if (bias) acc += bias[(e / HW) % M];
-        y[e] = act_apply(acc, act, slope);
+        st1(y + e, act_apply(acc, act, slope));
     }
 }
 
@@ -1248,12 +1284,13 @@ __global__ void repack_bwd_multi_kernel(PackBwdArgs a) {
 
 // fold the gradient of a reflection-padded tensor back onto the unpadded tensor
 // grid = (row groups, planes): one thread = 4 consecutive pixels of one row, plane-local 32-bit index math
-__global__ void reflect_fold_kernel(const float* __restrict__ t, float* __restrict__ dx, int NC, int H, int W,
+template <typename TA>
+__global__ void reflect_fold_kernel(const TA* __restrict__ t, TA* __restrict__ dx, int NC, int H, int W,
                                     int pad) {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int W4 = (W + 3) >> 2;
-    const float* tp = t + (size_t)blockIdx.y * Hp * Wp;
-    float* dp = dx + (size_t)blockIdx.y * H * W;
+    const TA* tp = t + (size_t)blockIdx.y * Hp * Wp;
+    TA* dp = dx + (size_t)blockIdx.y * H * W;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W4; i += gridDim.x * blockDim.x) {
         const int y = i / W4, x0 = (i - y * W4) * 4;
         int ys[3], ny = 0;
@@ -1262,21 +1299,21 @@ __global__ void reflect_fold_kernel(const float* __restrict__ t, float* __restri
         if (y >= H - 1 - pad && y <= H - 2) ys[ny++] = pad + 2 * (H - 1) - y;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int a = 0; a < ny; ++a) {
-            const float* row = tp + ys[a] * Wp;
+            const TA* row = tp + ys[a] * Wp;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int x = x0 + j;
                 if (x >= W) continue;
-                float v = row[x + pad];
-                if (x >= 1 && x <= pad) v += row[pad - x];
-                if (x >= W - 1 - pad && x <= W - 2) v += row[pad + 2 * (W - 1) - x];
+                float v = ld1(row + x + pad);
+                if (x >= 1 && x <= pad) v += ld1(row + pad - x);
+                if (x >= W - 1 - pad && x <= W - 2) v += ld1(row + pad + 2 * (W - 1) - x);
                 acc[j] += v;
             }
         }
         if ((W & 3) == 0) {
-            *reinterpret_cast<float4*>(dp + y * W + x0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            st4(dp + y * W + x0, make_float4(acc[0], acc[1], acc[2], acc[3]));
         } else {
-            for (int j = 0; j < 4 && x0 + j < W; ++j) dp[y * W + x0 + j] = acc[j];
+            for (int j = 0; j < 4 && x0 + j < W; ++j) st1(dp + y * W + x0 + j, acc[j]);
         }
     }
 }
@@ -1291,8 +1328,9 @@ __global__ void reflect_fold_kernel(const float* __restrict__ t, float* __restri
 // VECA: dY planes are a multiple of 4 pixels, so a thread fetches 4 consecutive pixels with one 16-byte load.
 // KMODE: 0 = generic (Cgp % 8 == 0), 1 = SMALLC (per-thread tap), 2 = ONETAP (Cgp % 128 == 0: the whole 128-column
 // tile lies inside one filter tap -> one spatial offset per stage, straight-line code, interleaved schedule)
-template <int MODE, int BM, int KMODE, bool VECA>
+template <int MODE, int BM, int KMODE, bool VECA, typename TA>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+    constexpr unsigned ES = sizeof(TA);
     constexpr bool SMALLC = KMODE == 1;
     constexpr bool ONETAP = KMODE == 2;
     constexpr int BN = 128;
@@ -1338,13 +1376,13 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
             unsigned vb = OOB;
             {
                 const int n = pg / HoWo;
-                const unsigned vv = (unsigned)((n * a.M + m0) * HoWo + (pg - n * HoWo)) * 4u;
+                const unsigned vv = (unsigned)((n * a.M + m0) * HoWo + (pg - n * HoWo)) * ES;
                 vb = (pg < a.Ptot) ? vv : OOB;
             }
 #pragma unroll
             for (int j = 0; j < AV; ++j) {
                 const int row = (tid >> 3) + 32 * j;
-                const float4 v = ld_b128(rY, ((vb != OOB) & (m0 + row < a.M)) ? vb + (unsigned)(row * HoWo) * 4u : OOB);
+                const float4 v = ldx4<TA>(rY, ((vb != OOB) & (m0 + row < a.M)) ? vb + (unsigned)(row * HoWo) * ES : OOB, 0u);
                 areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
             }
         }
@@ -1357,10 +1395,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
         const int oy = rem / a.Wo;
         const int ox = rem - oy * a.Wo;
         if (!VECA) {
-            const unsigned vb = pvalid ? (unsigned)((n * a.M + m0 + rg) * HoWo + rem) * 4u : OOB;
+            const unsigned vb = pvalid ? (unsigned)((n * a.M + m0 + rg) * HoWo + rem) * ES : OOB;
 #pragma unroll
             for (int i = 0; i < AR; ++i)
-                areg[i] = ld_b32(rY, (pvalid & (m0 + rg + 8 * i < a.M)) ? vb : OOB, (unsigned)(8 * i * HoWo) * 4u);
+                areg[i] = ldx<TA>(rY, (pvalid & (m0 + rg + 8 * i < a.M)) ? vb : OOB, (unsigned)(8 * i * HoWo) * ES);
         }
         const int vbase = n * a.Cg * HgWg;
         if (ONETAP) {
@@ -1368,10 +1406,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
             const int s = tap_b - r * a.S;
             int off;
             const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off) & pvalid;
-            const unsigned voff = ok ? (unsigned)(vbase + off + rg * HgWg) * 4u : OOB;
+            const unsigned voff = ok ? (unsigned)(vbase + off + rg * HgWg) * ES : OOB;
 #pragma unroll
             for (int i = 0; i < BR; ++i)
-                breg[i] = ld_b32(rX, (c_b + 8 * i + rg < a.Cg) ? voff : OOB, (unsigned)((c_b + 8 * i) * HgWg) * 4u);
+                breg[i] = ldx<TA>(rX, (c_b + 8 * i + rg < a.Cg) ? voff : OOB, (unsigned)((c_b + 8 * i) * HgWg) * ES);
         } else if (!SMALLC) {
             int tap = tap_b, c = c_b;
             unsigned voff = OOB;
@@ -1382,10 +1420,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
                     const int s = tap - r * a.S;
                     int off;
                     const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off) & pvalid;
-                    voff = ok ? (unsigned)(vbase + off + rg * HgWg) * 4u : OOB;
+                    voff = ok ? (unsigned)(vbase + off + rg * HgWg) * ES : OOB;
                 }
                 const bool okc = (c + rg < a.Cg) & (kb + 8 * i + rg < a.Kp);
-                breg[i] = ld_b32(rX, okc ? voff : OOB, (unsigned)(c * HgWg) * 4u);
+                breg[i] = ldx<TA>(rX, okc ? voff : OOB, (unsigned)(c * HgWg) * ES);
                 c += 8;
                 if (c >= a.Cgp) {
                     c -= a.Cgp;
@@ -1401,7 +1439,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
                 const int s = tap - r * a.S;
                 int off;
                 const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off) && pvalid && kcol < a.Kp && c < a.Cg;
-                breg[i] = ld_b32(rX, ok ? (unsigned)(vbase + c * HgWg + off) * 4u : OOB, 0u);
+                breg[i] = ldx<TA>(rX, ok ? (unsigned)(vbase + c * HgWg + off) * ES : OOB, 0u);
             }
         }
     };
@@ -1511,8 +1549,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 // strip; for each filter column the 8 + NT - 1 input values are loaded once and reused by all NT row taps:
 // M * NT * 8 fused multiply-adds per 8 + NT - 1 gathers.  Every thread keeps the NT x NT x M partial sums of ITS pixels in
 // registers; the workgroup reduces them once at the end (wave shuffles, then LDS) and writes Wp[split][m][tap * Cgp + c].
-template <int MODE, int NT>
+template <int MODE, int NT, typename TA>
 __global__ void __launch_bounds__(256) smallm_wgrad_strip_kernel(WgradArgs a) {
+    constexpr unsigned ES = sizeof(TA);
     constexpr int PX = 8, NW = PX + NT - 1, MO = 3;
     constexpr int SG = NT > 4 ? 4 : NT;     // filter columns per workgroup (blockIdx.z picks the group): keeps the
                                             // accumulators at SG x NT x 3 registers so that 2-3 waves fit a SIMD
@@ -1551,7 +1590,7 @@ __global__ void __launch_bounds__(256) smallm_wgrad_strip_kernel(WgradArgs a) {
                 iy = iy < 0 ? -iy : iy;
                 iy = iy >= a.Hg ? 2 * (a.Hg - 1) - iy : iy;
             }
-            rowoff[k] = ((unsigned)iy < (unsigned)a.Hg) ? (unsigned)((n * a.Cg + c) * HgWg + iy * a.Wg) * 4u : SM_INV;
+            rowoff[k] = ((unsigned)iy < (unsigned)a.Hg) ? (unsigned)((n * a.Cg + c) * HgWg + iy * a.Wg) * ES : SM_INV;
         }
         auto col_off = [&](int sj) {
             int ix = ox - a.pad + s_lo + sj;
@@ -1559,28 +1598,28 @@ __global__ void __launch_bounds__(256) smallm_wgrad_strip_kernel(WgradArgs a) {
                 ix = ix < 0 ? -ix : ix;
                 ix = ix >= a.Wg ? 2 * (a.Wg - 1) - ix : ix;
             }
-            return (s_lo + sj < a.S && (unsigned)ix < (unsigned)a.Wg) ? (unsigned)ix * 4u : SM_INV;
+            return (s_lo + sj < a.S && (unsigned)ix < (unsigned)a.Wg) ? (unsigned)ix * ES : SM_INV;
         };
         float xin[2][NW];
         {
             const unsigned co = col_off(0);
 #pragma unroll
-            for (int k = 0; k < NW; ++k) xin[0][k] = ld_b32(rX, rowoff[k] + co, 0u);
+            for (int k = 0; k < NW; ++k) xin[0][k] = ldx<TA>(rX, rowoff[k] + co, 0u);
         }
         // dY of the strip (rows past the end: 0)
         float dyv[MO][PX];
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
-            const unsigned vo = (oy0 + j < a.Ho) ? (unsigned)(n * a.M * HoWo + (oy0 + j) * a.Wo + ox) * 4u : OOB;
+            const unsigned vo = (oy0 + j < a.Ho) ? (unsigned)(n * a.M * HoWo + (oy0 + j) * a.Wo + ox) * ES : OOB;
 #pragma unroll
-            for (int m = 0; m < MO; ++m) dyv[m][j] = m < a.M ? ld_b32(rY, vo, (unsigned)(m * HoWo) * 4u) : 0.f;
+            for (int m = 0; m < MO; ++m) dyv[m][j] = m < a.M ? ldx<TA>(rY, vo, (unsigned)(m * HoWo) * ES) : 0.f;
         }
 #pragma unroll
         for (int sj = 0; sj < SG; ++sj) {
             if (sj + 1 < SG) {   // next filter column in flight while this one is consumed
                 const unsigned co = col_off(sj + 1);
 #pragma unroll
-                for (int k = 0; k < NW; ++k) xin[(sj + 1) & 1][k] = ld_b32(rX, rowoff[k] + co, 0u);
+                for (int k = 0; k < NW; ++k) xin[(sj + 1) & 1][k] = ldx<TA>(rX, rowoff[k] + co, 0u);
             }
 #pragma unroll
             for (int ri = 0; ri < NT; ++ri)
@@ -1625,8 +1664,9 @@ __global__ void __launch_bounds__(256) smallm_wgrad_strip_kernel(WgradArgs a) {
 //   stage t: group 0/1 of the MFMA chain + LDS writes of stage t+1 (loaded one stage ago)
 //            group 2/3 + global loads of stage t+2; the barrier sits between group 2 and 3, the operands of
 //            stage t+1's first group are read under group 3
-template <int MODE, int BM, bool VECA, int NT>
+template <int MODE, int BM, bool VECA, int NT, typename TA>
 __global__ void __launch_bounds__(256) wgrad2_kernel(WgradArgs a) {
+    constexpr unsigned ES = sizeof(TA);
     constexpr int BN = 128;
     constexpr int WM = (BM == 128) ? 2 : 1;
     constexpr int WN = 4 / WM;
@@ -1653,7 +1693,7 @@ __global__ void __launch_bounds__(256) wgrad2_kernel(WgradArgs a) {
     const int m0 = mt * BM, kb = kt * BN;
     const int split = blockIdx.y;
     const int HoWo = a.Ho * a.Wo, HgWg = a.Hg * a.Wg;
-    const int HoWo4 = HoWo * 4, HgWg4 = HgWg * 4;
+    const int HoWo4 = HoWo * (int)ES, HgWg4 = HgWg * (int)ES;     // bytes of one plane
     const Geom g{a.Hg, a.Wg, a.sl, a.pad};
     const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.dY, a.dy_bytes);
@@ -1676,14 +1716,14 @@ __global__ void __launch_bounds__(256) wgrad2_kernel(WgradArgs a) {
         const int rem = pg - n * HoWo;
         const int oy = rem / a.Wo;
         const int ox = rem - oy * a.Wo;
-        yoffT[slot][pl] = valid ? (unsigned)((n * a.M + m0) * HoWo + rem) * 4u : OOB;
+        yoffT[slot][pl] = valid ? (unsigned)((n * a.M + m0) * HoWo + rem) * ES : OOB;
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             const int tap = tap_b + ti;
             const int r = tap / a.S, sx = tap - r * a.S;
             int off;
             const bool ok = tap_offset<MODE>(g, oy, ox, r, sx, off) & valid & (tap < ntaps);
-            xoffT[slot][ti][pl] = ok ? (unsigned)(n * a.Cg * HgWg + off) * 4u : OOB;
+            xoffT[slot][ti][pl] = ok ? (unsigned)(n * a.Cg * HgWg + off) * ES : OOB;
         }
     };
 
@@ -1716,15 +1756,15 @@ __global__ void __launch_bounds__(256) wgrad2_kernel(WgradArgs a) {
     };
     auto load_a = [&](int j) {
         if (VECA) {
-            const float4 v = ld_b128s(rY, yo | yflag[j], (unsigned)(32 * j * HoWo4));
+            const float4 v = ldx4<TA>(rY, yo | yflag[j], (unsigned)(32 * j * HoWo4));
             areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
         } else {
-            areg[j] = ld_b32(rY, yo | yflag[j], (unsigned)(8 * j * HoWo4));
+            areg[j] = ldx<TA>(rY, yo | yflag[j], (unsigned)(8 * j * HoWo4));
         }
     };
     auto load_b = [&](int i) {
         constexpr int PER = BR / NT;   // K-columns (i) per tap
-        breg[i] = ld_b32(rX, xo[i / PER], (unsigned)((c_b + 8 * (i % PER)) * HgWg4));
+        breg[i] = ldx<TA>(rX, xo[i / PER], (unsigned)((c_b + 8 * (i % PER)) * HgWg4));
     };
     auto store_a = [&](int buf, int j) {
         if (VECA) {
@@ -1897,6 +1937,26 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // host side
 // ------------------------------------------------------------------------------------
 static inline int round4(int v) { return (v + 3) & ~3; }
+static inline size_t esz(const pcgan_conv_desc* d) { return d->dtype == PCGAN_BF16 ? 2 : 4; }   // bytes per activation element
+
+// launch KERNEL<template arguments..., TA> with TA = the activation storage type `dt` (256 threads, stream `st`)
+#define LAUNCH_TA(dt, KERNEL, GRID, ARG, ...)                                                                   \
+    do {                                                                                                        \
+        if ((dt) == PCGAN_BF16) hipLaunchKernelGGL((KERNEL<__VA_ARGS__, bf16>), GRID, dim3(256), 0, st, ARG);    \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, float>), GRID, dim3(256), 0, st, ARG);                      \
+    } while (0)
+
+static int launch_splitk_reduce(int dtype, hipStream_t st, const float* part, void* y, const float* bias, int ks, size_t out_elems, int M,
+                                int HW, int act, float slope) {
+    size_t b = (out_elems / 4 + 255) / 256;
+    b = b > 4096 ? 4096 : (b < 1 ? 1 : b);
+    if (dtype == PCGAN_BF16)
+        hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3((unsigned)b), dim3(256), 0, st, part, (bf16*)y, bias, ks, out_elems, M, HW, act, slope);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, part, (float*)y, bias, ks, out_elems, M, HW, act, slope);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
 
 static int check_desc(const pcgan_conv_desc* d) {
     PCGAN_CHECK(d != nullptr, "conv: null descriptor");
@@ -1904,6 +1964,7 @@ static int check_desc(const pcgan_conv_desc* d) {
                 "conv: non-positive dimension");
     PCGAN_CHECK(ilog2_exact(d->stride) >= 0 && d->stride <= 4, "conv: stride %d unsupported (1,2,4)", d->stride);
     PCGAN_CHECK(d->pad_mode == 0 || d->pad_mode == 1, "conv: pad_mode %d", d->pad_mode);
+    PCGAN_CHECK(d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16, "conv: dtype %d (PCGAN_F32 / PCGAN_BF16)", d->dtype);
     const int P = (d->H + 2 * d->pad - d->R) / d->stride + 1, Q = (d->W + 2 * d->pad - d->S) / d->stride + 1;
     PCGAN_CHECK(P == d->P && Q == d->Q, "conv: output dims %dx%d do not match geometry %dx%d", d->P, d->Q, P, Q);
     if (d->pad_mode == 1)
@@ -2003,18 +2064,12 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
                 a.ksplit = ks;
                 a.Ypart = part_ws;
                 const dim3 gs((unsigned)((maxstrips + 63) / 64), (unsigned)a.nphase, (unsigned)ks);
-#define LS(NRV) do { if (a.M <= 3) hipLaunchKernelGGL((smallm_strip_kernel<SMODE, NRV, 3>), gs, dim3(256), 0, st, a); \
-                     else hipLaunchKernelGGL((smallm_strip_kernel<SMODE, NRV, 4>), gs, dim3(256), 0, st, a); } while (0)
+#define LS(NRV) do { if (a.M <= 3) LAUNCH_TA(a.dtype, smallm_strip_kernel, gs, a, SMODE, NRV, 3); \
+                     else LAUNCH_TA(a.dtype, smallm_strip_kernel, gs, a, SMODE, NRV, 4); } while (0)
                 if (maxR <= 4) LS(4); else LS(7);
 #undef LS
                 PCGAN_LAUNCH_CHECK();
-                if (ks > 1) {
-                    size_t b = (out_elems / 4 + 255) / 256;
-                    b = b > 4096 ? 4096 : (b < 1 ? 1 : b);
-                    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, (const float*)part_ws, a.Y, a.bias,
-                                       ks, out_elems, a.M, a.Yh * a.Yw, a.act, a.slope);
-                    PCGAN_LAUNCH_CHECK();
-                }
+                if (ks > 1 && launch_splitk_reduce(a.dtype, st, part_ws, a.Y, a.bias, ks, out_elems, a.M, a.Yh * a.Yw, a.act, a.slope)) return 2;
                 return 0;
             }
         }
@@ -2022,12 +2077,12 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
         for (int i = 0; i < a.nphase; ++i) maxtaps = a.ph[i].nR * a.ph[i].nS > maxtaps ? a.ph[i].nR * a.ph[i].nS : maxtaps;
         if (maxtaps <= 9) {
             const dim3 g1((unsigned)((pmax + 255) / 256), (unsigned)a.nphase);
-            hipLaunchKernelGGL((smallm_conv_fewtaps_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE)>), g1, dim3(256), 0, st, a);
+            LAUNCH_TA(a.dtype, smallm_conv_fewtaps_kernel, g1, a, (MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE));
             PCGAN_LAUNCH_CHECK();
             return 0;
         }
         const dim3 grid((unsigned)((pmax + 63) / 64), (unsigned)a.nphase);
-        hipLaunchKernelGGL((smallm_conv_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE)>), grid, dim3(256), 0, st, a);
+        LAUNCH_TA(a.dtype, smallm_conv_kernel, grid, a, (MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE));
         PCGAN_LAUNCH_CHECK();
         return 0;
     }
@@ -2058,9 +2113,9 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
     }
 #define LI(BMV, BPV)                                                                                   \
     do {                                                                                               \
-        if (cg16) hipLaunchKernelGGL((igemm2_kernel<MODE, BMV, BPV>), grid2, dim3(256), 0, st, a);      \
-        else if (cg4) hipLaunchKernelGGL((igemm2_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV, 4>), grid2, dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((igemm_kernel<(MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV>), grid, dim3(256), 0, st, a); \
+        if (cg16) LAUNCH_TA(a.dtype, igemm2_kernel, grid2, a, MODE, BMV, BPV, 16);                      \
+        else if (cg4) LAUNCH_TA(a.dtype, igemm2_kernel, grid2, a, (MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV, 4); \
+        else LAUNCH_TA(a.dtype, igemm_kernel, grid, a, (MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE), BMV, BPV); \
     } while (0)
     if (bm == 128 && bp == 128) LI(128, 128);
     else if (bm == 128) LI(128, 64);
@@ -2069,14 +2124,7 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
     else LI(32, 128);
 #undef LI
     PCGAN_LAUNCH_CHECK();
-    if (ks > 1) {
-        size_t b = (out_elems / 4 + 255) / 256;
-        if (b > 4096) b = 4096;
-        if (b < 1) b = 1;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, (const float*)part_ws, a.Y, a.bias, ks,
-                           out_elems, a.M, a.Yh * a.Yw, a.act, a.slope);
-        PCGAN_LAUNCH_CHECK();
-    }
+    if (ks > 1 && launch_splitk_reduce(a.dtype, st, part_ws, a.Y, a.bias, ks, out_elems, a.M, a.Yh * a.Yw, a.act, a.slope)) return 2;
     return 0;
 }
 
@@ -2217,8 +2265,8 @@ static int pack_fwd(const pcgan_conv_desc* d, const float* w, float* A, hipStrea
     return 0;
 }
 
-static int conv2d_fwd_impl(const pcgan_conv_desc* d, const float* x, const float* w, const float* packed,
-                           const float* bias, float* y, int act, float slope, void* ws, size_t ws_bytes,
+static int conv2d_fwd_impl(const pcgan_conv_desc* d, const void* x, const float* w, const float* packed,
+                           const float* bias, void* y, int act, float slope, void* ws, size_t ws_bytes,
                            pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(x && (w || packed) && y, "conv2d_fwd: null pointer");
@@ -2230,12 +2278,12 @@ static int conv2d_fwd_impl(const pcgan_conv_desc* d, const float* x, const float
     if (!packed && pack_fwd(d, w, A, st)) return 2;
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.X = x; a.Y = y; a.bias = bias;
+    a.X = x; a.Y = y; a.bias = bias; a.dtype = d->dtype;
     a.M = d->K; a.N = d->N; a.Cg = d->C; a.Cgp = Cgp; a.Hg = d->H; a.Wg = d->W;
     a.Yh = d->P; a.Yw = d->Q;
     a.ostep = 1; a.sl = ilog2_exact(d->stride); a.pad = d->pad; a.tstep = 1;
     a.act = act; a.slope = slope;
-    a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
+    a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * esz(d));
     a.nphase = 1;
     a.chunked = chunked_k(d->C, d->K, d->R, d->S) ? 1 : (cg4_k(d->C, d->K, d->R, d->S) ? 2 : 0);
     PhaseArgs& p = a.ph[0];
@@ -2250,22 +2298,22 @@ static int conv2d_fwd_impl(const pcgan_conv_desc* d, const float* x, const float
                             : launch_igemm<MODE_FWD_ZERO>(a, st, part, fwd_part_bytes(d));
 }
 
-extern "C" int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const float* x, const float* w, const float* bias,
-                                float* y, int act, float slope, void* ws, size_t ws_bytes, pcgan_stream_t s) {
+extern "C" int pcgan_conv2d_fwd(const pcgan_conv_desc* d, const void* x, const float* w, const float* bias,
+                                void* y, int act, float slope, void* ws, size_t ws_bytes, pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(w, "conv2d_fwd: null weight pointer");
     return conv2d_fwd_impl(d, x, w, nullptr, bias, y, act, slope, ws, ws_bytes, s);
 }
-extern "C" int pcgan_conv2d_fwd_packed(const pcgan_conv_desc* d, const float* x, const float* packed,
-                                       const float* bias, float* y, int act, float slope, void* ws, size_t ws_bytes,
+extern "C" int pcgan_conv2d_fwd_packed(const pcgan_conv_desc* d, const void* x, const float* packed,
+                                       const float* bias, void* y, int act, float slope, void* ws, size_t ws_bytes,
                                        pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(packed, "conv2d_fwd_packed: null packed-weight pointer");
     return conv2d_fwd_impl(d, x, nullptr, packed, bias, y, act, slope, ws, ws_bytes, s);
 }
 
-static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const float* w, const float* packed,
-                                const float* bias, float* dx, void* ws, size_t ws_bytes, pcgan_stream_t s) {
+static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const void* dy, const float* w, const float* packed,
+                                const float* bias, void* dx, void* ws, size_t ws_bytes, pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     const bool pack_only = dx == nullptr;   // pcgan_conv2d_pack_weights: run the repack launches into `packed` only
     PCGAN_CHECK(pack_only ? (w && packed) : (dy && (w || packed)), "conv2d_bwd_data: null pointer");
@@ -2289,19 +2337,19 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     const int H = reflect ? d->H + 2 * d->pad : d->H;
     const int W = reflect ? d->W + 2 * d->pad : d->W;
     const int pad = reflect ? 0 : d->pad;
-    float* out = reflect ? (float*)((char*)ws + a_bytes) : dx;
+    void* out = reflect ? (void*)((char*)ws + a_bytes) : dx;
     const int stv = d->stride;
 
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.X = dy; a.Y = out; a.bias = bias;
+    a.X = dy; a.Y = out; a.bias = bias; a.dtype = d->dtype;
     a.M = d->C; a.N = d->N; a.Cg = d->K; a.Cgp = Kgp; a.Hg = d->P; a.Wg = d->Q;
     a.Yh = H; a.Yw = W;
     a.ostep = stv; a.sl = ilog2_exact(stv); a.pad = pad; a.tstep = stv;
     a.act = PCGAN_ACT_NONE; a.slope = 0.f;
     a.chunked = chunked ? 1 : (cg4_k(d->K, d->C, d->R, d->S) ? 2 : 0);
     a.rowfold = rowfold;
-    a.x_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * 4);
+    a.x_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * esz(d));
 
     if (rowfold) {
         // three row classes with their own weights: rows without a mirror image | row 1 | row H-2
@@ -2389,7 +2437,7 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     if (need_zero) {
         // pixels that no phase writes would also miss the bias; never happens for the nets on the hot path
         PCGAN_CHECK(!bias, "conv2d_bwd_data: bias with uncovered phases is unsupported");
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)d->N * d->C * H * W * 4, st);
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)d->N * d->C * H * W * esz(d), st);
         PCGAN_CHECK(e == hipSuccess, "memset failed: %s", hipGetErrorString(e));
     }
     // split-K partials live behind the A matrices (not with the padded-grid fallback or uncovered phases)
@@ -2399,22 +2447,26 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const float* dy, const
     if (reflect) {
         PCGAN_CHECK(d->N * d->C <= 65535, "conv2d_bwd_data: more than 65535 planes in the reflect fold");
         const int per_plane = d->H * ((d->W + 3) / 4);
-        hipLaunchKernelGGL(reflect_fold_kernel, dim3((per_plane + 255) / 256, d->N * d->C), dim3(256), 0, st, out, dx,
-                           d->N * d->C, d->H, d->W, d->pad);
+        if (d->dtype == PCGAN_BF16)
+            hipLaunchKernelGGL(reflect_fold_kernel<bf16>, dim3((per_plane + 255) / 256, d->N * d->C), dim3(256), 0, st, (const bf16*)out,
+                               (bf16*)dx, d->N * d->C, d->H, d->W, d->pad);
+        else
+            hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3((per_plane + 255) / 256, d->N * d->C), dim3(256), 0, st, (const float*)out,
+                               (float*)dx, d->N * d->C, d->H, d->W, d->pad);
         PCGAN_LAUNCH_CHECK();
     }
     return 0;
 }
 
-extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const float* dy, const float* w,
-                                     const float* bias, float* dx, void* ws, size_t ws_bytes,
+extern "C" int pcgan_conv2d_bwd_data(const pcgan_conv_desc* d, const void* dy, const float* w,
+                                     const float* bias, void* dx, void* ws, size_t ws_bytes,
                                      pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(w && dx, "conv2d_bwd_data: null pointer");
     return conv2d_bwd_data_impl(d, dy, w, nullptr, bias, dx, ws, ws_bytes, s);
 }
-extern "C" int pcgan_conv2d_bwd_data_packed(const pcgan_conv_desc* d, const float* dy, const float* packed,
-                                            const float* bias, float* dx, void* ws, size_t ws_bytes,
+extern "C" int pcgan_conv2d_bwd_data_packed(const pcgan_conv_desc* d, const void* dy, const float* packed,
+                                            const float* bias, void* dx, void* ws, size_t ws_bytes,
                                             pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(packed && dx, "conv2d_bwd_data_packed: null pointer");
@@ -2436,7 +2488,7 @@ extern "C" int pcgan_conv2d_pack_weights(const pcgan_conv_desc* d, int pass, con
     return conv2d_bwd_data_impl(d, nullptr, w, packed, nullptr, nullptr, nullptr, 0, s);
 }
 
-extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x, const float* dy, float* dw,
+extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const void* x, const void* dy, float* dw,
                                        int accumulate, void* ws, size_t ws_bytes, pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(x && dy && dw, "conv2d_bwd_weight: null pointer");
@@ -2446,19 +2498,19 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
     const int Cgp = round4(d->C), RS = d->R * d->S;
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.dY = dy; a.X = x; a.Wp = (float*)ws;
+    a.dY = dy; a.X = x; a.Wp = (float*)ws; a.dtype = d->dtype;
     a.M = d->K; a.Kp = RS * Cgp; a.N = d->N; a.Cg = d->C; a.Cgp = Cgp;
     a.Hg = d->H; a.Wg = d->W; a.Ho = d->P; a.Wo = d->Q;
     a.sl = ilog2_exact(d->stride); a.pad = d->pad; a.S = d->S;
     a.magicS = (65536 + d->S - 1) / d->S;
     a.Ptot = d->N * d->P * d->Q;
-    a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
-    a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * 4);
+    a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * esz(d));
+    a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * esz(d));
     const int splits = wgrad_splits(d, &a.chunks_per_split);
     if (smallm_wgrad_strip(d)) {
         const dim3 sgrid((unsigned)d->C, (unsigned)splits, (unsigned)((d->R <= 4 && d->S <= 4) ? 1 : (d->S + 3) / 4));
-#define LWS(MODE) do { if (d->R <= 4 && d->S <= 4) hipLaunchKernelGGL((smallm_wgrad_strip_kernel<MODE, 4>), sgrid, dim3(256), 0, st, a); \
-                       else hipLaunchKernelGGL((smallm_wgrad_strip_kernel<MODE, 7>), sgrid, dim3(256), 0, st, a); } while (0)
+#define LWS(MODE) do { if (d->R <= 4 && d->S <= 4) LAUNCH_TA(a.dtype, smallm_wgrad_strip_kernel, sgrid, a, MODE, 4); \
+                       else LAUNCH_TA(a.dtype, smallm_wgrad_strip_kernel, sgrid, a, MODE, 7); } while (0)
         if (d->pad_mode == 1) LWS(MODE_FWD_REFLECT); else LWS(MODE_FWD_ZERO);
 #undef LWS
         PCGAN_LAUNCH_CHECK();
@@ -2471,8 +2523,8 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
     }
     if (smallm_wgrad(d)) {
         const dim3 sgrid((unsigned)(a.Kp / 16), (unsigned)splits);
-        if (d->pad_mode == 1) hipLaunchKernelGGL((smallm_wgrad_kernel<MODE_FWD_REFLECT>), sgrid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((smallm_wgrad_kernel<MODE_FWD_ZERO>), sgrid, dim3(256), 0, st, a);
+        if (d->pad_mode == 1) LAUNCH_TA(a.dtype, smallm_wgrad_kernel, sgrid, a, MODE_FWD_REFLECT);
+        else LAUNCH_TA(a.dtype, smallm_wgrad_kernel, sgrid, a, MODE_FWD_ZERO);
         PCGAN_LAUNCH_CHECK();
         const size_t total = (size_t)d->K * RS * Cgp;
         const int blocks = (int)((total + 63) / 64);
@@ -2490,8 +2542,8 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
     static const bool old_wgrad = getenv("PCGAN_OLD_WGRAD") != nullptr;   // A/B experiments
     const bool w2 = !old_wgrad && (d->C % 64) == 0 && ((Cgp % 128) == 0 || Cgp == 64);
     if (w2) {
-#define LW2(MODE, BMV, VA) do { if (Cgp == 64) hipLaunchKernelGGL((wgrad2_kernel<MODE, BMV, VA, 2>), grid, dim3(256), 0, st, a); \
-                                else hipLaunchKernelGGL((wgrad2_kernel<MODE, BMV, VA, 1>), grid, dim3(256), 0, st, a); } while (0)
+#define LW2(MODE, BMV, VA) do { if (Cgp == 64) LAUNCH_TA(a.dtype, wgrad2_kernel, grid, a, MODE, BMV, VA, 2); \
+                                else LAUNCH_TA(a.dtype, wgrad2_kernel, grid, a, MODE, BMV, VA, 1); } while (0)
 #define LW2_VA(MODE, BMV) do { if (veca) LW2(MODE, BMV, true); else LW2(MODE, BMV, false); } while (0)
 #define LW2_BM(MODE) do { if (bm == 128) LW2_VA(MODE, 128); else if (bm == 64) LW2_VA(MODE, 64); else LW2_VA(MODE, 32); } while (0)
         if (reflect) LW2_BM(MODE_FWD_REFLECT); else LW2_BM(MODE_FWD_ZERO);
@@ -2499,7 +2551,7 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const float* x,
 #undef LW2_VA
 #undef LW2
     } else {
-#define LW(MODE, BMV, KM, VA) hipLaunchKernelGGL((wgrad_kernel<MODE, BMV, KM, VA>), grid, dim3(256), 0, st, a)
+#define LW(MODE, BMV, KM, VA) LAUNCH_TA(a.dtype, wgrad_kernel, grid, a, MODE, BMV, KM, VA)
 #define LW_VA(MODE, BMV, KM) do { if (veca) LW(MODE, BMV, KM, true); else LW(MODE, BMV, KM, false); } while (0)
 #define LW_SC(MODE, BMV) do { if (kmode == 1) LW_VA(MODE, BMV, 1); else if (kmode == 2) LW_VA(MODE, BMV, 2); else LW_VA(MODE, BMV, 0); } while (0)
 #define LW_BM(MODE) do { if (bm == 128) LW_SC(MODE, 128); else if (bm == 64) LW_SC(MODE, 64); else LW_SC(MODE, 32); } while (0)

@@ -12,16 +12,18 @@ namespace pcgan {
 enum { LOSS_BCE = 0, LOSS_L1 = 1, LOSS_MSE = 2 };
 static constexpr int LOSS_BLOCKS = 256;
 
-template <int KIND>
-__global__ void __launch_bounds__(256) loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                           float* __restrict__ grad, float* __restrict__ part, size_t n,
+// a (prediction / image) and grad are activation tensors of storage type T; the BCE target is a per-sample fp32 vector, the
+// L1 / MSE target b an activation tensor; partial sums and the loss are fp32
+template <int KIND, typename T>
+__global__ void __launch_bounds__(256) loss_partial_kernel(const T* __restrict__ a, const void* __restrict__ bv,
+                                                           T* __restrict__ grad, float* __restrict__ part, size_t n,
                                                            int per_n, float gs) {
     __shared__ float scratch[16];
     float acc = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float p = a[i];
+        const float p = ld1(a + i);
         if (KIND == LOSS_BCE) {
-            const float t = b[i / per_n];
+            const float t = ((const float*)bv)[i / per_n];
             float lp = logf(p), lq = logf(1.f - p);
             lp = lp < -100.f ? -100.f : lp;
             lq = lq < -100.f ? -100.f : lq;
@@ -29,16 +31,16 @@ __global__ void __launch_bounds__(256) loss_partial_kernel(const float* __restri
             if (grad) {
                 float den = (1.f - p) * p;
                 den = den < 1e-12f ? 1e-12f : den;
-                grad[i] = gs * (p - t) / den;
+                st1(grad + i, gs * (p - t) / den);
             }
         } else if (KIND == LOSS_L1) {
-            const float d = p - b[i];
+            const float d = p - ld1((const T*)bv + i);
             acc += fabsf(d);
-            if (grad) grad[i] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+            if (grad) st1(grad + i, d > 0.f ? gs : (d < 0.f ? -gs : 0.f));
         } else {
-            const float d = p - b[i];
+            const float d = p - ld1((const T*)bv + i);
             acc += d * d;
-            if (grad) grad[i] = 2.f * gs * d;
+            if (grad) st1(grad + i, 2.f * gs * d);
         }
     }
     acc = block_sum(acc, scratch);
@@ -55,14 +57,15 @@ __global__ void __launch_bounds__(256) loss_finish_kernel(const float* __restric
 }
 
 template <int KIND>
-static int run_loss(const float* a, const float* b, float* loss, float* grad, size_t n, int per_n, float gscale,
-                    void* ws, size_t ws_bytes, hipStream_t st) {
+static int run_loss(const void* a, const void* b, float* loss, void* grad, size_t n, int per_n, float gscale,
+                    void* ws, size_t ws_bytes, int dtype, hipStream_t st) {
     PCGAN_CHECK(a && b && loss && n > 0, "loss: bad arguments");
     PCGAN_CHECK(ws && ws_bytes >= LOSS_BLOCKS * sizeof(float), "loss: workspace too small");
     int blocks = (int)((n + 255) / 256);
     if (blocks > LOSS_BLOCKS) blocks = LOSS_BLOCKS;
     const float gs = gscale / (float)n;
-    hipLaunchKernelGGL((loss_partial_kernel<KIND>), dim3(blocks), dim3(256), 0, st, a, b, grad, (float*)ws, n, per_n, gs);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL((loss_partial_kernel<KIND, T>), dim3(blocks), dim3(256), 0, st, (const T*)a, b, (T*)grad,
+                                                    (float*)ws, n, per_n, gs));
     PCGAN_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, 1.f / (float)n, loss);
     PCGAN_LAUNCH_CHECK();
@@ -101,18 +104,18 @@ extern "C" size_t pcgan_loss_workspace_bytes(size_t n) {
     return LOSS_BLOCKS * sizeof(float);
 }
 
-extern "C" int pcgan_bce_loss(const float* pred, const float* target_n, float* loss, float* grad, int N, int per_n,
-                              float gscale, void* ws, size_t ws_bytes, pcgan_stream_t s) {
+extern "C" int pcgan_bce_loss(const void* pred, const float* target_n, float* loss, void* grad, int N, int per_n,
+                              float gscale, void* ws, size_t ws_bytes, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(N > 0 && per_n > 0, "bce_loss: bad shape");
-    return run_loss<LOSS_BCE>(pred, target_n, loss, grad, (size_t)N * per_n, per_n, gscale, ws, ws_bytes, (hipStream_t)s);
+    return run_loss<LOSS_BCE>(pred, target_n, loss, grad, (size_t)N * per_n, per_n, gscale, ws, ws_bytes, dtype, (hipStream_t)s);
 }
-extern "C" int pcgan_l1_loss(const float* a, const float* b, float* loss, float* grad_a, size_t n, float gscale,
-                             void* ws, size_t ws_bytes, pcgan_stream_t s) {
-    return run_loss<LOSS_L1>(a, b, loss, grad_a, n, 1, gscale, ws, ws_bytes, (hipStream_t)s);
+extern "C" int pcgan_l1_loss(const void* a, const void* b, float* loss, void* grad_a, size_t n, float gscale,
+                             void* ws, size_t ws_bytes, int dtype, pcgan_stream_t s) {
+    return run_loss<LOSS_L1>(a, b, loss, grad_a, n, 1, gscale, ws, ws_bytes, dtype, (hipStream_t)s);
 }
-extern "C" int pcgan_mse_loss(const float* a, const float* b, float* loss, float* grad_a, size_t n, float gscale,
-                              void* ws, size_t ws_bytes, pcgan_stream_t s) {
-    return run_loss<LOSS_MSE>(a, b, loss, grad_a, n, 1, gscale, ws, ws_bytes, (hipStream_t)s);
+extern "C" int pcgan_mse_loss(const void* a, const void* b, float* loss, void* grad_a, size_t n, float gscale,
+                              void* ws, size_t ws_bytes, int dtype, pcgan_stream_t s) {
+    return run_loss<LOSS_MSE>(a, b, loss, grad_a, n, 1, gscale, ws, ws_bytes, dtype, (hipStream_t)s);
 }
 
 extern "C" int pcgan_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,

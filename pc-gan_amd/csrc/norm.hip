@@ -13,33 +13,32 @@
 namespace pcgan {
 
 // one workgroup per plane; mean and M2 = sum (x - mean)^2 by an exact two-pass
-__global__ void __launch_bounds__(256) plane_stats_kernel(const float* __restrict__ x, float* __restrict__ mean_nc,
+template <typename T>
+__global__ void __launch_bounds__(256) plane_stats_kernel(const T* __restrict__ x, float* __restrict__ mean_nc,
                                                           float* __restrict__ m2_nc, int HW) {
     __shared__ float scratch[16];
     const size_t plane = blockIdx.x;
-    const float* xp = x + plane * (size_t)HW;
+    const T* xp = x + plane * (size_t)HW;
     float s = 0.f;
     if ((HW & 3) == 0) {
-        const float4* x4 = reinterpret_cast<const float4*>(xp);
         for (int i = threadIdx.x; i < (HW >> 2); i += blockDim.x) {
-            const float4 v = x4[i];
+            const float4 v = ld4(xp + 4 * i);
             s += (v.x + v.y) + (v.z + v.w);
         }
     } else {
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += xp[i];
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += ld1(xp + i);
     }
     const float mean = block_sum(s, scratch) / (float)HW;
     float q = 0.f;
     if ((HW & 3) == 0) {
-        const float4* x4 = reinterpret_cast<const float4*>(xp);
         for (int i = threadIdx.x; i < (HW >> 2); i += blockDim.x) {
-            const float4 v = x4[i];
+            const float4 v = ld4(xp + 4 * i);
             const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
             q += (a * a + b * b) + (c * c + d * d);
         }
     } else {
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            const float a = xp[i] - mean;
+            const float a = ld1(xp + i) - mean;
             q += a * a;
         }
     }
@@ -97,18 +96,18 @@ __global__ void in_running_kernel(const float* __restrict__ mean_nc, const float
 }
 
 struct NormArgs {
-    const float* x;
-    const float* y;
-    const float* dy;
+    const void* x;          // activation tensors: storage type T of the kernel template
+    const void* y;
+    const void* dy;
     const float* mean;
     const float* var;
     const float* gamma;
     const float* beta;
-    const float* residual;
+    const void* residual;
     const float* s1;
     const float* s2;
-    float* out;
-    float* out2;
+    void* out;              // T (norm_act_fwd, norm_bwd_apply) or float (norm_bwd_stats)
+    void* out2;
     int N, C, HW, per_plane, act;
     float eps, slope, inv_cnt;
 };
@@ -124,56 +123,58 @@ __device__ __forceinline__ void plane_coeffs(const NormArgs& a, size_t plane, fl
     b = a.beta ? a.beta[c] : 0.f;
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256) norm_act_fwd_kernel(NormArgs a) {
     const size_t plane = blockIdx.x;
     float mean, rstd, g, b;
     plane_coeffs(a, plane, mean, rstd, g, b);
     const float sc = rstd * g, sh = b - mean * rstd * g;
-    const float* xp = a.x + plane * (size_t)a.HW;
-    const float* rp = a.residual ? a.residual + plane * (size_t)a.HW : nullptr;
-    float* yp = a.out + plane * (size_t)a.HW;
+    const T* xp = (const T*)a.x + plane * (size_t)a.HW;
+    const T* rp = a.residual ? (const T*)a.residual + plane * (size_t)a.HW : nullptr;
+    T* yp = (T*)a.out + plane * (size_t)a.HW;
     if ((a.HW & 3) == 0) {
         for (int i = threadIdx.x; i < (a.HW >> 2); i += blockDim.x) {
-            float4 v = reinterpret_cast<const float4*>(xp)[i];
+            float4 v = ld4(xp + 4 * i);
             v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
             if (rp) {
-                const float4 r = reinterpret_cast<const float4*>(rp)[i];
+                const float4 r = ld4(rp + 4 * i);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
             v.x = act_apply(v.x, a.act, a.slope); v.y = act_apply(v.y, a.act, a.slope);
             v.z = act_apply(v.z, a.act, a.slope); v.w = act_apply(v.w, a.act, a.slope);
-            reinterpret_cast<float4*>(yp)[i] = v;
+            st4(yp + 4 * i, v);
         }
     } else {
         for (int i = threadIdx.x; i < a.HW; i += blockDim.x) {
-            float v = xp[i] * sc + sh;
-            if (rp) v += rp[i];
-            yp[i] = act_apply(v, a.act, a.slope);
+            float v = ld1(xp + i) * sc + sh;
+            if (rp) v += ld1(rp + i);
+            st1(yp + i, act_apply(v, a.act, a.slope));
         }
     }
 }
 
 // s1[plane] = sum g, s2[plane] = sum g * xhat, g = dy * act'(y)
+template <typename T>
 __global__ void __launch_bounds__(256) norm_bwd_stats_kernel(NormArgs a) {
     __shared__ float scratch[16];
     const size_t plane = blockIdx.x;
     float mean, rstd, g_, b_;
     plane_coeffs(a, plane, mean, rstd, g_, b_);
-    const float* xp = a.x + plane * (size_t)a.HW;
-    const float* dp = a.dy + plane * (size_t)a.HW;
-    const float* yp = (a.act != PCGAN_ACT_NONE) ? a.y + plane * (size_t)a.HW : nullptr;
+    const T* xp = (const T*)a.x + plane * (size_t)a.HW;
+    const T* dp = (const T*)a.dy + plane * (size_t)a.HW;
+    const T* yp = (a.act != PCGAN_ACT_NONE) ? (const T*)a.y + plane * (size_t)a.HW : nullptr;
     float s1 = 0.f, s2 = 0.f;
     for (int i = threadIdx.x; i < a.HW; i += blockDim.x) {
-        float g = dp[i];
-        if (yp) g *= act_grad_from_out(yp[i], a.act, a.slope);
+        float g = ld1(dp + i);
+        if (yp) g *= act_grad_from_out(ld1(yp + i), a.act, a.slope);
         s1 += g;
-        s2 += g * ((xp[i] - mean) * rstd);
+        s2 += g * ((ld1(xp + i) - mean) * rstd);
     }
     s1 = block_sum(s1, scratch);
     s2 = block_sum(s2, scratch);
     if (threadIdx.x == 0) {
-        a.out[plane] = s1;
-        a.out2[plane] = s2;
+        ((float*)a.out)[plane] = s1;
+        ((float*)a.out2)[plane] = s2;
     }
 }
 
@@ -195,6 +196,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ s1_nc, const floa
     }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(NormArgs a) {
     const size_t plane = blockIdx.x;
     float mean, rstd, g_, b_;
@@ -203,17 +205,17 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(NormArgs a) {
     const size_t si = a.per_plane ? plane : (size_t)c;
     const float m1 = a.s1[si] * a.inv_cnt, m2 = a.s2[si] * a.inv_cnt;
     const float k = rstd * g_;
-    const float* xp = a.x + plane * (size_t)a.HW;
-    const float* dp = a.dy + plane * (size_t)a.HW;
-    const float* yp = (a.act != PCGAN_ACT_NONE) ? a.y + plane * (size_t)a.HW : nullptr;
-    float* op = a.out + plane * (size_t)a.HW;
-    float* rp = a.out2 ? a.out2 + plane * (size_t)a.HW : nullptr;
+    const T* xp = (const T*)a.x + plane * (size_t)a.HW;
+    const T* dp = (const T*)a.dy + plane * (size_t)a.HW;
+    const T* yp = (a.act != PCGAN_ACT_NONE) ? (const T*)a.y + plane * (size_t)a.HW : nullptr;
+    T* op = (T*)a.out + plane * (size_t)a.HW;
+    T* rp = a.out2 ? (T*)a.out2 + plane * (size_t)a.HW : nullptr;
     for (int i = threadIdx.x; i < a.HW; i += blockDim.x) {
-        float g = dp[i];
-        if (yp) g *= act_grad_from_out(yp[i], a.act, a.slope);
-        const float xh = (xp[i] - mean) * rstd;
-        op[i] = k * (g - m1 - xh * m2);
-        if (rp) rp[i] = g;
+        float g = ld1(dp + i);
+        if (yp) g *= act_grad_from_out(ld1(yp + i), a.act, a.slope);
+        const float xh = (ld1(xp + i) - mean) * rstd;
+        st1(op + i, k * (g - m1 - xh * m2));
+        if (rp) st1(rp + i, g);
     }
 }
 
@@ -235,27 +237,44 @@ __device__ __forceinline__ void bn_for_each(int N, int C, int HW, int c, F f) {
     }
 }
 
-template <int V>
-__global__ void __launch_bounds__(256) bn_fwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, const float* __restrict__ res,
-                                                           float* __restrict__ y, float* __restrict__ mean_c,
+// V consecutive elements as fp32 (V = 4: one 16-byte / 8-byte access, V = 1: scalar)
+template <int V, typename T>
+__device__ __forceinline__ void ldv(const T* p, float (&v)[V]) {
+    if (V == 4) {
+        const float4 t = ld4(p);
+        v[0] = t.x; v[1 % V] = t.y; v[2 % V] = t.z; v[3 % V] = t.w;
+    } else {
+        v[0] = ld1(p);
+    }
+}
+template <int V, typename T>
+__device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
+    if (V == 4) st4(p, make_float4(v[0], v[1 % V], v[2 % V], v[3 % V]));
+    else st1(p, v[0]);
+}
+
+template <int V, typename T>
+__global__ void __launch_bounds__(256) bn_fwd_fused_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const T* __restrict__ res,
+                                                           T* __restrict__ y, float* __restrict__ mean_c,
                                                            float* __restrict__ var_c, float* running_mean, float* running_var,
                                                            long long* batches, int N, int C, int HW, float momentum, float eps,
                                                            int act, float slope) {
-    typedef float vec __attribute__((ext_vector_type(V)));
     __shared__ float scratch[16];
     const int c = blockIdx.x;
     const int cnt = N * HW;
     float s = 0.f;
     bn_for_each<V>(N, C, HW, c, [&](size_t i) {
-        const vec v = *reinterpret_cast<const vec*>(x + i);
+        float v[V];
+        ldv<V>(x + i, v);
 #pragma unroll
         for (int e = 0; e < V; ++e) s += v[e];
     });
     const float mean = block_sum(s, scratch) / (float)cnt;
     float q = 0.f;
     bn_for_each<V>(N, C, HW, c, [&](size_t i) {
-        const vec v = *reinterpret_cast<const vec*>(x + i);
+        float v[V];
+        ldv<V>(x + i, v);
 #pragma unroll
         for (int e = 0; e < V; ++e) q += (v[e] - mean) * (v[e] - mean);
     });
@@ -271,36 +290,36 @@ __global__ void __launch_bounds__(256) bn_fwd_fused_kernel(const float* __restri
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float sc = rsqrtf(var + eps) * g, sh = b - mean * sc;
     bn_for_each<V>(N, C, HW, c, [&](size_t i) {
-        vec v = *reinterpret_cast<const vec*>(x + i);
-        vec r;
-        if (res) r = *reinterpret_cast<const vec*>(res + i);
+        float v[V], r[V];
+        ldv<V>(x + i, v);
+        if (res) ldv<V>(res + i, r);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             float t = v[e] * sc + sh;
             if (res) t += r[e];
             v[e] = act_apply(t, act, slope);
         }
-        *reinterpret_cast<vec*>(y + i) = v;
+        stv<V>(y + i, v);
     });
 }
 
-template <int V>
-__global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           const float* __restrict__ y, const float* __restrict__ mean_c,
+template <int V, typename T>
+__global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y, const float* __restrict__ mean_c,
                                                            const float* __restrict__ var_c, const float* __restrict__ gamma,
-                                                           float* __restrict__ dx, float* __restrict__ dres,
+                                                           T* __restrict__ dx, T* __restrict__ dres,
                                                            float* __restrict__ s1_c, float* __restrict__ s2_c, int N, int C,
                                                            int HW, float eps, int act, float slope) {
-    typedef float vec __attribute__((ext_vector_type(V)));
     __shared__ float scratch[16];
     const int c = blockIdx.x;
     const int cnt = N * HW;
     const float mean = mean_c[c], rstd = rsqrtf(var_c[c] + eps);
     float s1 = 0.f, s2 = 0.f;
     bn_for_each<V>(N, C, HW, c, [&](size_t i) {
-        const vec d = *reinterpret_cast<const vec*>(dy + i), xv = *reinterpret_cast<const vec*>(x + i);
-        vec yv;
-        if (act != PCGAN_ACT_NONE) yv = *reinterpret_cast<const vec*>(y + i);
+        float d[V], xv[V], yv[V];
+        ldv<V>(dy + i, d);
+        ldv<V>(x + i, xv);
+        if (act != PCGAN_ACT_NONE) ldv<V>(y + i, yv);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             float g = d[e];
@@ -319,9 +338,10 @@ __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const float* __restri
     const float m1 = s1 / (float)cnt, m2 = s2 / (float)cnt;
     const float kk = rstd * (gamma ? gamma[c] : 1.f);
     bn_for_each<V>(N, C, HW, c, [&](size_t i) {
-        const vec d = *reinterpret_cast<const vec*>(dy + i), xv = *reinterpret_cast<const vec*>(x + i);
-        vec yv, o, gr;
-        if (act != PCGAN_ACT_NONE) yv = *reinterpret_cast<const vec*>(y + i);
+        float d[V], xv[V], yv[V], o[V], gr[V];
+        ldv<V>(dy + i, d);
+        ldv<V>(x + i, xv);
+        if (act != PCGAN_ACT_NONE) ldv<V>(y + i, yv);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             float g = d[e];
@@ -329,8 +349,8 @@ __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const float* __restri
             gr[e] = g;
             o[e] = kk * (g - m1 - ((xv[e] - mean) * rstd) * m2);
         }
-        if (dx) *reinterpret_cast<vec*>(dx + i) = o;
-        if (dres) *reinterpret_cast<vec*>(dres + i) = gr;
+        if (dx) stv<V>(dx + i, o);
+        if (dres) stv<V>(dres + i, gr);
     });
 }
 
@@ -339,28 +359,28 @@ __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const float* __restri
 // + ONE write (statistics, normalise, residual, activation) and backward ONE read of dy/x(/y) + ONE write.
 // T threads x E float4 per thread cover planes up to T*E*4 elements (HW % 4 == 0).
 // ------------------------------------------------------------------------------------------------
-template <int E>
-__global__ void __launch_bounds__(1024) instnorm_fwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                                   float* __restrict__ y, float* __restrict__ mean_nc,
+template <int E, typename T>
+__global__ void __launch_bounds__(1024) instnorm_fwd_fused_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                                   T* __restrict__ y, float* __restrict__ mean_nc,
                                                                    float* __restrict__ m2_nc, int HW, float eps, int act,
                                                                    float slope) {
     __shared__ float scratch[16];
     const size_t plane = blockIdx.x;
-    const int T = blockDim.x, n4 = HW >> 2;
-    const float4* x4 = reinterpret_cast<const float4*>(x + plane * (size_t)HW);
+    const int NT = blockDim.x, n4 = HW >> 2;
+    const T* xp = x + plane * (size_t)HW;
     float4 v[E];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-        const int i = threadIdx.x + k * T;
-        v[k] = i < n4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int i = threadIdx.x + k * NT;
+        v[k] = i < n4 ? ld4(xp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     }
     const float mean = block_sum(s, scratch) / (float)HW;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-        if (threadIdx.x + k * T < n4) {
+        if (threadIdx.x + k * NT < n4) {
             const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
             q += (a * a + b * b) + (c * c + d * d);
         }
@@ -368,20 +388,20 @@ __global__ void __launch_bounds__(1024) instnorm_fwd_fused_kernel(const float* _
     const float m2 = block_sum(q, scratch);
     const float rstd = rsqrtf(m2 / (float)HW + eps);
     const float sh = -mean * rstd;
-    const float4* r4 = res ? reinterpret_cast<const float4*>(res + plane * (size_t)HW) : nullptr;
-    float4* y4 = reinterpret_cast<float4*>(y + plane * (size_t)HW);
+    const T* rp = res ? res + plane * (size_t)HW : nullptr;
+    T* yp = y + plane * (size_t)HW;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-        const int i = threadIdx.x + k * T;
+        const int i = threadIdx.x + k * NT;
         if (i < n4) {
             float4 o = make_float4(v[k].x * rstd + sh, v[k].y * rstd + sh, v[k].z * rstd + sh, v[k].w * rstd + sh);
-            if (r4) {
-                const float4 r = r4[i];
+            if (rp) {
+                const float4 r = ld4(rp + 4 * i);
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             o.x = act_apply(o.x, act, slope); o.y = act_apply(o.y, act, slope);
             o.z = act_apply(o.z, act, slope); o.w = act_apply(o.w, act, slope);
-            y4[i] = o;
+            st4(yp + 4 * i, o);
         }
     }
     if (threadIdx.x == 0) {
@@ -390,30 +410,30 @@ __global__ void __launch_bounds__(1024) instnorm_fwd_fused_kernel(const float* _
     }
 }
 
-template <int E>
-__global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                   const float* __restrict__ y, const float* __restrict__ mean_nc,
-                                                                   const float* __restrict__ m2_nc, float* __restrict__ dx,
+template <int E, typename T>
+__global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                   const T* __restrict__ y, const float* __restrict__ mean_nc,
+                                                                   const float* __restrict__ m2_nc, T* __restrict__ dx,
                                                                    float* __restrict__ dx_psum, int HW, float eps, int act,
                                                                    float slope) {
     __shared__ float scratch[16];
     const size_t plane = blockIdx.x;
-    const int T = blockDim.x, n4 = HW >> 2;
+    const int NT = blockDim.x, n4 = HW >> 2;
     const float mean = mean_nc[plane];
     const float rstd = rsqrtf(m2_nc[plane] / (float)HW + eps);
-    const float4* d4 = reinterpret_cast<const float4*>(dy + plane * (size_t)HW);
-    const float4* x4 = reinterpret_cast<const float4*>(x + plane * (size_t)HW);
-    const float4* y4 = (act != PCGAN_ACT_NONE) ? reinterpret_cast<const float4*>(y + plane * (size_t)HW) : nullptr;
+    const T* dp = dy + plane * (size_t)HW;
+    const T* xp = x + plane * (size_t)HW;
+    const T* yp = (act != PCGAN_ACT_NONE) ? y + plane * (size_t)HW : nullptr;
     float4 g[E], xh[E];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-        const int i = threadIdx.x + k * T;
+        const int i = threadIdx.x + k * NT;
         if (i < n4) {
-            g[k] = d4[i];
-            const float4 xv = x4[i];
-            if (y4) {
-                const float4 yv = y4[i];
+            g[k] = ld4(dp + 4 * i);
+            const float4 xv = ld4(xp + 4 * i);
+            if (yp) {
+                const float4 yv = ld4(yp + 4 * i);
                 g[k].x *= act_grad_from_out(yv.x, act, slope); g[k].y *= act_grad_from_out(yv.y, act, slope);
                 g[k].z *= act_grad_from_out(yv.z, act, slope); g[k].w *= act_grad_from_out(yv.w, act, slope);
             }
@@ -428,15 +448,15 @@ __global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const float* _
     s1 = block_sum(s1, scratch);
     s2 = block_sum(s2, scratch);
     const float m1 = s1 / (float)HW, mm2 = s2 / (float)HW;
-    float4* o4 = reinterpret_cast<float4*>(dx + plane * (size_t)HW);
+    T* op = dx + plane * (size_t)HW;
     float ps = 0.f;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-        const int i = threadIdx.x + k * T;
+        const int i = threadIdx.x + k * NT;
         if (i < n4) {
             const float4 o = make_float4(rstd * (g[k].x - m1 - xh[k].x * mm2), rstd * (g[k].y - m1 - xh[k].y * mm2),
                                          rstd * (g[k].z - m1 - xh[k].z * mm2), rstd * (g[k].w - m1 - xh[k].w * mm2));
-            o4[i] = o;
+            st4(op + 4 * i, o);
             ps += (o.x + o.y) + (o.z + o.w);
         }
     }
@@ -450,7 +470,7 @@ __global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const float* _
 }
 
 // (threads, float4-per-thread) for a plane of HW elements; E == 0: plane too large / not a multiple of 4
-static inline void fused_plan(int HW, int* T, int* E) {
+static inline void fused_plan(int HW, int* T, int* E) {  // T: threads
     *T = 0;
     *E = 0;
     if (HW & 3) return;
@@ -467,10 +487,10 @@ static inline int plane_threads(int HW) { return HW >= 1024 ? 256 : (HW >= 256 ?
 
 using namespace pcgan;
 
-extern "C" int pcgan_plane_stats(const float* x, float* mean_nc, float* m2_nc, int NC, int HW, pcgan_stream_t s) {
+extern "C" int pcgan_plane_stats(const void* x, float* mean_nc, float* m2_nc, int NC, int HW, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(x && mean_nc && m2_nc && NC > 0 && HW > 0, "plane_stats: bad arguments");
-    hipLaunchKernelGGL(plane_stats_kernel, dim3(NC), dim3(plane_threads(HW)), 0, (hipStream_t)s, x, mean_nc, m2_nc,
-                       HW);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(plane_stats_kernel<T>, dim3(NC), dim3(plane_threads(HW)), 0, (hipStream_t)s,
+                                                    (const T*)x, mean_nc, m2_nc, HW));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -496,29 +516,29 @@ extern "C" int pcgan_in_running_update(const float* mean_nc, const float* m2_nc,
     return 0;
 }
 
-extern "C" int pcgan_norm_act_fwd(const float* x, const float* mean, const float* var, const float* gamma,
-                                  const float* beta, const float* residual, float* y, int N, int C, int HW,
-                                  int per_plane, float eps, int act, float slope, pcgan_stream_t s) {
+extern "C" int pcgan_norm_act_fwd(const void* x, const float* mean, const float* var, const float* gamma,
+                                  const float* beta, const void* residual, void* y, int N, int C, int HW,
+                                  int per_plane, float eps, int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(x && mean && var && y && N > 0 && C > 0 && HW > 0, "norm_act_fwd: bad arguments");
     NormArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.residual = residual; a.out = y;
     a.N = N; a.C = C; a.HW = HW; a.per_plane = per_plane; a.eps = eps; a.act = act; a.slope = slope;
-    hipLaunchKernelGGL(norm_act_fwd_kernel, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s, a);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(norm_act_fwd_kernel<T>, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s, a));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pcgan_norm_bwd_stats(const float* dy, const float* x, const float* y, const float* mean,
+extern "C" int pcgan_norm_bwd_stats(const void* dy, const void* x, const void* y, const float* mean,
                                     const float* var, float* s1_nc, float* s2_nc, int N, int C, int HW,
-                                    int per_plane, float eps, int act, float slope, pcgan_stream_t s) {
+                                    int per_plane, float eps, int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && x && mean && var && s1_nc && s2_nc, "norm_bwd_stats: null pointer");
     PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "norm_bwd_stats: activation mask needs y");
     NormArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.y = y; a.dy = dy; a.mean = mean; a.var = var; a.out = s1_nc; a.out2 = s2_nc;
     a.N = N; a.C = C; a.HW = HW; a.per_plane = per_plane; a.eps = eps; a.act = act; a.slope = slope;
-    hipLaunchKernelGGL(norm_bwd_stats_kernel, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s, a);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(norm_bwd_stats_kernel<T>, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s, a));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -532,10 +552,10 @@ extern "C" int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float
     return 0;
 }
 
-extern "C" int pcgan_norm_bwd_apply(const float* dy, const float* x, const float* y, const float* mean,
+extern "C" int pcgan_norm_bwd_apply(const void* dy, const void* x, const void* y, const float* mean,
                                     const float* var, const float* gamma, const float* s1, const float* s2,
-                                    float* dx, float* d_residual, int N, int C, int HW, int per_plane, float eps,
-                                    int act, float slope, pcgan_stream_t s) {
+                                    void* dx, void* d_residual, int N, int C, int HW, int per_plane, float eps,
+                                    int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && x && mean && var && s1 && s2 && dx, "norm_bwd_apply: null pointer");
     PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "norm_bwd_apply: activation mask needs y");
     NormArgs a;
@@ -544,82 +564,116 @@ extern "C" int pcgan_norm_bwd_apply(const float* dy, const float* x, const float
     a.out = dx; a.out2 = d_residual;
     a.N = N; a.C = C; a.HW = HW; a.per_plane = per_plane; a.eps = eps; a.act = act; a.slope = slope;
     a.inv_cnt = 1.f / (per_plane ? (float)HW : (float)N * (float)HW);
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s, a);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s, a));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pcgan_instnorm_fwd(const float* x, const float* residual, float* y, float* mean_nc, float* m2_nc, int N,
-                                  int C, int HW, float eps, int act, float slope, pcgan_stream_t s) {
+template <typename T>
+static void launch_instnorm_fwd(int E, int NT, int planes, hipStream_t st, const void* x, const void* residual, void* y, float* mean_nc,
+                                float* m2_nc, int HW, float eps, int act, float slope) {
+    const T* xp = (const T*)x;
+    const T* rp = (const T*)residual;
+    T* yp = (T*)y;
+    if (E == 1) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<1, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope);
+    else if (E == 4) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<4, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope);
+    else hipLaunchKernelGGL((instnorm_fwd_fused_kernel<16, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope);
+}
+
+extern "C" int pcgan_instnorm_fwd(const void* x, const void* residual, void* y, float* mean_nc, float* m2_nc, int N,
+                                  int C, int HW, float eps, int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(x && y && mean_nc && m2_nc && N > 0 && C > 0 && HW > 0, "instnorm_fwd: bad arguments");
-    int T, E;
-    fused_plan(HW, &T, &E);
+    int NT, E;
+    fused_plan(HW, &NT, &E);
     hipStream_t st = (hipStream_t)s;
     if (E == 0) {  // plane does not fit the register-resident kernel: statistics pass + apply pass
-        if (pcgan_plane_stats(x, mean_nc, m2_nc, N * C, HW, s)) return 1;
-        return pcgan_norm_act_fwd(x, mean_nc, m2_nc, nullptr, nullptr, residual, y, N, C, HW, 1, eps, act, slope, s);
+        if (pcgan_plane_stats(x, mean_nc, m2_nc, N * C, HW, dtype, s)) return 1;
+        return pcgan_norm_act_fwd(x, mean_nc, m2_nc, nullptr, nullptr, residual, y, N, C, HW, 1, eps, act, slope, dtype, s);
     }
-    if (E == 1) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<1>), dim3(N * C), dim3(T), 0, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope);
-    else if (E == 4) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<4>), dim3(N * C), dim3(T), 0, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope);
-    else hipLaunchKernelGGL((instnorm_fwd_fused_kernel<16>), dim3(N * C), dim3(T), 0, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope);
+    PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_fwd<T>(E, NT, N * C, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int pcgan_instnorm_fused(int HW) {
-    int T, E;
-    fused_plan(HW, &T, &E);
+    int NT, E;
+    fused_plan(HW, &NT, &E);
     return E != 0;
 }
 
-extern "C" int pcgan_instnorm_bwd(const float* dy, const float* x, const float* y, const float* mean_nc,
-                                  const float* m2_nc, float* dx, float* dx_psum, float* ws_s1s2, int N, int C, int HW, float eps,
-                                  int act, float slope, pcgan_stream_t s) {
+template <typename T>
+static void launch_instnorm_bwd(int E, int NT, int planes, hipStream_t st, const void* dy, const void* x, const void* y, const float* mean_nc,
+                                const float* m2_nc, void* dx, float* dx_psum, int HW, float eps, int act, float slope) {
+    const T* dp = (const T*)dy;
+    const T* xp = (const T*)x;
+    const T* yp = (const T*)y;
+    T* op = (T*)dx;
+    if (E == 1) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope);
+    else if (E == 4) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<4, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope);
+    else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<16, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope);
+}
+
+extern "C" int pcgan_instnorm_bwd(const void* dy, const void* x, const void* y, const float* mean_nc,
+                                  const float* m2_nc, void* dx, float* dx_psum, float* ws_s1s2, int N, int C, int HW, float eps,
+                                  int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && x && mean_nc && m2_nc && dx, "instnorm_bwd: null pointer");
     PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "instnorm_bwd: activation mask needs y");
-    int T, E;
-    fused_plan(HW, &T, &E);
+    int NT, E;
+    fused_plan(HW, &NT, &E);
     hipStream_t st = (hipStream_t)s;
     PCGAN_CHECK(E != 0 || !dx_psum, "instnorm_bwd: plane sums of dx come out of the register-resident kernel only (pcgan_instnorm_fused)");
     if (E == 0) {
         PCGAN_CHECK(ws_s1s2, "instnorm_bwd: the two-pass fallback needs 2*N*C floats of workspace");
-        if (pcgan_norm_bwd_stats(dy, x, y, mean_nc, m2_nc, ws_s1s2, ws_s1s2 + (size_t)N * C, N, C, HW, 1, eps, act, slope, s))
+        if (pcgan_norm_bwd_stats(dy, x, y, mean_nc, m2_nc, ws_s1s2, ws_s1s2 + (size_t)N * C, N, C, HW, 1, eps, act, slope, dtype, s))
             return 1;
         return pcgan_norm_bwd_apply(dy, x, y, mean_nc, m2_nc, nullptr, ws_s1s2, ws_s1s2 + (size_t)N * C, dx, nullptr, N, C,
-                                    HW, 1, eps, act, slope, s);
+                                    HW, 1, eps, act, slope, dtype, s);
     }
-    if (E == 1) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1>), dim3(N * C), dim3(T), 0, st, dy, x, y, mean_nc, m2_nc, dx, dx_psum, HW, eps, act, slope);
-    else if (E == 4) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<4>), dim3(N * C), dim3(T), 0, st, dy, x, y, mean_nc, m2_nc, dx, dx_psum, HW, eps, act, slope);
-    else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<16>), dim3(N * C), dim3(T), 0, st, dy, x, y, mean_nc, m2_nc, dx, dx_psum, HW, eps, act, slope);
+    PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_bwd<T>(E, NT, N * C, st, dy, x, y, mean_nc, m2_nc, dx, dx_psum, HW, eps, act, slope));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pcgan_bn_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
-                                  float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches,
-                                  int N, int C, int HW, float momentum, float eps, int act, float slope, pcgan_stream_t s) {
-    PCGAN_CHECK(x && y && mean_c && var_c && N > 0 && C > 0 && HW > 0 && (long long)N * HW > 1, "bn_fwd_fused: bad arguments");
-    if ((HW & 3) == 0)
-        hipLaunchKernelGGL(bn_fwd_fused_kernel<4>, dim3(C), dim3(256), 0, (hipStream_t)s, x, gamma, beta, residual, y, mean_c,
+template <typename T>
+static void launch_bn_fwd(bool v4, hipStream_t st, const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                          float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches, int N, int C, int HW,
+                          float momentum, float eps, int act, float slope) {
+    if (v4)
+        hipLaunchKernelGGL((bn_fwd_fused_kernel<4, T>), dim3(C), dim3(256), 0, st, (const T*)x, gamma, beta, (const T*)residual, (T*)y, mean_c,
                            var_c, running_mean, running_var, batches, N, C, HW, momentum, eps, act, slope);
     else
-        hipLaunchKernelGGL(bn_fwd_fused_kernel<1>, dim3(C), dim3(256), 0, (hipStream_t)s, x, gamma, beta, residual, y, mean_c,
+        hipLaunchKernelGGL((bn_fwd_fused_kernel<1, T>), dim3(C), dim3(256), 0, st, (const T*)x, gamma, beta, (const T*)residual, (T*)y, mean_c,
                            var_c, running_mean, running_var, batches, N, C, HW, momentum, eps, act, slope);
+}
+
+extern "C" int pcgan_bn_fwd_fused(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                                  float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches,
+                                  int N, int C, int HW, float momentum, float eps, int act, float slope, int dtype, pcgan_stream_t s) {
+    PCGAN_CHECK(x && y && mean_c && var_c && N > 0 && C > 0 && HW > 0 && (long long)N * HW > 1, "bn_fwd_fused: bad arguments");
+    PCGAN_DTYPE_SWITCH(dtype, T, launch_bn_fwd<T>((HW & 3) == 0, (hipStream_t)s, x, gamma, beta, residual, y, mean_c, var_c, running_mean,
+                                                  running_var, batches, N, C, HW, momentum, eps, act, slope));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pcgan_bn_bwd_fused(const float* dy, const float* x, const float* y, const float* mean_c, const float* var_c,
-                                  const float* gamma, float* dx, float* dres, float* s1_c, float* s2_c, int N, int C, int HW,
-                                  float eps, int act, float slope, pcgan_stream_t s) {
+template <typename T>
+static void launch_bn_bwd(bool v4, hipStream_t st, const void* dy, const void* x, const void* y, const float* mean_c, const float* var_c,
+                          const float* gamma, void* dx, void* dres, float* s1_c, float* s2_c, int N, int C, int HW, float eps, int act, float slope) {
+    if (v4)
+        hipLaunchKernelGGL((bn_bwd_fused_kernel<4, T>), dim3(C), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, mean_c, var_c, gamma,
+                           (T*)dx, (T*)dres, s1_c, s2_c, N, C, HW, eps, act, slope);
+    else
+        hipLaunchKernelGGL((bn_bwd_fused_kernel<1, T>), dim3(C), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, mean_c, var_c, gamma,
+                           (T*)dx, (T*)dres, s1_c, s2_c, N, C, HW, eps, act, slope);
+}
+
+extern "C" int pcgan_bn_bwd_fused(const void* dy, const void* x, const void* y, const float* mean_c, const float* var_c,
+                                  const float* gamma, void* dx, void* dres, float* s1_c, float* s2_c, int N, int C, int HW,
+                                  float eps, int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && x && mean_c && var_c && s1_c && s2_c && N > 0 && C > 0 && HW > 0, "bn_bwd_fused: bad arguments");
     PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "bn_bwd_fused: activation mask needs y");
-    if ((HW & 3) == 0)
-        hipLaunchKernelGGL(bn_bwd_fused_kernel<4>, dim3(C), dim3(256), 0, (hipStream_t)s, dy, x, y, mean_c, var_c, gamma, dx, dres,
-                           s1_c, s2_c, N, C, HW, eps, act, slope);
-    else
-        hipLaunchKernelGGL(bn_bwd_fused_kernel<1>, dim3(C), dim3(256), 0, (hipStream_t)s, dy, x, y, mean_c, var_c, gamma, dx, dres,
-                           s1_c, s2_c, N, C, HW, eps, act, slope);
+    PCGAN_DTYPE_SWITCH(dtype, T, launch_bn_bwd<T>((HW & 3) == 0, (hipStream_t)s, dy, x, y, mean_c, var_c, gamma, dx, dres, s1_c, s2_c, N, C, HW,
+                                                  eps, act, slope));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

@@ -10,14 +10,15 @@
 
 namespace pcgan {
 
-__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ arg,
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int32_t* __restrict__ arg,
                                    int H, int W, int k, int stride, int pad, int P, int Q, size_t total) {
     const size_t nc = blockIdx.y;   // plane; blockIdx.x = chunk of the output plane (32-bit index math)
     for (int me = blockIdx.x * blockDim.x + threadIdx.x; me < P * Q; me += gridDim.x * blockDim.x) {
         const int p = me / Q;
         const int q = me - p * Q;
         const size_t i = nc * (size_t)P * Q + me;
-        const float* xp = x + nc * (size_t)H * W;
+        const T* xp = x + nc * (size_t)H * W;
         const int y0 = p * stride - pad, x0 = q * stride - pad;
         float best = -FLT_MAX;
         int bi = -1;
@@ -27,19 +28,20 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
             for (int s = 0; s < k; ++s) {
                 const int ix = x0 + s;
                 if (ix < 0 || ix >= W) continue;
-                const float v = xp[iy * W + ix];
+                const float v = ld1(xp + iy * W + ix);
                 if (bi < 0 || v > best || v != v) {  // first maximum in scan order; NaN propagates
                     best = v;
                     bi = iy * W + ix;
                 }
             }
         }
-        y[i] = best;
+        st1(y + i, best);        // (a stored bf16 value is exact again in bf16: max of stored values)
         arg[i] = bi;
     }
 }
 
-__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, float* __restrict__ dx,
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ arg, T* __restrict__ dx,
                                    int H, int W, int k, int stride, int pad, int P, int Q, size_t total) {
     // blockIdx.y = plane, blockIdx.x = 256-element chunk of the plane: no 64-bit divisions per element
     const size_t nc = blockIdx.y;
@@ -60,23 +62,24 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* 
         const size_t ob = nc * (size_t)P * Q;
         for (int p = p_lo; p <= p_hi; ++p)
             for (int q = q_lo; q <= q_hi; ++q)
-                if (arg[ob + p * Q + q] == me) acc += dy[ob + p * Q + q];
-        dx[i] = acc;
+                if (arg[ob + p * Q + q] == me) acc += ld1(dy + ob + p * Q + q);
+        st1(dx + i, acc);
     }
 }
 
 // one wave per plane
-__global__ void global_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ arg,
+template <typename T>
+__global__ void global_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int32_t* __restrict__ arg,
                                        int NC, int HW, int is_max) {
     const int plane = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (plane >= NC) return;
     const int lane = threadIdx.x & 63;
-    const float* xp = x + (size_t)plane * HW;
+    const T* xp = x + (size_t)plane * HW;
     if (is_max) {
         float best = -FLT_MAX;
         int bi = 0x7fffffff;
         for (int i = lane; i < HW; i += 64) {
-            const float v = xp[i];
+            const float v = ld1(xp + i);
             if (v > best || (v == best && i < bi)) { best = v; bi = i; }
         }
         for (int o = 32; o > 0; o >>= 1) {
@@ -84,22 +87,23 @@ __global__ void global_pool_fwd_kernel(const float* __restrict__ x, float* __res
             const int oi = __shfl_xor(bi, o, 64);
             if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
         }
-        if (lane == 0) { y[plane] = best; arg[plane] = bi; }
+        if (lane == 0) { st1(y + plane, best); arg[plane] = bi; }
     } else {
         float s = 0.f;
-        for (int i = lane; i < HW; i += 64) s += xp[i];
+        for (int i = lane; i < HW; i += 64) s += ld1(xp + i);
         s = wave_sum(s);
-        if (lane == 0) y[plane] = s / (float)HW;
+        if (lane == 0) st1(y + plane, s / (float)HW);
     }
 }
 
-__global__ void global_pool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg,
-                                       float* __restrict__ dx, int HW, int is_max, size_t total) {
+template <typename T>
+__global__ void global_pool_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ arg,
+                                       T* __restrict__ dx, int HW, int is_max, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t plane = i / HW;
         const int e = (int)(i - plane * HW);
-        if (is_max) dx[i] = (arg[plane] == e) ? dy[plane] : 0.f;
-        else dx[i] = dy[plane] / (float)HW;
+        if (is_max) st1(dx + i, (arg[plane] == e) ? ld1(dy + plane) : 0.f);
+        else st1(dx + i, ld1(dy + plane) / (float)HW);
     }
 }
 
@@ -113,7 +117,8 @@ __device__ __forceinline__ void bilin_src(int dst, float scale, int in_size, int
     l1 = src - (float)i0;
 }
 
-__global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int P, int Q,
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int P, int Q,
                                     float sh, float sw, size_t total) {
     const size_t nc = blockIdx.y;   // plane; blockIdx.x = chunk of the output plane (32-bit index math)
     for (int me = blockIdx.x * blockDim.x + threadIdx.x; me < P * Q; me += gridDim.x * blockDim.x) {
@@ -125,14 +130,16 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restri
         bilin_src(p, sh, H, y0, y1, ly);
         bilin_src(q, sw, W, x0, x1, lx);
         const float hy = 1.f - ly, hx = 1.f - lx;
-        const float* xp = x + nc * (size_t)H * W;
-        y[i] = hy * (hx * xp[y0 * W + x0] + lx * xp[y0 * W + x1]) + ly * (hx * xp[y1 * W + x0] + lx * xp[y1 * W + x1]);
+        const T* xp = x + nc * (size_t)H * W;
+        st1(y + i, hy * (hx * ld1(xp + y0 * W + x0) + lx * ld1(xp + y0 * W + x1)) +
+                       ly * (hx * ld1(xp + y1 * W + x0) + lx * ld1(xp + y1 * W + x1)));
     }
 }
 
 // gather form of the backward: for input row iy the output rows p whose (y0,y1) touch it
 // lie in [ceil((iy-1)/sh), floor((iy+1)/sh)]; every candidate is re-derived exactly.
-__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int P, int Q,
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int P, int Q,
                                     float sh, float sw, size_t total) {
     const size_t nc = blockIdx.y;   // plane; blockIdx.x = chunk of the plane (32-bit index math)
     for (int me = blockIdx.x * blockDim.x + threadIdx.x; me < H * W; me += gridDim.x * blockDim.x) {
@@ -152,7 +159,7 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restr
             if (q_lo < 0) q_lo = 0;
             if (q_hi > Q - 1) q_hi = Q - 1;
         }
-        const float* dp = dy + nc * (size_t)P * Q;
+        const T* dp = dy + nc * (size_t)P * Q;
         float acc = 0.f;
         for (int p = p_lo; p <= p_hi; ++p) {
             int y0, y1;
@@ -169,10 +176,10 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restr
                 float wx = 0.f;
                 if (x0 == ix) wx += 1.f - lx;
                 if (x1 == ix) wx += lx;
-                if (wx != 0.f) acc += wy * wx * dp[p * Q + q];
+                if (wx != 0.f) acc += wy * wx * ld1(dp + p * Q + q);
             }
         }
-        dx[i] = acc;
+        st1(dx + i, acc);
     }
 }
 
@@ -185,71 +192,71 @@ static inline int ew_blocks(size_t n) {
 
 using namespace pcgan;
 
-extern "C" int pcgan_maxpool_fwd(const float* x, float* y, int32_t* argmax, int NC, int H, int W, int k, int stride,
-                                 int pad, int P, int Q, pcgan_stream_t s) {
+extern "C" int pcgan_maxpool_fwd(const void* x, void* y, int32_t* argmax, int NC, int H, int W, int k, int stride,
+                                 int pad, int P, int Q, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(x && y && argmax && NC > 0 && H > 0 && W > 0 && k > 0 && stride > 0, "maxpool_fwd: bad arguments");
     PCGAN_CHECK(P == (H + 2 * pad - k) / stride + 1 && Q == (W + 2 * pad - k) / stride + 1,
                 "maxpool_fwd: output dims do not match (floor mode)");
     const size_t total = (size_t)NC * P * Q;
     PCGAN_CHECK(NC <= 65535, "maxpool_fwd: more than 65535 planes");
     const int bx = (P * Q + 255) / 256;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s, x, y, argmax, H, W, k,
-                       stride, pad, P, Q, total);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s,
+                                                    (const T*)x, (T*)y, argmax, H, W, k, stride, pad, P, Q, total));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pcgan_maxpool_bwd(const float* dy, const int32_t* argmax, float* dx, int NC, int H, int W, int k,
-                                 int stride, int pad, int P, int Q, pcgan_stream_t s) {
+extern "C" int pcgan_maxpool_bwd(const void* dy, const int32_t* argmax, void* dx, int NC, int H, int W, int k,
+                                 int stride, int pad, int P, int Q, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && argmax && dx && NC > 0, "maxpool_bwd: bad arguments");
     const size_t total = (size_t)NC * H * W;
     PCGAN_CHECK(NC <= 65535, "maxpool_bwd: more than 65535 planes");
     const int bx = (H * W + 255) / 256;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s, dy, argmax, dx, H, W,
-                       k, stride, pad, P, Q, total);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s,
+                                                    (const T*)dy, argmax, (T*)dx, H, W, k, stride, pad, P, Q, total));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pcgan_global_pool_fwd(const float* x, float* y, int32_t* argmax, int NC, int HW, int is_max,
+extern "C" int pcgan_global_pool_fwd(const void* x, void* y, int32_t* argmax, int NC, int HW, int is_max, int dtype,
                                      pcgan_stream_t s) {
     PCGAN_CHECK(x && y && NC > 0 && HW > 0 && (!is_max || argmax), "global_pool_fwd: bad arguments");
-    hipLaunchKernelGGL(global_pool_fwd_kernel, dim3((NC + 3) / 4), dim3(256), 0, (hipStream_t)s, x, y, argmax, NC, HW,
-                       is_max);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(global_pool_fwd_kernel<T>, dim3((NC + 3) / 4), dim3(256), 0, (hipStream_t)s, (const T*)x,
+                                                    (T*)y, argmax, NC, HW, is_max));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pcgan_global_pool_bwd(const float* dy, const int32_t* argmax, float* dx, int NC, int HW, int is_max,
+extern "C" int pcgan_global_pool_bwd(const void* dy, const int32_t* argmax, void* dx, int NC, int HW, int is_max, int dtype,
                                      pcgan_stream_t s) {
     PCGAN_CHECK(dy && dx && NC > 0 && HW > 0 && (!is_max || argmax), "global_pool_bwd: bad arguments");
     const size_t total = (size_t)NC * HW;
-    hipLaunchKernelGGL(global_pool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, dy, argmax, dx, HW,
-                       is_max, total);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(global_pool_bwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s,
+                                                    (const T*)dy, argmax, (T*)dx, HW, is_max, total));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
-extern "C" int pcgan_bilinear_fwd(const float* x, float* y, int NC, int H, int W, int P, int Q, pcgan_stream_t s) {
+extern "C" int pcgan_bilinear_fwd(const void* x, void* y, int NC, int H, int W, int P, int Q, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(x && y && NC > 0 && H > 0 && W > 0 && P > 0 && Q > 0, "bilinear_fwd: bad arguments");
     const size_t total = (size_t)NC * P * Q;
     PCGAN_CHECK(NC <= 65535, "bilinear_fwd: more than 65535 planes");
     const int bx = (P * Q + 255) / 256;
-    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s, x, y, H, W, P, Q,
-                       ac_scale(H, P), ac_scale(W, Q), total);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s,
+                                                    (const T*)x, (T*)y, H, W, P, Q, ac_scale(H, P), ac_scale(W, Q), total));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pcgan_bilinear_bwd(const float* dy, float* dx, int NC, int H, int W, int P, int Q, pcgan_stream_t s) {
+extern "C" int pcgan_bilinear_bwd(const void* dy, void* dx, int NC, int H, int W, int P, int Q, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && dx && NC > 0 && H > 0 && W > 0 && P > 0 && Q > 0, "bilinear_bwd: bad arguments");
     const size_t total = (size_t)NC * H * W;
     PCGAN_CHECK(NC <= 65535, "bilinear_bwd: more than 65535 planes");
     const int bx = (H * W + 255) / 256;
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s, dy, dx, H, W, P, Q,
-                       ac_scale(H, P), ac_scale(W, Q), total);
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s,
+                                                    (const T*)dy, (T*)dx, H, W, P, Q, ac_scale(H, P), ac_scale(W, Q), total));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

@@ -368,6 +368,23 @@ def upsample2d(x, size):
     return _BilinearFn.apply(x, int(size))
 
 
+# ---------------------------------------------------------------------------- storage casts (bf16 path boundary)
+class _CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return ops.cast(_c(x), dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.cast(_c(dy), ctx.src), None
+
+
+def cast(x, dtype):
+    """x in another activation storage type (torch.float32 / torch.bfloat16), differentiable; identity if it already is"""
+    return x if x.dtype == dtype else _CastFn.apply(x, dtype)
+
+
 # ---------------------------------------------------------------------------- losses
 class _LossFn(torch.autograd.Function):
     @staticmethod

@@ -1,7 +1,7 @@
 """ctypes binding of libpcgan_hip.so (the C-ABI declared in include/pcgan_hip.h).
 
 The library is the product path: there is no CPU or eager-PyTorch fallback.  If the
-shared object is missing or a tensor is not a contiguous fp32 tensor on an AMD GPU the
+shared object is missing or a tensor is not a contiguous fp32 / bf16 tensor on an AMD GPU the
 call raises -- loudly -- instead of computing something else.
 """
 import ctypes
@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get('PCGAN_LIB') or os.path.join(os.path.dirname(_HERE), '
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PASS_FWD, PASS_BWD_DATA, PASS_BWD_WEIGHT = 0, 1, 2
+F32, BF16 = 0, 1          # storage type of activation tensors (include/pcgan_hip.h)
 
 
 class ImageDesc(ctypes.Structure):
@@ -22,7 +23,7 @@ class ImageDesc(ctypes.Structure):
 class ConvDesc(ctypes.Structure):
     """pcgan_conv_desc (include/pcgan_hip.h)."""
     _fields_ = [(n, ctypes.c_int) for n in
-                ('N', 'C', 'H', 'W', 'K', 'R', 'S', 'stride', 'pad', 'pad_mode', 'P', 'Q')]
+                ('N', 'C', 'H', 'W', 'K', 'R', 'S', 'stride', 'pad', 'pad_mode', 'P', 'Q', 'dtype')]
 
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -43,35 +44,36 @@ SIGNATURES = {
     'pcgan_conv2d_fwd_packed': (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
     'pcgan_conv2d_bwd_data_packed': (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pcgan_conv2d_bwd_weight': (_i, [_dp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
-    'pcgan_channel_sum': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'pcgan_act_bwd': (_i, [_vp, _vp, _vp, _sz, _i, _f, _vp]),
-    'pcgan_act_fwd': (_i, [_vp, _vp, _sz, _i, _f, _vp]),
-    'pcgan_concat_z': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'pcgan_add': (_i, [_vp, _vp, _vp, _sz, _vp]),
-    'pcgan_scale': (_i, [_vp, _vp, _f, _vp, _sz, _vp]),
-    'pcgan_channel_scale': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
-    'pcgan_plane_stats': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'pcgan_channel_sum': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_act_bwd': (_i, [_vp, _vp, _vp, _sz, _i, _f, _i, _vp]),
+    'pcgan_act_fwd': (_i, [_vp, _vp, _sz, _i, _f, _i, _vp]),
+    'pcgan_concat_z': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_add': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    'pcgan_scale': (_i, [_vp, _vp, _f, _vp, _sz, _i, _vp]),
+    'pcgan_cast': (_i, [_vp, _i, _vp, _i, _sz, _vp]),
+    'pcgan_channel_scale': (_i, [_vp, _vp, _vp, _i, _i, _f, _i, _vp]),
+    'pcgan_plane_stats': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'pcgan_bn_merge': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     'pcgan_in_running_update': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
-    'pcgan_norm_act_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp]),
-    'pcgan_norm_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp]),
-    'pcgan_norm_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp]),
+    'pcgan_norm_act_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
+    'pcgan_norm_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
+    'pcgan_norm_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
     'pcgan_bn_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
-    'pcgan_bn_fwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _vp]),
-    'pcgan_bn_bwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
-    'pcgan_instnorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
-    'pcgan_instnorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
+    'pcgan_bn_fwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _i, _vp]),
+    'pcgan_bn_bwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
+    'pcgan_instnorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
+    'pcgan_instnorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
     'pcgan_instnorm_fused': (_i, [_i]),
     'pcgan_sum_planes': (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    'pcgan_maxpool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    'pcgan_maxpool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    'pcgan_global_pool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
-    'pcgan_global_pool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
-    'pcgan_bilinear_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'pcgan_bilinear_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'pcgan_bce_loss': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),
-    'pcgan_l1_loss': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _vp, _sz, _vp]),
-    'pcgan_mse_loss': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _vp, _sz, _vp]),
+    'pcgan_maxpool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_maxpool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_global_pool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'pcgan_global_pool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'pcgan_bilinear_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_bilinear_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pcgan_bce_loss': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _i, _vp]),
+    'pcgan_l1_loss': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _vp, _sz, _i, _vp]),
+    'pcgan_mse_loss': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _vp, _sz, _i, _vp]),
     'pcgan_loss_workspace_bytes': (_sz, [_sz]),
     'pcgan_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _vp]),
     'pcgan_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _f, _f, _f, _vp]),

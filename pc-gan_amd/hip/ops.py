@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import lib as _L
-from .lib import ConvDesc, ACT_NONE
+from .lib import ConvDesc, ACT_NONE, F32, BF16
 
 _vp = ctypes.c_void_p
 
@@ -22,6 +22,7 @@ def _stream():
 
 
 def _chk(*tensors):
+    """fp32 tensors (parameters, statistics, per-sample targets ...): contiguous, on the GPU"""
     for t in tensors:
         if t is None:
             continue
@@ -33,6 +34,38 @@ def _chk(*tensors):
             raise RuntimeError('pcgan_amd: tensor must be contiguous')
 
 
+_DTYPES = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _act(*tensors):
+    """ACTIVATION tensors (and their gradients): fp32 or bf16 storage, all of one type; returns the C-ABI dtype code"""
+    code = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('pcgan_amd: tensor on %s -- the HIP path needs GPU tensors (no CPU fallback)' % t.device)
+        c = _DTYPES.get(t.dtype)
+        if c is None:
+            raise RuntimeError('pcgan_amd: activation tensors are float32 or bfloat16, got %s' % t.dtype)
+        if code is not None and c != code:
+            raise RuntimeError('pcgan_amd: activation tensors of one call must share a storage type (float32 and bfloat16 mixed)')
+        code = c
+        if not t.is_contiguous():
+            raise RuntimeError('pcgan_amd: tensor must be contiguous')
+    return F32 if code is None else code
+
+
+def cast(x, dtype):
+    """storage cast fp32 <-> bf16 (round to nearest even): the bf16 path's boundary"""
+    src = _act(x)
+    if x.dtype == dtype:
+        return x
+    y = torch.empty_like(x, dtype=dtype)
+    _L.check(_L.load().pcgan_cast(_p(x), src, _p(y), _DTYPES[dtype], x.numel(), _stream()), 'cast')
+    return y
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -41,9 +74,9 @@ def conv_out_size(H, k, stride, pad):
     return (H + 2 * pad - k) // stride + 1
 
 
-def make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode):
+def make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode, dtype=F32):
     return ConvDesc(N, C, H, W, K, R, S, stride, pad, pad_mode,
-                    conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad))
+                    conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad), dtype)
 
 
 # ---------------------------------------------------------------- side stream for parameter gradients
@@ -166,7 +199,7 @@ PASS_BWD_BSPLIT = 101
 
 
 def _packed_weights(lib, d, pass_, w, cache):
-    key = (pass_, d.stride, d.pad, d.pad_mode)
+    key = (pass_, d.stride, d.pad, d.pad_mode, d.dtype)
     stamp = (_PACK_EPOCH[0], w._version, w.data_ptr(), tuple(w.shape))
     cur = torch.cuda.current_stream()
     ent = cache.get(key)
@@ -204,18 +237,19 @@ def _packed_weights(lib, d, pass_, w, cache):
 def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pack_cache=None):
     """pack_cache: a dict owned by the caller (one per weight tensor) that keeps the packed weights between
     calls; None packs inside the call."""
-    _chk(x, w, bias)
+    _chk(w, bias)
+    dt = _act(x)
     lib = _L.load()
     N, C, H, W = x.shape
     K, C2, R, S = w.shape
     assert C == C2, 'conv2d_fwd: channel mismatch %d vs %d' % (C, C2)
-    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode)
-    y = torch.empty((N, K, d.P, d.Q), dtype=torch.float32, device=x.device)
+    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
+    y = torch.empty((N, K, d.P, d.Q), dtype=x.dtype, device=x.device)
     nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_FWD)
     ws = _ws(nb, x.device)
     if pack_cache is not None:
         # (one tile shape, no split-K yet: only where whole 128 x 128 tiles fill the chip, i.e. the residual-block convolutions)
-        bsplit = BF16X6 and K % 128 == 0 and N * d.P * d.Q >= 16384 and lib.pcgan_conv2d_bsplit_supported(ctypes.byref(d))
+        bsplit = (BF16X6 or dt == BF16) and K % 128 == 0 and N * d.P * d.Q >= 16384 and lib.pcgan_conv2d_bsplit_supported(ctypes.byref(d))
         pk = _packed_weights(lib, d, PASS_FWD_BSPLIT if bsplit else _L.PASS_FWD, w, pack_cache)
         ev = None
         if KERNEL_TIMER is not None and KERNEL_TIMER['key'] == (N, C, H, W, K, R, S, stride, pad, pad_mode):
@@ -238,19 +272,20 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
 
 def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache=None):
     """dx[N][C][H][W] for a conv with weight w[K][C][R][S]; in_hw = (H, W) of the conv input."""
-    _chk(dy, w, bias)
+    _chk(w, bias)
+    dt = _act(dy)
     lib = _L.load()
     N, K, P, Q = dy.shape
     K2, C, R, S = w.shape
     assert K == K2, 'conv2d_bwd_data: channel mismatch'
     H, W = in_hw
-    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode)
+    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
     assert (d.P, d.Q) == (P, Q), 'conv2d_bwd_data: geometry mismatch %s vs %s' % ((d.P, d.Q), (P, Q))
-    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device)
     nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_BWD_DATA)
     ws = _ws(nb, dy.device)
     if pack_cache is not None:
-        if BF16X6 and bias is None and C % 128 == 0 and N * H * W >= 16384 and lib.pcgan_conv2d_bsplit_dgrad_supported(ctypes.byref(d)):
+        if (BF16X6 or dt == BF16) and bias is None and C % 128 == 0 and N * H * W >= 16384 and lib.pcgan_conv2d_bsplit_dgrad_supported(ctypes.byref(d)):
             pk = _packed_weights(lib, d, PASS_BWD_BSPLIT, w, pack_cache)
             _L.check(lib.pcgan_conv2d_bwd_data_bsplit(ctypes.byref(d), _p(dy), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_bsplit')
             return dx
@@ -265,19 +300,20 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
 
 def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=None):
     """dw, or -- with accumulate_into = the parameter's gradient buffer -- `accumulate_into += dw` in place."""
-    _chk(x, dy, accumulate_into)
+    _chk(accumulate_into)
+    dt = _act(x, dy)
     lib = _L.load()
     N, C, H, W = x.shape
     K, C2, R, S = w_shape
     assert C == C2 and dy.shape[1] == K
-    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode)
+    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
     assert (d.P, d.Q) == tuple(dy.shape[2:]), 'conv2d_bwd_weight: geometry mismatch'
     if accumulate_into is not None:
         assert tuple(accumulate_into.shape) == (K, C, R, S)
         dw = accumulate_into
     else:
         dw = torch.empty((K, C, R, S), dtype=torch.float32, device=x.device)
-    if BF16X6 and K in (128, 256) and N * H * W >= 16384 and lib.pcgan_conv2d_bsplit_wgrad_supported(ctypes.byref(d)):
+    if (BF16X6 or dt == BF16) and K in (128, 256) and N * H * W >= 16384 and lib.pcgan_conv2d_bsplit_wgrad_supported(ctypes.byref(d)):
         ws = _ws(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
         _L.check(lib.pcgan_conv2d_bwd_weight_bsplit(ctypes.byref(d), _p(x), _p(dy), _p(dw), int(accumulate_into is not None),
                                                     _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight_bsplit')
@@ -291,7 +327,8 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=N
 
 # ---------------------------------------------------------------- pointwise
 def channel_sum(x, accumulate_into=None):
-    _chk(x, accumulate_into)
+    _chk(accumulate_into)
+    dt = _act(x)
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     out = accumulate_into if accumulate_into is not None else torch.empty(C, dtype=torch.float32, device=x.device)
@@ -304,66 +341,69 @@ def channel_sum(x, accumulate_into=None):
         return out
     PLANE_SUM_STATS['full'] += 1
     scratch = torch.empty(N * C, dtype=torch.float32, device=x.device)
-    _L.check(_L.load().pcgan_channel_sum(_p(x), _p(out), _p(scratch), N, C, HW, int(accumulate_into is not None),
+    _L.check(_L.load().pcgan_channel_sum(_p(x), _p(out), _p(scratch), N, C, HW, int(accumulate_into is not None), dt,
                                          _stream()), 'channel_sum')
     return out
 
 
 def act_fwd(x, act, slope=0.0):
-    _chk(x)
+    dt = _act(x)
     y = torch.empty_like(x)
-    _L.check(_L.load().pcgan_act_fwd(_p(x), _p(y), x.numel(), act, float(slope), _stream()), 'act_fwd')
+    _L.check(_L.load().pcgan_act_fwd(_p(x), _p(y), x.numel(), act, float(slope), dt, _stream()), 'act_fwd')
     return y
 
 
 def act_bwd(dy, y, act, slope=0.0):
-    _chk(dy, y)
+    dt = _act(dy, y)
     dx = torch.empty_like(dy)
-    _L.check(_L.load().pcgan_act_bwd(_p(dy), _p(y), _p(dx), dy.numel(), act, float(slope), _stream()), 'act_bwd')
+    _L.check(_L.load().pcgan_act_bwd(_p(dy), _p(y), _p(dx), dy.numel(), act, float(slope), dt, _stream()), 'act_bwd')
     return dx
 
 
 def add(a, b):
-    _chk(a, b)
+    dt = _act(a, b)
     assert a.shape == b.shape
     y = torch.empty_like(a)
-    _L.check(_L.load().pcgan_add(_p(a), _p(b), _p(y), a.numel(), _stream()), 'add')
+    _L.check(_L.load().pcgan_add(_p(a), _p(b), _p(y), a.numel(), dt, _stream()), 'add')
     return y
 
 
 def scale(x, scalar_dev=None, alpha=1.0):
-    _chk(x, scalar_dev)
+    _chk(scalar_dev)
+    dt = _act(x)
     y = torch.empty_like(x)
-    _L.check(_L.load().pcgan_scale(_p(x), _p(scalar_dev), float(alpha), _p(y), x.numel(), _stream()), 'scale')
+    _L.check(_L.load().pcgan_scale(_p(x), _p(scalar_dev), float(alpha), _p(y), x.numel(), dt, _stream()), 'scale')
     return y
 
 
 def concat_z(img, z):
-    _chk(img, z)
+    _chk(z)                   # ratings stay fp32
+    dt = _act(img)
     N, C, H, W = img.shape
     zb, nz = z.shape[0], z.shape[1]
-    out = torch.empty((N, C + nz, H, W), dtype=torch.float32, device=img.device)
-    _L.check(_L.load().pcgan_concat_z(_p(img), _p(z), _p(out), N, C, nz, H * W, zb, _stream()), 'concat_z')
+    out = torch.empty((N, C + nz, H, W), dtype=img.dtype, device=img.device)
+    _L.check(_L.load().pcgan_concat_z(_p(img), _p(z), _p(out), N, C, nz, H * W, zb, dt, _stream()), 'concat_z')
     return out
 
 
 def channel_scale(x, mask_nc, scale_):
-    _chk(x, mask_nc)
+    _chk(mask_nc)
+    dt = _act(x)
     N, C = x.shape[0], x.shape[1]
     y = torch.empty_like(x)
-    _L.check(_L.load().pcgan_channel_scale(_p(x), _p(mask_nc), _p(y), N * C, x.numel() // (N * C), float(scale_),
+    _L.check(_L.load().pcgan_channel_scale(_p(x), _p(mask_nc), _p(y), N * C, x.numel() // (N * C), float(scale_), dt,
                                            _stream()), 'channel_scale')
     return y
 
 
 # ---------------------------------------------------------------- normalisation
 def plane_stats(x):
-    _chk(x)
+    dt = _act(x)
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
     m2 = torch.empty(N * C, dtype=torch.float32, device=x.device)
-    _L.check(_L.load().pcgan_plane_stats(_p(x), _p(mean), _p(m2), N * C, HW, _stream()), 'plane_stats')
+    _L.check(_L.load().pcgan_plane_stats(_p(x), _p(mean), _p(m2), N * C, HW, dt, _stream()), 'plane_stats')
     return mean, m2
 
 
@@ -383,24 +423,26 @@ def in_running_update(mean_nc, m2_nc, running_mean, running_var, N, C, HW, momen
 
 
 def norm_act_fwd(x, mean, var, gamma, beta, residual, per_plane, eps, act, slope):
-    _chk(x, mean, var, gamma, beta, residual)
+    _chk(mean, var, gamma, beta)
+    dt = _act(x, residual)
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     y = torch.empty_like(x)
     _L.check(_L.load().pcgan_norm_act_fwd(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(residual), _p(y), N, C,
-                                          HW, int(per_plane), float(eps), act, float(slope), _stream()),
+                                          HW, int(per_plane), float(eps), act, float(slope), dt, _stream()),
              'norm_act_fwd')
     return y
 
 
 def norm_bwd_stats(dy, x, y, mean, var, per_plane, eps, act, slope):
-    _chk(dy, x, y, mean, var)
+    _chk(mean, var)
+    dt = _act(dy, x, y)
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     s1 = torch.empty(N * C, dtype=torch.float32, device=x.device)
     s2 = torch.empty(N * C, dtype=torch.float32, device=x.device)
     _L.check(_L.load().pcgan_norm_bwd_stats(_p(dy), _p(x), _p(y), _p(mean), _p(var), _p(s1), _p(s2), N, C, HW,
-                                            int(per_plane), float(eps), act, float(slope), _stream()),
+                                            int(per_plane), float(eps), act, float(slope), dt, _stream()),
              'norm_bwd_stats')
     return s1, s2
 
@@ -414,14 +456,15 @@ def bn_bwd_reduce(s1_nc, s2_nc, N, C):
 
 
 def norm_bwd_apply(dy, x, y, mean, var, gamma, s1, s2, per_plane, eps, act, slope, want_residual_grad):
-    _chk(dy, x, y, mean, var, gamma, s1, s2)
+    _chk(mean, var, gamma, s1, s2)
+    dt = _act(dy, x, y)
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_residual_grad else None
     _L.check(_L.load().pcgan_norm_bwd_apply(_p(dy), _p(x), _p(y), _p(mean), _p(var), _p(gamma), _p(s1), _p(s2),
                                             _p(dx), _p(dres), N, C, HW, int(per_plane), float(eps), act,
-                                            float(slope), _stream()), 'norm_bwd_apply')
+                                            float(slope), dt, _stream()), 'norm_bwd_apply')
     return dx, dres
 
 
@@ -430,7 +473,8 @@ BN_FUSED_MAX = int(os.environ.get('PCGAN_BN_FUSED_MAX', 8192))   # elements per 
 
 def bn_fwd_fused(x, gamma, beta, residual, running_mean, running_var, batches, momentum, eps, act, slope):
     """training-mode BatchNorm2d (+ residual + activation) of a small tensor in one launch; returns y, mean, var (biased)"""
-    _chk(x, gamma, beta, residual, running_mean, running_var)
+    _chk(gamma, beta, running_mean, running_var)
+    dt = _act(x, residual)
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     y = torch.empty_like(x)
@@ -440,12 +484,13 @@ def bn_fwd_fused(x, gamma, beta, residual, running_mean, running_var, batches, m
         assert batches.dtype == torch.int64 and batches.is_cuda
     _L.check(_L.load().pcgan_bn_fwd_fused(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(mean), _p(var), _p(running_mean),
                                           _p(running_var), _p(batches), N, C, HW, float(momentum), float(eps), act, float(slope),
-                                          _stream()), 'bn_fwd_fused')
+                                          dt, _stream()), 'bn_fwd_fused')
     return y, mean, var
 
 
 def bn_bwd_fused(dy, x, y, mean, var, gamma, eps, act, slope, want_dx, want_dres):
-    _chk(dy, x, y, mean, var, gamma)
+    _chk(mean, var, gamma)
+    dt = _act(dy, x, y)
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     dx = torch.empty_like(x) if want_dx else None
@@ -453,20 +498,20 @@ def bn_bwd_fused(dy, x, y, mean, var, gamma, eps, act, slope, want_dx, want_dres
     s1 = torch.empty(C, dtype=torch.float32, device=x.device)
     s2 = torch.empty(C, dtype=torch.float32, device=x.device)
     _L.check(_L.load().pcgan_bn_bwd_fused(_p(dy), _p(x), _p(y), _p(mean), _p(var), _p(gamma), _p(dx), _p(dres), _p(s1), _p(s2),
-                                          N, C, HW, float(eps), act, float(slope), _stream()), 'bn_bwd_fused')
+                                          N, C, HW, float(eps), act, float(slope), dt, _stream()), 'bn_bwd_fused')
     return dx, dres, s1, s2
 
 
 def instnorm_fwd(x, residual, eps, act, slope):
     """fused instance norm forward: returns y, mean[N*C], m2[N*C]"""
-    _chk(x, residual)
+    dt = _act(x, residual)
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     y = torch.empty_like(x)
     mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
     m2 = torch.empty(N * C, dtype=torch.float32, device=x.device)
     _L.check(_L.load().pcgan_instnorm_fwd(_p(x), _p(residual), _p(y), _p(mean), _p(m2), N, C, HW, float(eps), act,
-                                          float(slope), _stream()), 'instnorm_fwd')
+                                          float(slope), dt, _stream()), 'instnorm_fwd')
     return y, mean, m2
 
 
@@ -476,7 +521,8 @@ PLANE_SUM_STATS = {'fused': 0, 'full': 0}     # bias gradients finished from pla
 def instnorm_bwd(dy, x, y, mean, m2, eps, act, slope):
     """dx; where the plane runs in the register-resident kernel dx also carries `_pcgan_plane_sums` ([N*C] sums of dx over
     each plane, free there): the convolution in front of the norm finishes its bias gradient from them (channel_sum)."""
-    _chk(dy, x, y, mean, m2)
+    _chk(mean, m2)
+    dt = _act(dy, x, y)
     lib = _L.load()
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
@@ -485,7 +531,7 @@ def instnorm_bwd(dy, x, y, mean, m2, eps, act, slope):
     psum = torch.empty(N * C, dtype=torch.float32, device=x.device) if fused else None
     ws = None if fused else torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
     _L.check(lib.pcgan_instnorm_bwd(_p(dy), _p(x), _p(y), _p(mean), _p(m2), _p(dx), _p(psum), _p(ws), N, C, HW, float(eps),
-                                    act, float(slope), _stream()), 'instnorm_bwd')
+                                    act, float(slope), dt, _stream()), 'instnorm_bwd')
     if psum is not None:
         dx._pcgan_plane_sums = psum
     return dx
@@ -493,97 +539,98 @@ def instnorm_bwd(dy, x, y, mean, m2, eps, act, slope):
 
 # ---------------------------------------------------------------- pooling / resize
 def maxpool_fwd(x, k, stride, pad):
-    _chk(x)
+    dt = _act(x)
     N, C, H, W = x.shape
     P, Q = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
-    y = torch.empty((N, C, P, Q), dtype=torch.float32, device=x.device)
+    y = torch.empty((N, C, P, Q), dtype=x.dtype, device=x.device)
     arg = torch.empty((N, C, P, Q), dtype=torch.int32, device=x.device)
-    _L.check(_L.load().pcgan_maxpool_fwd(_p(x), _p(y), _vp(arg.data_ptr()), N * C, H, W, k, stride, pad, P, Q,
+    _L.check(_L.load().pcgan_maxpool_fwd(_p(x), _p(y), _vp(arg.data_ptr()), N * C, H, W, k, stride, pad, P, Q, dt,
                                          _stream()), 'maxpool_fwd')
     return y, arg
 
 
 def maxpool_bwd(dy, arg, in_hw, k, stride, pad):
-    _chk(dy)
+    dt = _act(dy)
     N, C, P, Q = dy.shape
     H, W = in_hw
-    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
-    _L.check(_L.load().pcgan_maxpool_bwd(_p(dy), _vp(arg.data_ptr()), _p(dx), N * C, H, W, k, stride, pad, P, Q,
+    dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device)
+    _L.check(_L.load().pcgan_maxpool_bwd(_p(dy), _vp(arg.data_ptr()), _p(dx), N * C, H, W, k, stride, pad, P, Q, dt,
                                          _stream()), 'maxpool_bwd')
     return dx
 
 
 def global_pool_fwd(x, is_max):
-    _chk(x)
+    dt = _act(x)
     N, C, H, W = x.shape
-    y = torch.empty((N, C, 1, 1), dtype=torch.float32, device=x.device)
+    y = torch.empty((N, C, 1, 1), dtype=x.dtype, device=x.device)
     arg = torch.empty((N, C), dtype=torch.int32, device=x.device) if is_max else None
     _L.check(_L.load().pcgan_global_pool_fwd(_p(x), _p(y), _vp(arg.data_ptr()) if is_max else _vp(0), N * C, H * W,
-                                             int(is_max), _stream()), 'global_pool_fwd')
+                                             int(is_max), dt, _stream()), 'global_pool_fwd')
     return y, arg
 
 
 def global_pool_bwd(dy, arg, in_hw, is_max):
-    _chk(dy)
+    dt = _act(dy)
     N, C = dy.shape[0], dy.shape[1]
     H, W = in_hw
-    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device)
     _L.check(_L.load().pcgan_global_pool_bwd(_p(dy), _vp(arg.data_ptr()) if is_max else _vp(0), _p(dx), N * C, H * W,
-                                             int(is_max), _stream()), 'global_pool_bwd')
+                                             int(is_max), dt, _stream()), 'global_pool_bwd')
     return dx
 
 
 def bilinear_fwd(x, size):
-    _chk(x)
+    dt = _act(x)
     N, C, H, W = x.shape
     P, Q = size
-    y = torch.empty((N, C, P, Q), dtype=torch.float32, device=x.device)
-    _L.check(_L.load().pcgan_bilinear_fwd(_p(x), _p(y), N * C, H, W, P, Q, _stream()), 'bilinear_fwd')
+    y = torch.empty((N, C, P, Q), dtype=x.dtype, device=x.device)
+    _L.check(_L.load().pcgan_bilinear_fwd(_p(x), _p(y), N * C, H, W, P, Q, dt, _stream()), 'bilinear_fwd')
     return y
 
 
 def bilinear_bwd(dy, in_hw):
-    _chk(dy)
+    dt = _act(dy)
     N, C, P, Q = dy.shape
     H, W = in_hw
-    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
-    _L.check(_L.load().pcgan_bilinear_bwd(_p(dy), _p(dx), N * C, H, W, P, Q, _stream()), 'bilinear_bwd')
+    dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device)
+    _L.check(_L.load().pcgan_bilinear_bwd(_p(dy), _p(dx), N * C, H, W, P, Q, dt, _stream()), 'bilinear_bwd')
     return dx
 
 
 # ---------------------------------------------------------------- losses / optimizer
-def _loss(fn_name, a, b, n_or_N, per_n, want_grad):
+def _loss(fn_name, a, b, n_or_N, per_n, want_grad, dt):
     lib = _L.load()
-    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    loss = torch.empty((), dtype=torch.float32, device=a.device)       # the loss itself is always fp32
     grad = torch.empty_like(a) if want_grad else None
     ws = _ws(lib.pcgan_loss_workspace_bytes(a.numel()), a.device)
     fn = getattr(lib, fn_name)
     if fn_name == 'pcgan_bce_loss':
-        st = fn(_p(a), _p(b), _p(loss), _p(grad), n_or_N, per_n, 1.0, _p(ws), ws.numel(), _stream())
+        st = fn(_p(a), _p(b), _p(loss), _p(grad), n_or_N, per_n, 1.0, _p(ws), ws.numel(), dt, _stream())
     else:
-        st = fn(_p(a), _p(b), _p(loss), _p(grad), a.numel(), 1.0, _p(ws), ws.numel(), _stream())
+        st = fn(_p(a), _p(b), _p(loss), _p(grad), a.numel(), 1.0, _p(ws), ws.numel(), dt, _stream())
     _L.check(st, fn_name)
     return loss, grad
 
 
 def bce_loss(pred, target_n, want_grad=True):
     """mean BCE of pred[N][...] against target_n[N] broadcast over each sample."""
-    _chk(pred, target_n)
+    _chk(target_n)
+    dt = _act(pred)
     N = pred.shape[0]
     assert target_n.numel() == N
-    return _loss('pcgan_bce_loss', pred, target_n, N, pred.numel() // N, want_grad)
+    return _loss('pcgan_bce_loss', pred, target_n, N, pred.numel() // N, want_grad, dt)
 
 
 def l1_loss(a, b, want_grad=True):
-    _chk(a, b)
+    dt = _act(a, b)
     assert a.shape == b.shape
-    return _loss('pcgan_l1_loss', a, b, 0, 1, want_grad)
+    return _loss('pcgan_l1_loss', a, b, 0, 1, want_grad, dt)
 
 
 def mse_loss(a, b, want_grad=True):
-    _chk(a, b)
+    dt = _act(a, b)
     assert a.shape == b.shape
-    return _loss('pcgan_mse_loss', a, b, 0, 1, want_grad)
+    return _loss('pcgan_mse_loss', a, b, 0, 1, want_grad, dt)
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):

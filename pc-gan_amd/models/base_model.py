@@ -31,6 +31,14 @@ class BaseModel(object):
     def name(self):
         return 'BaseModel'
 
+    def to_act(self, image):
+        """a loader image batch on the device in the model's activation storage type (one cast kernel under --dtype bf16)"""
+        image = image.to(self.device, non_blocking=True)
+        if image.dtype != self.act_dtype and image.is_cuda:
+            from ..hip import ops
+            image = ops.cast(image.contiguous(), self.act_dtype)
+        return image
+
     def set_input(self, input):
         self.input = input
 
@@ -47,6 +55,8 @@ class BaseModel(object):
         self.gpu_ids = opt.gpu_ids
         self.use_gpu = bool(opt.gpu_ids) and torch.cuda.is_available()
         self.device = torch.device('cuda:%d' % opt.gpu_ids[0]) if opt.gpu_ids else torch.device('cpu')
+        # storage type of activations (build-only --dtype: fp32 | bf16); parameters, statistics, losses, Adam: always fp32
+        self.act_dtype = torch.bfloat16 if getattr(opt, 'dtype', 'fp32') == 'bf16' else torch.float32
         self.Tensor = torch.cuda.FloatTensor if self.use_gpu else torch.Tensor
         self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
         for attr in ('loss_names', 'model_names', 'load_model_names', 'visual_names', 'image_paths', 'optimizers'):

@@ -357,9 +357,11 @@ class SiameseFeature(tnn.Module):
     def forward(self, x):
         h = self.base.forward(x)
         out = run_sequential(self.cnn, h) if self.cnn is not None else h
-        out = self._pool(out)
+        # ratings leave the encoder as fp32 whatever the storage type of its activations (the bf16 path: the rating
+        # arithmetic of the step -- normalisation, resampling, bin look-ups, the z_rec loss -- stays fp32)
+        out = HF.cast(self._pool(out), torch.float32)
         if self._noisy:
-            return out, self._pool(run_sequential(self.cnn_logvar, h))
+            return out, HF.cast(self._pool(run_sequential(self.cnn_logvar, h)), torch.float32)
         return out
 
     def load_pretrained(self, state_dict):

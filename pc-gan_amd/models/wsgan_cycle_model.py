@@ -128,7 +128,7 @@ class WSGANCycleModel(BaseModel):
 
     # ------------------------------------------------------------------ the step (reference :148-256)
     def set_input(self, input):
-        self.real_x = input['A'].to(self.device, non_blocking=True)
+        self.real_x = self.to_act(input['A'])
         if self.isTrain:
             self.real_y = self.attr_normalize(input['B_attr'].to(self.device, non_blocking=True))
             self.image_paths = input['B_paths']

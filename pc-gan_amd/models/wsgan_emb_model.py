@@ -190,23 +190,23 @@ class WSGANEmbModel(BaseModel):
     def set_input(self, input):
         if self.isTrain:
             if not self.opt.no_mixed_label_D:
-                self.real_A = input['A'].to(self.device, non_blocking=True)
-                self.real_B = input['B'].to(self.device, non_blocking=True)
+                self.real_A = self.to_act(input['A'])
+                self.real_B = self.to_act(input['B'])
                 self.image_paths = input['B_paths']
                 self.label_AB = input['label']
             else:
                 L = int(np.random.choice(range(len(self.relabel_D)), p=self.weight_label_D))
                 self.label_AB = [L]
-                self.real_A = input[str(L) + '_A'].to(self.device, non_blocking=True)
-                self.real_B = input[str(L) + '_B'].to(self.device, non_blocking=True)
+                self.real_A = self.to_act(input[str(L) + '_A'])
+                self.real_B = self.to_act(input[str(L) + '_B'])
                 self.image_paths = input[str(L) + '_B_paths']
             lab = self.label_AB if isinstance(self.label_AB, torch.Tensor) else torch.as_tensor(self.label_AB)
             self._label_dev = lab.to(self.device, dtype=torch.int64, non_blocking=True).reshape(-1)
         else:
-            self.real_A = input['A'].to(self.device)
+            self.real_A = self.to_act(input['A'])
             self.image_paths = input['A_paths']
             if 'B' in input:
-                self.real_B = input['B'].to(self.device)
+                self.real_B = self.to_act(input['B'])
                 self.image_paths = input['B_paths']
         self.current_iter += 1
         self.current_batch_size = int(self.real_A.size(0))

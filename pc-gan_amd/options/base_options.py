@@ -66,6 +66,9 @@ _BASE_FLAGS = [
     ('--sorted', dict(action='store_true')),
     # build-only
     ('--seed', dict(type=int, default=None, help='(pcgan_amd) seed torch/numpy if given')),
+    ('--dtype', dict(type=str, default='fp32', choices=['fp32', 'bf16'],
+                     help='(pcgan_amd) storage type of activations and their gradients: fp32, or bf16 with fp32 master '
+                          'weights / accumulation / statistics / losses / Adam (BASELINE config 3)')),
     ('--local_rank', dict(type=int, default=None, help='(pcgan_amd) set by launchers; LOCAL_RANK env wins')),
     ('--gpu_transform', dict(action='store_true', help='(pcgan_amd) resize / crop / flip / normalise on the GPU '
                                                        '(bit-exact with the PIL path); workers only decode')),
