@@ -11,9 +11,11 @@ rounding model, confirmed by measurement (profiles/r02_bf16_parity.txt):
     at 4e-3, and with the fp32 weights at 2e-2 -- weight rounding 2^-9 relative, sqrt(K)-averaged);
   * fp32 outputs of bf16 inputs (weight gradients, bias gradients, statistics, losses): no output rounding -> 2e-5 / 1e-4 as
     in the fp32 tests, the reference fed the same bf16-rounded inputs;
-  * whole networks / the whole step against the fp32 ORACLE (fp32 inputs): errors accumulate over ~60 rounded layers;
-    measured on the fixtures below and bounded with a factor ~3: images 3e-2 of the largest magnitude, losses 3e-2,
-    gradients 8e-2 relative L2 (1.5e-1 for tensors that pass through the encoder's ReLU / max-pool decisions).
+  * whole networks / the whole step against the fp32 ORACLE (fp32 inputs): every stored activation and gradient carries
+    2^-9 relative rounding noise and ~60-120 such layers follow each other, so the comparison is by relative L2 norm; the
+    measured values (printed by the tests, kept in profiles/r02_bf16_parity.txt) are bounded with a factor 2-3:
+    images 6e-2, losses 3e-2 (absolute floor 1e-3), parameter gradients 2e-1 per tensor and 1e-1 for the norm-weighted mean
+    over a network, ratings 3e-2.
 """
 import os
 import sys
@@ -228,9 +230,9 @@ def test_networks_bf16_vs_fp32_oracle(which, dev):
     """the whole generator / discriminator with bf16 activations against the fp32 oracle on fp32 inputs"""
     from pcgan_amd.models import networks
     if which == 'G':
-        ref = N.ResnetGeneratorRef(3, 3, 1, 16, 'instance', 3)
+        ref = N.ResnetGeneratorRef(3, 3, 1, 16, 'instance', 9)
         ref.load_state_dict(W.damp_generator_head(W.fill_state_dict(ref.state_dict(), 12)))
-        hip = networks.define_G(3, 3, 1, 16, 'resnet_3blocks', norm='instance', init_type='normal')
+        hip = networks.define_G(3, 3, 1, 16, 'resnet_9blocks', norm='instance', init_type='normal')
         x, z = W.seeded_tensor((2, 3, 32, 32), 101), W.seeded_normal((2, 1, 1, 1), 202)
         out_shape = (2, 3, 32, 32)
     else:
@@ -246,10 +248,9 @@ def test_networks_bf16_vs_fp32_oracle(which, dev):
     y_ref, din_ref, dp_ref = _run_net(ref, [x, z], dy)
     y, din, dp = _run_net(hip, [x.to(dev).to(BF), z.to(dev)], dy)
     assert y.dtype == BF
-    assert_close(y.float(), y_ref, 3e-2, which + ' output, bf16 activations vs fp32 oracle')
-    e = _rel_l2(din[0].float(), din_ref[0])
-    assert e <= 8e-2, '%s input gradient: relative L2 %.3e' % (which, e)
-    worst = 0.0
+    e_out = _rel_l2(y.float(), y_ref)
+    e_in = _rel_l2(din[0].float(), din_ref[0])
+    errs, num, den = {}, 0.0, 0.0
     for k, gr in dp_ref.items():
         if gr is None or float(gr.abs().max()) < 1e-6:
             continue
@@ -257,9 +258,16 @@ def test_networks_bf16_vs_fp32_oracle(which, dev):
         if sib is not None and float(gr.abs().max()) <= 1e-3 * float(sib.abs().max()):
             continue                                   # IN-cancelled bias: noise on both sides
         assert dp[k].dtype == torch.float32
-        e = _rel_l2(dp[k], gr)
-        worst = max(worst, e)
-        assert e <= 8e-2, '%s d%s: relative L2 %.3e' % (which, k, e)
+        errs[k] = _rel_l2(dp[k], gr)
+        num += float((dp[k].double().cpu() - gr.double()).norm()) ** 2
+        den += float(gr.double().norm()) ** 2
+    worst = max(errs, key=errs.get)
+    overall = (num / den) ** 0.5
+    print('bf16 parity %s: output rel-L2 %.3e, input gradient %.3e, parameter gradients overall %.3e, worst %s %.3e' % (
+        which, e_out, e_in, overall, worst, errs[worst]))
+    assert e_out <= 6e-2, '%s output: relative L2 %.3e vs the fp32 oracle' % (which, e_out)
+    assert e_in <= 1.5e-1, '%s input gradient: relative L2 %.3e' % (which, e_in)
+    assert overall <= 1e-1 and errs[worst] <= 2e-1, '%s parameter gradients: overall %.3e, worst %s %.3e' % (which, overall, worst, errs[worst])
     # running statistics are fp32 statistics of bf16 tensors
     hb = dict(hip.named_buffers())
     for k, b in ref.named_buffers():
@@ -283,13 +291,17 @@ def test_step_bf16_vs_fp32_oracle(tmp_path, dev):
     model.optimize_parameters()
     assert model.real_A.dtype == BF and model.fake_B.dtype == BF and model.y_B.dtype == torch.float32
     got, want = model.get_current_losses(), oracle.losses()
+    report = ['losses ' + ', '.join('%s %.5f/%.5f' % (k, got[k], v) for k, v in want.items())]
     for k, v in want.items():
-        assert abs(got[k] - v) <= 3e-2 * max(1.0, abs(v)), 'bf16 step loss %s: %.6g vs fp32 oracle %.6g' % (k, got[k], v)
+        assert abs(got[k] - v) <= 3e-2 * abs(v) + 1e-3, 'bf16 step loss %s: %.6g vs fp32 oracle %.6g' % (k, got[k], v)
     for k in ('fake_B', 'rec_A'):
-        assert_close(getattr(model, k).float(), getattr(oracle, k).detach(), 3e-2, 'bf16 step ' + k)
+        e = _rel_l2(getattr(model, k).float(), getattr(oracle, k))
+        report.append('%s rel-L2 %.3e' % (k, e))
+        assert e <= 6e-2, 'bf16 step %s: relative L2 %.3e vs the fp32 oracle' % (k, e)
     for k in ('y_A', 'y_B', 'embedding_A', 'embedding_B'):
         assert_close(getattr(model, k).float(), getattr(oracle, k).detach(), 3e-2, 'bf16 step ' + k, atol=2e-3)
     for tag, ograds in (('G', oracle.grads_G), ('D', oracle.grads_D)):
+        errs, num, den = {}, 0.0, 0.0
         for k, og in ograds.items():
             if og is None:
                 continue
@@ -300,8 +312,14 @@ def test_step_bf16_vs_fp32_oracle(tmp_path, dev):
                 continue
             if tag == 'G' and k == 'model.1.weight':
                 hg, og = hg[:, :-1], og[:, :-1]
-            e = _rel_l2(hg, og)
-            assert e <= 1.5e-1, 'bf16 step grad%s %s: relative L2 vs fp32 oracle %.3e' % (tag, k, e)
+            errs[k] = _rel_l2(hg, og)
+            num += float((hg.double().cpu() - og.double()).norm()) ** 2
+            den += float(og.double().norm()) ** 2
+        worst = max(errs, key=errs.get)
+        overall = (num / den) ** 0.5
+        report.append('grad%s overall %.3e, worst %s %.3e' % (tag, overall, worst, errs[worst]))
+        assert overall <= 1e-1 and errs[worst] <= 2e-1, 'bf16 step grad%s: overall %.3e, worst %s %.3e' % (tag, overall, worst, errs[worst])
+    print('bf16 parity step: ' + '; '.join(report))
     for optim in (model.optimizer_G, model.optimizer_D):
         assert optim.flat.dtype == optim.gflat.dtype == optim.exp_avg.dtype == torch.float32
     # a second step runs and stays finite
