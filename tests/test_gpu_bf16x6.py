@@ -74,7 +74,7 @@ def test_host_switch_routes_large_convs_and_follows_the_weights(dev, monkeypatch
     ref = R.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1, 1)
     cache = {}
     y = ops.conv2d_fwd(x, w, None, 1, 1, 1, pack_cache=cache)
-    assert list(cache) == [(ops.PASS_FWD_BSPLIT, 1, 1, 1)]
+    assert list(cache) == [(ops.PASS_FWD_BSPLIT, 1, 1, 1, 0)]      # (pass, stride, pad, pad_mode, dtype)
     assert float((y.double().cpu() - ref).norm() / ref.norm()) < 3e-6
     assert not torch.equal(y, ops.conv2d_fwd(x, w, None, 1, 1, 1))            # another kernel: other low bits
     w.mul_(2.0)
@@ -82,7 +82,7 @@ def test_host_switch_routes_large_convs_and_follows_the_weights(dev, monkeypatch
     assert float((y2.double().cpu() - 2 * ref).norm() / ref.norm()) < 6e-6
     small = {}
     ops.conv2d_fwd(x[:1, :, :16, :16].contiguous(), w, None, 1, 1, 1, pack_cache=small)
-    assert list(small) == [(0, 1, 1, 1)]
+    assert list(small) == [(0, 1, 1, 1, 0)]
 
 
 @pytest.mark.parametrize('N,C,H,W,K', [

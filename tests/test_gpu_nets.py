@@ -1,9 +1,17 @@
 """GPU parity of the HIP-backed networks (define_G / define_D / define_E / define_IP) against
 (a) the golden vectors captured from the reference itself and (b) the oracle's float64 twin.
 
-Tolerances: activations / outputs rtol 1e-4; data gradients 2e-4; parameter
-gradients are judged against the fp64 twin: |g_hip - g64| <= 2 * |g_ref32 - g64| + tiny, with
-an absolute floor of 1e-6 for the biases an affine-less InstanceNorm cancels (true gradient 0).
+Tolerances: activations / outputs rtol 1e-4.  Gradients -- two checks, both run:
+
+  SHARP   against the float64 twin evaluated ON THE HIP RUN'S OWN DECISIONS: every ReLU / LeakyReLU sign mask and every
+          max-pool arg-max of the HIP forward pass is recorded (`record_decisions`) and replayed by the twin
+          (oracle.networks_ref.DecisionTape), so both sides differentiate the same smooth branch of the network: input and
+          parameter gradients to 5e-4 relative L2 (measured 1e-6 .. 1e-4), absolute floor 1e-6 for the tensors whose true
+          gradient is 0 (biases an affine-less InstanceNorm cancels).  A dropped tap, a wrong split-K partial or a 0.1 %
+          scaling error in any backward kernel fails this.
+  LOOSE   (labelled) against the twin's / the reference's OWN decisions at 3e-2 relative L2: a handful of pre-activations
+          within rounding of zero flip between implementations and move whole tensors by 1e-3 .. 1e-2 (one flip in
+          layer3.0 of the encoder: 1.2e-3); this band only guards against O(1) errors and documents the effect.
 """
 import os
 
@@ -32,6 +40,84 @@ def _run(net, inputs, seed_dy):
     return ys, [x.grad for x in xs], {k: p.grad for k, p in net.named_parameters()}
 
 
+class record_decisions(object):
+    """context manager: the HIP forward pass's discontinuous decisions, in call order -- (y > 0) of every fused or stand-alone
+    ReLU / LeakyReLU, the arg-max of every max pooling -- as CPU tensors in `.tape`"""
+
+    def __init__(self, nets=None):
+        """nets: {name: module} -- decisions are then filed per network in `.tapes[name]` (a training step interleaves
+        its networks); without it everything goes to `.tape`"""
+        self.nets = nets or {}
+
+    def __enter__(self):
+        from pcgan_amd.hip import functional as F, ops
+        from pcgan_amd.hip.lib import ACT_RELU, ACT_LRELU
+        self.tape, self.saved, self.hooks = [], [], []
+        self.tapes = {name: [] for name in self.nets}
+        rec = self
+
+        class _Sink(object):
+            """appends to the tape of the network whose forward() is running"""
+            current = None
+
+            def append(self_, t):
+                (rec.tapes[self_.current] if self_.current in rec.tapes else rec.tape).append(t)
+        tape = _Sink()
+        for name, net in self.nets.items():
+            def pre(mod, args, name=name):
+                tape.current = name
+
+            def post(mod, args, out):
+                tape.current = None
+            self.hooks += [net.register_forward_pre_hook(pre), net.register_forward_hook(post)]
+
+        def patch(mod, name, wrap):
+            orig = getattr(mod, name)
+            self.saved.append((mod, name, orig))
+            setattr(mod, name, wrap(orig))
+
+        def mask_of(act_index, kw_name):
+            def wrap(orig):
+                def f(*a, **kw):
+                    y = orig(*a, **kw)
+                    act = kw.get(kw_name, a[act_index] if len(a) > act_index else 0)
+                    if act in (ACT_RELU, ACT_LRELU):
+                        tape.append((y.detach() > 0).cpu())
+                    return y
+                return f
+            return wrap
+
+        patch(F, 'conv2d', mask_of(6, 'act'))
+        patch(F, 'instance_norm_act', mask_of(5, 'act'))
+        patch(F, 'batch_norm_act', mask_of(7, 'act'))
+        patch(F, 'activation', mask_of(1, 'act'))
+
+        def wrap_maxpool(orig):
+            def f(*a, **kw):
+                y, arg = orig(*a, **kw)
+                tape.append(arg.detach().cpu())
+                return y, arg
+            return f
+
+        def wrap_global(orig):
+            def f(x, is_max):
+                y, arg = orig(x, is_max)
+                if is_max:
+                    tape.append(arg.detach().cpu())
+                return y, arg
+            return f
+
+        patch(ops, 'maxpool_fwd', wrap_maxpool)
+        patch(ops, 'global_pool_fwd', wrap_global)
+        return self
+
+    def __exit__(self, *exc):
+        for mod, name, orig in reversed(self.saved):
+            setattr(mod, name, orig)
+        for h in self.hooks:
+            h.remove()
+
+
 def _assert_mostly_close(got, ref, name, rel_l2=3e-2):
     """Relative-L2 criterion for gradients that have passed through ReLU / max-pool decisions.
 
@@ -51,7 +137,33 @@ def _compare(hip_net, ref_net, inputs, seed_dy, dev, gold=None, prefix=None, out
     hip_net.load_state_dict(sd)
     hip_net.to(dev)
     ref64 = ref_net.double()
-    ys, dins, dps = _run(hip_net, [i.to(dev) for i in inputs], seed_dy)
+    with record_decisions() as rec:
+        ys, dins, dps = _run(hip_net, [i.to(dev) for i in inputs], seed_dy)
+    # SHARP check: the float64 twin on the HIP run's decisions (a copy of the twin: its running statistics must move once only)
+    import copy
+    twin_r = copy.deepcopy(ref64)
+    N.DecisionTape.replay = iter(rec.tape)
+    try:
+        ys_r, dins_r, dps_r = _run(twin_r, [i.double() for i in inputs], seed_dy)
+        assert next(N.DecisionTape.replay, None) is None, 'the twin consumed fewer decisions than the HIP pass recorded'
+    finally:
+        N.DecisionTape.replay = None
+    sharp = 5e-4
+    for j, (a, b) in enumerate(zip(ys, ys_r)):
+        assert_close(a, b, out_tol, 'out%d vs fp64 twin on the HIP decisions' % j)
+    for j, (a, b) in enumerate(zip(dins, dins_r)):
+        if float(b.abs().max()) < 1e-9:
+            assert float(a.abs().max()) < 1e-3, 'din%d should be ~0' % j
+            continue
+        _assert_mostly_close(a, b, 'SHARP din%d vs fp64 twin on the HIP decisions' % j, sharp)
+    wmax = max(float(g.abs().max()) for g in dps_r.values() if g is not None)
+    for k, g in dps.items():
+        gr = dps_r[k]
+        if float(gr.abs().max()) < 1e-5 * wmax:
+            assert float(g.abs().max()) < 1e-3 * wmax + 1e-6, 'd%s should be ~0' % k       # cancelled by a following norm
+            continue
+        _assert_mostly_close(g, gr, 'SHARP d%s vs fp64 twin on the HIP decisions' % k, sharp)
+    # LOOSE (labelled) checks below: the twin / the reference on their OWN decisions
     ys64, dins64, dps64 = _run(ref64, [i.double() for i in inputs], seed_dy)
     for j, (a, b) in enumerate(zip(ys, ys64)):
         assert_close(a, b, out_tol, 'out%d vs fp64 twin' % j)

@@ -4,9 +4,14 @@ driven through the unchanged option parser, against
   (a) the golden vectors the REFERENCE's own optimize_parameters() produced (tests/golden/step_*.npz),
   (b) the oracle step (oracle/step_ref.py) run side by side on the CPU with the same random draws.
 
-Tolerances: losses 1e-4 (abs/rel); images rtol 2e-4; gradients per tensor relative L2 error
-<= 5e-3 (the reference's own fp32-vs-fp64 error on G weight gradients is 3.5e-3),
-noise-level tensors (IN-cancelled biases) by absolute floor 1e-6.
+Tolerances: losses 1e-4 (abs/rel); images rtol 2e-4.  Gradients, per tensor, two checks:
+  SHARP  relative L2 <= 5e-4 (5e-3 for the heteroscedastic variants, whose z_rec term divides by an MC variance) against
+         the float64 twin evaluated on the HIP run's own ReLU / LeakyReLU / max-pool decisions (recorded per network with
+         test_gpu_nets.record_decisions, replayed through oracle.networks_ref.DecisionTape): same smooth branch of the
+         step on both sides, so operator-level agreement carries through the whole step;
+  LOOSE  (labelled) <= 3e-2 against the fp32 oracle on ITS OWN decisions: the gradient is a discontinuous function of
+         the weights through those decisions and single flips move whole tensors by 1e-3 .. 1e-2.
+Noise-level tensors (IN-cancelled biases) by absolute floor 1e-6.
 """
 import os
 import sys
@@ -19,6 +24,7 @@ from oracle import networks_ref as N
 from oracle import weights as W
 from oracle.make_golden import STEP_VARIANTS, step_batch, NP_SEED
 from test_oracle_golden import build_oracle_step, step_inputs, oracle_set_input
+from test_gpu_nets import record_decisions
 from util_cmp import assert_close
 
 pytestmark = pytest.mark.gpu
@@ -99,28 +105,36 @@ def test_step_matches_reference_and_oracle(variant, tmp_path, dev):
         oracle_set_input(oracle, variant, it)
         oracle.optimize_parameters()
         masks, N.Dropout2dRec.record = N.Dropout2dRec.record, None
-        # 1b. the fp64 twin replays the same draws from the same weights
+        # 2. HIP model on the GPU, replaying the same draws; its ReLU / max-pool decisions are recorded per network
+        hnn.Dropout2d.mask_source = iter(masks) if masks else None
+        hutil.inject_noise(iter(oracle.draws) if oracle.draws else None)
+        try:
+            np.random.seed(NP_SEED + it)          # --no_mixed_label_D draws the batch's label from numpy's global generator
+            with record_decisions({'G': model.netG, 'D': model.netD, 'E': model.netE, 'IP': model.netIP}) as rec:
+                model.set_input(step_batch(variant, it))
+                model.optimize_parameters()
+        finally:
+            hnn.Dropout2d.mask_source = None
+            hutil.inject_noise(None)
+        # 3. the fp64 twin: same weights, same draws, and the HIP run's decisions
         with torch.no_grad():
             for tnet, onet in ((twin.netG, oracle_prev['G']), (twin.netD, oracle_prev['D'])):
                 for k, tp in tnet.named_parameters():
                     tp.copy_(onet[k].double())
         N.Dropout2dRec.inject = iter(masks) if masks else None
         twin.inject = iter(oracle.draws) if oracle.draws else None
+        queues = {k: iter(v) for k, v in rec.tapes.items()}
+        for name, tnet in (('G', twin.netG), ('D', twin.netD), ('E', twin.netE), ('IP', twin.netIP)):
+            N.DecisionTape.bind(tnet, queues[name])
         try:
             oracle_set_input(twin, variant, it, torch.float64)
             twin.optimize_parameters()
+            for name, q in queues.items():
+                assert next(q, None) is None, 'the twin consumed fewer %s decisions than the HIP step recorded' % name
         finally:
             N.Dropout2dRec.inject = None
-        # 2. HIP model on the GPU, replaying the same draws
-        hnn.Dropout2d.mask_source = iter(masks) if masks else None
-        hutil.inject_noise(iter(oracle.draws) if oracle.draws else None)
-        try:
-            np.random.seed(NP_SEED + it)          # --no_mixed_label_D draws the batch's label from numpy's global generator
-            model.set_input(step_batch(variant, it))
-            model.optimize_parameters()
-        finally:
-            hnn.Dropout2d.mask_source = None
-            hutil.inject_noise(None)
+            for tnet in (twin.netG, twin.netD, twin.netE, twin.netIP):
+                N.DecisionTape.bind(tnet, None)
         if ('it%d/label_AB' % it) in gold.files:
             assert [int(v) for v in model.label_AB] == [int(v) for v in gold['it%d/label_AB' % it]] == [int(v) for v in oracle.label_AB]
         p = 'it%d' % it
@@ -173,18 +187,16 @@ def test_step_matches_reference_and_oracle(variant, tmp_path, dev):
                 g64 = (twin.grads_G if tag == 'G' else twin.grads_D)[k]
                 if tag == 'G' and k == 'model.1.weight':
                     g64 = g64[:, :-opt.embedding_nc]
-                e_hip, e_ref = _rel_l2(hg, g64), _rel_l2(og, g64)
-                # Slack on top of the fp32 oracle's own error.  With the z_rec / IP terms off the G+D path is smooth
-                # and HIP sits within 1e-5 of the fp64 twin (2e-4 allowed).  With them on the gradient runs through
-                # the encoder's ReLU masks / max-pool arg-max, i.e. it is a discontinuous function of its input, and
-                # 1e-6-level differences between implementations flip a few decisions: measured on these fixtures,
-                # either side can be the odd one out (HIP 1.2e-3 off the twin while oneDNN was at 1.6e-5; after the
-                # fixture change HIP at 1.6e-5 while oneDNN on the GPU box's host was 1.6e-2 off), whereas E alone
-                # on IDENTICAL inputs agrees to 1e-5 (scripts/diag/diag_E2.py, tests/test_gpu_nets.py).  5e-3 / 2e-2
-                # (heteroscedastic variants: division by an MC variance) cover that without masking O(1) errors.
-                slack = 2e-4 if variant == 'no_ip_no_z' else (2e-2 if hetero else 5e-3)
-                assert e_hip <= 2 * e_ref + slack, '%s it%d grad%s %s: rel-L2 vs fp64 twin hip %.3e, fp32 oracle %.3e' % (
-                    variant, it, tag, k, e_hip, e_ref)
+                # SHARP: the twin ran on the HIP step's own decisions (same smooth branch)
+                e_hip = _rel_l2(hg, g64)
+                sharp = 5e-3 if hetero else 5e-4
+                assert e_hip <= sharp, '%s it%d grad%s %s: SHARP rel-L2 vs the fp64 twin on the HIP decisions %.3e > %.1e' % (
+                    variant, it, tag, k, e_hip, sharp)
+                # LOOSE (labelled): the fp32 oracle on its OWN decisions -- single ReLU / arg-max flips in the encoder / AlexNet /
+                # discriminator move whole tensors by 1e-3 .. 1e-2 between two correct implementations
+                e_own = _rel_l2(hg, og)
+                assert e_own <= 3e-2, '%s it%d grad%s %s: LOOSE rel-L2 vs the fp32 oracle on its own decisions %.3e' % (
+                    variant, it, tag, k, e_own)
                 if it == 0 and not (tag == 'G' and k == 'model.1.weight'):
                     st = gold['%s/grad%s/stat/%s' % (p, tag, k)]
                     l2 = float(hg.double().norm())
