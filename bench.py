@@ -161,6 +161,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_issued = time.perf_counter() - t0     # host side done issuing (the GPU may still be running): launch-bound if ~ dt
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -212,6 +213,7 @@ def main():
                                'PatchGAN + ResNet-18 Elo encoder@224 + AlexNet IP@224, full optimize_parameters()' % (
                                    'bf16 activations (fp32 master weights, accumulation, statistics, losses, Adam)' if bf16 else 'fp32'),
                    'global_batch': PER_GPU_BATCH * world, 'parallelism': 'dp%d' % world},
+        'host_issue_ms_per_step': round(t_issued / args.steps * 1e3, 3),
         'step_flop_fraction': round(GFLOP_PER_IMG_FULL * 1e9 * value / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4),
         'roofline': roof if bf16 else {'bound': 'mfma', 'kernel': kname,
                      'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
