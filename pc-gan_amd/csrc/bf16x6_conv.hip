@@ -239,8 +239,12 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, (int)a.x_bytes, 0x00020000);
-    auto ldx = [&](unsigned voff, unsigned soff) -> float {      // one activation element as fp32
+    // one activation element: its fp32 value -- except on the one-piece route without mirror sums (RAW), where the stored
+    // bf16 pattern goes to LDS as it is (zero-extended here, truncated again in stash: no shift, no conversion instruction)
+    constexpr bool RAW = NP == 1 && !DGRAD;
+    auto ldx = [&](unsigned voff, unsigned soff) -> float {
         if constexpr (ES == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, voff, soff, 0));
+        else if constexpr (RAW) return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rX, voff, soff, 0));
         else return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rX, voff, soff, 0) << 16);
     };
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)a.a_bytes, 0x00020000);
@@ -295,8 +299,10 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
                 h[j] = x;
                 m[j] = y;
                 l[j] = z;
+            } else if constexpr (RAW) {
+                h[j] = __builtin_bit_cast(__bf16, (unsigned short)__float_as_uint(v));
             } else {
-                h[j] = (__bf16)v;      // a stored bf16 value comes back unchanged; the mirror sum of the data gradient is rounded once
+                h[j] = (__bf16)v;      // the mirror sum of the data gradient is rounded once
             }
         }
         // this thread's KB consecutive k of pixel pl: offset (kq * KB) % 8 inside the pixel's 8-wide half

@@ -71,6 +71,76 @@ __device__ __forceinline__ float4 ldx4<bf16>(__amdgpu_buffer_rsrc_t r, unsigned 
                        __uint_as_float(v.y & 0xffff0000u));
 }
 
+// ---- bf16 tensors on the fp32-MFMA kernels without a conversion instruction per element ---------------------------------
+// A gathered bf16 element arrives zero-extended in the LOW half of a VGPR; the fp32 value it stands for has those 16 bits in
+// the HIGH half.  Shifting in the vector ALU costs one VALU instruction per element, which these VALU-starved loops feel
+// (4 VALU per MFMA = 18 %; measured +20-30 % on igemm2, +95 % on wgrad2 with the shift).  Instead the LDS
+// operand tiles of the ACTIVATIONS are zeroed once per workgroup and every element is stored with a 16-bit LDS write into the
+// high half of its fp32 slot (ds_write_b16 / ds_write_b16_d16_hi: same instruction count as the 32-bit store they replace).
+//   ldr / ldr4   raw gathered element(s): the fp32 value itself, or (bf16) the zero-extended / packed 16-bit pattern(s)
+//   put1 / put4 / put4p  store raw element(s) into consecutive fp32 LDS slots
+//   raw2f        the fp32 value of a raw element (where arithmetic on it is needed before the store)
+template <typename TA>
+__device__ __forceinline__ float ldr(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ float ldr<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return ld_b32(r, voff, soff); }
+template <>
+__device__ __forceinline__ float ldr<bf16>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0));
+}
+template <typename TA>
+__device__ __forceinline__ float raw2f(float raw) {
+    if constexpr (sizeof(TA) == 2) return __uint_as_float(__float_as_uint(raw) << 16);
+    else return raw;
+}
+template <typename TA>
+__device__ __forceinline__ void put1(float* slot, float raw) {
+    if constexpr (sizeof(TA) == 2) reinterpret_cast<unsigned short*>(slot)[1] = (unsigned short)__float_as_uint(raw);
+    else *slot = raw;
+}
+template <typename TA>
+__device__ __forceinline__ void put4(float* slot, float r0, float r1, float r2, float r3) {
+    if constexpr (sizeof(TA) == 2) {
+        unsigned short* p = reinterpret_cast<unsigned short*>(slot);
+        p[1] = (unsigned short)__float_as_uint(r0);
+        p[3] = (unsigned short)__float_as_uint(r1);
+        p[5] = (unsigned short)__float_as_uint(r2);
+        p[7] = (unsigned short)__float_as_uint(r3);
+    } else {
+        *reinterpret_cast<float4*>(slot) = make_float4(r0, r1, r2, r3);
+    }
+}
+// four CONSECUTIVE elements: fp32: four values; bf16: two dwords of two packed elements each (in .x, .y)
+template <typename TA>
+__device__ __forceinline__ float4 ldr4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (sizeof(TA) == 2) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), 0.f, 0.f);
+    } else {
+        return ldx4<float>(r, voff, soff);
+    }
+}
+template <typename TA>
+__device__ __forceinline__ void put4p(float* slot, const float4& raw) {
+    if constexpr (sizeof(TA) == 2) {
+        unsigned short* p = reinterpret_cast<unsigned short*>(slot);
+        const unsigned a = __float_as_uint(raw.x), b = __float_as_uint(raw.y);
+        p[1] = (unsigned short)a;
+        p[3] = (unsigned short)(a >> 16);       // ds_write_b16_d16_hi
+        p[5] = (unsigned short)b;
+        p[7] = (unsigned short)(b >> 16);
+    } else {
+        *reinterpret_cast<float4*>(slot) = raw;
+    }
+}
+// zero an LDS tile (all threads of the workgroup; the caller's next barrier publishes it)
+template <typename TA>
+__device__ __forceinline__ void zero_tile(float* tile, int n) {
+    if constexpr (sizeof(TA) == 2)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) tile[i] = 0.f;
+}
+
 struct PhaseArgs {
     const float* A;  // [M][Kp], k = (tap_index * Cgp + c)
     int Kp;
@@ -240,7 +310,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
                     voff = (ok && pvalid) ? (unsigned)(vbase + off) * ES : OOB;
                 }
             }
-            breg[i] = (e.c < a.Cg) ? ldx<TA>(rX, voff, (unsigned)(e.c * HgWg) * ES) : 0.f;
+            breg[i] = (e.c < a.Cg) ? ldr<TA>(rX, voff, (unsigned)(e.c * HgWg) * ES) : 0.f;
             e.advance(1, a.Cgp, ph_nS);
         }
         it.advance(16, a.Cgp, ph_nS);
@@ -254,8 +324,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         }
 #pragma unroll
         for (int gq = 0; gq < KPT / 4; ++gq)
-            *reinterpret_cast<float4*>(&Bs[buf][((ksub * (KPT / 4) + gq) * BP + pl) * 4]) =
-                make_float4(breg[gq * 4 + 0], breg[gq * 4 + 1], breg[gq * 4 + 2], breg[gq * 4 + 3]);
+            put4<TA>(&Bs[buf][((ksub * (KPT / 4) + gq) * BP + pl) * 4], breg[gq * 4 + 0], breg[gq * 4 + 1], breg[gq * 4 + 2], breg[gq * 4 + 3]);
     };
 
     f32x16 acc[MI][PJ];
@@ -289,6 +358,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][jj], bv[j][jj], acc[i][j], 0, 0, 0);
     };
     if (st_begin < st_end) {  // (empty K range of a split-K tail: accumulators stay zero, stored below)
+        if constexpr (sizeof(TA) == 2) {
+            zero_tile<TA>(&Bs[0][0], 2 * 4 * BP * 4);
+            __syncthreads();
+        }
         load_stage(st_begin * 16);
         store_stage(0);
         __syncthreads();
@@ -494,6 +567,7 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
             }
         }
         if (tid < BM) biasS[tid] = (a.bias != nullptr && m0 + tid < a.M) ? a.bias[m0 + tid] : 0.f;
+        zero_tile<TA>(&Bs[0][0], 2 * 4 * BP * 4);     // (published by the barrier in front of the first stage)
     }
     const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);
 
@@ -561,15 +635,15 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
         constexpr int NM = decltype(nm_tag)::value;
         if constexpr (CPS == 4) {
             const unsigned v = (i & 3) < a.Cg ? (i < 4 ? vo[0] : vo_b) : OOB;   // 3-channel tensors: the pad channel reads 0
-            breg[i] = ldx<TA>(rX, v, (unsigned)((i & 3) * HgWg4));
+            breg[i] = ldr<TA>(rX, v, (unsigned)((i & 3) * HgWg4));
             return;
         }
         const unsigned so = (unsigned)((vo_c + ksub * KPT + i) * HgWg4);
-        breg[i] = ldx<TA>(rX, vo[0], so);
-        if constexpr (NM >= 1) bmir[0][i] = ldx<TA>(rX, vo[NCOMB > 1 ? 1 : 0], so);
+        breg[i] = ldr<TA>(rX, vo[0], so);
+        if constexpr (NM >= 1) bmir[0][i] = ldr<TA>(rX, vo[NCOMB > 1 ? 1 : 0], so);
         if constexpr (NM >= 3) {
-            bmir[1][i] = ldx<TA>(rX, vo[NCOMB > 1 ? 2 : 0], so);
-            bmir[2][i] = ldx<TA>(rX, vo[NCOMB > 1 ? 3 : 0], so);
+            bmir[1][i] = ldr<TA>(rX, vo[NCOMB > 1 ? 2 : 0], so);
+            bmir[2][i] = ldr<TA>(rX, vo[NCOMB > 1 ? 3 : 0], so);
         }
     };
     auto store_a = [&](int buf, int j) {
@@ -579,15 +653,20 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
     };
     auto store_b = [&](int buf, int gq, auto nm_tag) {
         constexpr int NM = decltype(nm_tag)::value;
-        float v[4];
+        float* slot = &Bs[buf][((ksub * (KPT / 4) + gq) * BP + pl) * 4];
+        if constexpr (NM == 0) {       // raw elements straight into their slots
+            put4<TA>(slot, breg[gq * 4 + 0], breg[gq * 4 + 1], breg[gq * 4 + 2], breg[gq * 4 + 3]);
+        } else {                       // border workgroups of the fused reflect gradient: sum the mirror images as fp32 values
+            float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = gq * 4 + e;
-            v[e] = breg[i];
-            if constexpr (NM == 1) v[e] += bmir[0][i];
-            if constexpr (NM == 3) v[e] += (bmir[0][i] + bmir[1][i]) + bmir[2][i];
+            for (int e = 0; e < 4; ++e) {
+                const int i = gq * 4 + e;
+                v[e] = raw2f<TA>(breg[i]);
+                if constexpr (NM == 1) v[e] += raw2f<TA>(bmir[0][i]);
+                if constexpr (NM == 3) v[e] += (raw2f<TA>(bmir[0][i]) + raw2f<TA>(bmir[1][i])) + raw2f<TA>(bmir[2][i]);
+            }
+            *reinterpret_cast<float4*>(slot) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *reinterpret_cast<float4*>(&Bs[buf][((ksub * (KPT / 4) + gq) * BP + pl) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
     };
 
     f32x16 acc[MI][PJ];
@@ -1382,7 +1461,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int j = 0; j < AV; ++j) {
                 const int row = (tid >> 3) + 32 * j;
-                const float4 v = ldx4<TA>(rY, ((vb != OOB) & (m0 + row < a.M)) ? vb + (unsigned)(row * HoWo) * ES : OOB, 0u);
+                const float4 v = ldr4<TA>(rY, ((vb != OOB) & (m0 + row < a.M)) ? vb + (unsigned)(row * HoWo) * ES : OOB, 0u);
                 areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
             }
         }
@@ -1398,7 +1477,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
             const unsigned vb = pvalid ? (unsigned)((n * a.M + m0 + rg) * HoWo + rem) * ES : OOB;
 #pragma unroll
             for (int i = 0; i < AR; ++i)
-                areg[i] = ldx<TA>(rY, (pvalid & (m0 + rg + 8 * i < a.M)) ? vb : OOB, (unsigned)(8 * i * HoWo) * ES);
+                areg[i] = ldr<TA>(rY, (pvalid & (m0 + rg + 8 * i < a.M)) ? vb : OOB, (unsigned)(8 * i * HoWo) * ES);
         }
         const int vbase = n * a.Cg * HgWg;
         if (ONETAP) {
@@ -1409,7 +1488,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
             const unsigned voff = ok ? (unsigned)(vbase + off + rg * HgWg) * ES : OOB;
 #pragma unroll
             for (int i = 0; i < BR; ++i)
-                breg[i] = ldx<TA>(rX, (c_b + 8 * i + rg < a.Cg) ? voff : OOB, (unsigned)((c_b + 8 * i) * HgWg) * ES);
+                breg[i] = ldr<TA>(rX, (c_b + 8 * i + rg < a.Cg) ? voff : OOB, (unsigned)((c_b + 8 * i) * HgWg) * ES);
         } else if (!SMALLC) {
             int tap = tap_b, c = c_b;
             unsigned voff = OOB;
@@ -1423,7 +1502,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
                     voff = ok ? (unsigned)(vbase + off + rg * HgWg) * ES : OOB;
                 }
                 const bool okc = (c + rg < a.Cg) & (kb + 8 * i + rg < a.Kp);
-                breg[i] = ldx<TA>(rX, okc ? voff : OOB, (unsigned)(c * HgWg) * ES);
+                breg[i] = ldr<TA>(rX, okc ? voff : OOB, (unsigned)(c * HgWg) * ES);
                 c += 8;
                 if (c >= a.Cgp) {
                     c -= a.Cgp;
@@ -1439,7 +1518,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
                 const int s = tap - r * a.S;
                 int off;
                 const bool ok = tap_offset<MODE>(g, oy, ox, r, s, off) && pvalid && kcol < a.Kp && c < a.Cg;
-                breg[i] = ldx<TA>(rX, ok ? (unsigned)(vbase + c * HgWg + off) * ES : OOB, 0u);
+                breg[i] = ldr<TA>(rX, ok ? (unsigned)(vbase + c * HgWg + off) * ES : OOB, 0u);
             }
         }
     };
@@ -1447,14 +1526,14 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
         if (VECA) {
 #pragma unroll
             for (int j = 0; j < AV; ++j)
-                *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * j) * PT + (tid & 7) * 4]) =
-                    make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
+                put4p<TA>(&As[buf][((tid >> 3) + 32 * j) * PT + (tid & 7) * 4],
+                          make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]));
         } else {
 #pragma unroll
-            for (int i = 0; i < AR; ++i) As[buf][(rg + 8 * i) * PT + pl] = areg[i];
+            for (int i = 0; i < AR; ++i) put1<TA>(&As[buf][(rg + 8 * i) * PT + pl], areg[i]);
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) Gs[buf][(rg + 8 * i) * PT + pl] = breg[i];
+        for (int i = 0; i < BR; ++i) put1<TA>(&Gs[buf][(rg + 8 * i) * PT + pl], breg[i]);
     };
 
     f32x16 acc[MI][NJ];
@@ -1471,6 +1550,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     if (c_end > nchunks) c_end = nchunks;
     const int nst = c_end - c_begin;
     if (nst > 0) {
+        if constexpr (sizeof(TA) == 2) {
+            zero_tile<TA>(&As[0][0], 2 * BM * PT);
+            zero_tile<TA>(&Gs[0][0], 2 * BN * PT);
+            __syncthreads();
+        }
         load_stage(c_begin);
         store_stage(0);
         __syncthreads();
@@ -1756,25 +1840,24 @@ __global__ void __launch_bounds__(256) wgrad2_kernel(WgradArgs a) {
     };
     auto load_a = [&](int j) {
         if (VECA) {
-            const float4 v = ldx4<TA>(rY, yo | yflag[j], (unsigned)(32 * j * HoWo4));
+            const float4 v = ldr4<TA>(rY, yo | yflag[j], (unsigned)(32 * j * HoWo4));
             areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
         } else {
-            areg[j] = ldx<TA>(rY, yo | yflag[j], (unsigned)(8 * j * HoWo4));
+            areg[j] = ldr<TA>(rY, yo | yflag[j], (unsigned)(8 * j * HoWo4));
         }
     };
     auto load_b = [&](int i) {
         constexpr int PER = BR / NT;   // K-columns (i) per tap
-        breg[i] = ldx<TA>(rX, xo[i / PER], (unsigned)((c_b + 8 * (i % PER)) * HgWg4));
+        breg[i] = ldr<TA>(rX, xo[i / PER], (unsigned)((c_b + 8 * (i % PER)) * HgWg4));
     };
     auto store_a = [&](int buf, int j) {
         if (VECA) {
-            *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * j) * PT + pc]) =
-                make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
+            put4p<TA>(&As[buf][((tid >> 3) + 32 * j) * PT + pc], make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]));
         } else {
-            As[buf][(rg + 8 * j) * PT + pl] = areg[j];
+            put1<TA>(&As[buf][(rg + 8 * j) * PT + pl], areg[j]);
         }
     };
-    auto store_b = [&](int buf, int i) { Gs[buf][(rg + 8 * i) * PT + pl] = breg[i]; };
+    auto store_b = [&](int buf, int i) { put1<TA>(&Gs[buf][(rg + 8 * i) * PT + pl], breg[i]); };
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -1801,6 +1884,8 @@ __global__ void __launch_bounds__(256) wgrad2_kernel(WgradArgs a) {
     };
 
     if (nst > 0) {
+        zero_tile<TA>(&As[0][0], 2 * BM * PT);
+        zero_tile<TA>(&Gs[0][0], 2 * BN * PT);
         refill(0);
         refill(8);
         __syncthreads();

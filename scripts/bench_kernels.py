@@ -10,6 +10,7 @@ import torch
 from pcgan_amd.hip import ops
 
 dev = torch.device('cuda:0')
+DT = torch.bfloat16 if os.environ.get('BK_DTYPE') == 'bf16' else torch.float32
 N = 32
 # name, C, H, K, R, stride, pad, pad_mode, transposed, (n_fwd, n_dgrad, n_wgrad) per step, batch
 L = [
@@ -67,14 +68,15 @@ def main():
         if flt not in name:
             continue
         P = (H + 2 * pad - R) // stride + 1
-        x = torch.rand(N, C, H, H, device=dev) * 2 - 1
+        x = (torch.rand(N, C, H, H, device=dev) * 2 - 1).to(DT)
         w = torch.randn(K, C, R, R, device=dev) * 0.05
         b = torch.zeros(K, device=dev)
-        dy = torch.randn(N, K, P, P, device=dev)
+        dy = torch.randn(N, K, P, P, device=dev).to(DT)
         flop = 2.0 * N * P * P * K * C * R * R
         iters = 10 if flop > 5e9 else 20
-        t_f = timeit(lambda: ops.conv2d_fwd(x, w, b, stride, pad, pm), iters)
-        t_d = timeit(lambda: ops.conv2d_bwd_data(dy, w, (H, H), stride, pad, pm), iters)
+        cf, cb = {}, {}      # packed weights cached as in the step (and the step's routing)
+        t_f = timeit(lambda: ops.conv2d_fwd(x, w, b, stride, pad, pm, pack_cache=cf), iters)
+        t_d = timeit(lambda: ops.conv2d_bwd_data(dy, w, (H, H), stride, pad, pm, pack_cache=cb), iters)
         t_w = timeit(lambda: ops.conv2d_bwd_weight(x, dy, (K, C, R, R), stride, pad, pm), iters)
         if tr:   # ConvTranspose: its forward is the conv's dgrad and vice versa
             t_f, t_d = t_d, t_f
