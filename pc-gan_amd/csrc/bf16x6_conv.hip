@@ -24,11 +24,13 @@
 //   per wave and stage 12 ds_read_b128 and 24 MFMAs (smallest terms first); global loads run three stages ahead, the LDS reads
 //   of the next stage sit under the MFMAs of the current one (operands double-buffered in registers), one barrier per stage.
 #include "common.h"
+#include <stdlib.h>
 
 namespace pcgan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 static constexpr unsigned BS_OOB = 0x80000000u;
 static constexpr int BS_MAXTAP = 25;
@@ -38,6 +40,25 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     const float r1 = x - (float)h;
     m = (__bf16)r1;
     l = (__bf16)(r1 - (float)m);
+}
+
+// Two fp16 pieces, x * 2^e = h + l (11 + 11 significand bits), products (l,h) (h,l) (h,h): HALF the matrix instructions of the
+// three-piece bf16 split.  scripts/micro/bf16_split, K = 2304 against float64: relative L2 error 5.3e-7 (fp32 MFMA 6.1e-7, bf16 x 6
+// 7.0e-7).  fp16 has 5 exponent bits, so each operand tensor is scaled by a power of two that puts its largest magnitude in
+// (2^13, 2^14] (the largest magnitude is computed on the device: pcgan_absmax, or handed over by the producing kernel); the
+// accumulators are scaled back (exactly) in the epilogue.  An element below 2^-17 of the tensor's largest loses its low piece
+// (error <= 2^-39 of the largest magnitude per element).
+__device__ __forceinline__ float pow2_scale(float amax) {
+    if (!(amax > 0.f)) return 1.f;
+    int e;
+    frexpf(amax, &e);                     // amax = m * 2^e, m in [0.5, 1)
+    e = 14 - e;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return ldexpf(1.f, e);
+}
+__device__ __forceinline__ void split2h(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)(x - (float)h);
 }
 
 struct BsplitArgs {
@@ -61,8 +82,9 @@ enum { BS_FWD_ZERO = 0, BS_FWD_REFLECT = 1, BS_DGRAD_REFLECT = 2, BS_WGRAD = 3 }
 
 // weights w[M][C][R][S] -> [piece][mt][stage][half][BM][8] bf16 (BM = 128 << bm_shift), stage = chunk * T + tap, k in stage =
 // channel in chunk
+// np = 2: two fp16 pieces of w * pow2_scale(*amax) (the fp16 route)
 __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int M, int C, int T, int nMt, int nst,
-                                   int bm_shift, int np) {
+                                   int bm_shift, int np, const float* __restrict__ amax = nullptr) {
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nMt * nst * 16 * BM;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_piece; i += (size_t)gridDim.x * blockDim.x) {
@@ -71,6 +93,13 @@ __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restri
         const int st = (int)(q % nst), mt = (int)(q / nst);
         const int m = mt * BM + row, c = (st / T) * 16 + half * 8 + j, tap = st % T;
         const float v = m < M ? w[((size_t)m * C + c) * T + tap] : 0.f;
+        if (np == 2) {
+            _Float16 h, l;
+            split2h(v * pow2_scale(*amax), h, l);
+            reinterpret_cast<_Float16*>(A)[i] = h;
+            reinterpret_cast<_Float16*>(A)[per_piece + i] = l;
+            continue;
+        }
         __bf16 h, mm, l;
         split3(v, h, mm, l);
         A[i] = h;                      // (np == 1: the weight rounded to nearest-even bf16)
@@ -78,6 +107,34 @@ __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restri
             A[per_piece + i] = mm;
             A[2 * per_piece + i] = l;
         }
+    }
+}
+
+// largest magnitude of a tensor, as the bit pattern of a non-negative float (ordered like an unsigned integer); *out zeroed before
+template <typename TA>
+__global__ void __launch_bounds__(256) absmax_kernel(const TA* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    // scalar head up to a 16-byte boundary (a weight tensor may be a view into the optimizer's flat buffer), vector body, scalar tail
+    size_t head = ((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) / sizeof(TA);
+    head = head < n ? head : n;
+    const TA* xb = x + head;
+    const size_t nb = n - head, n4 = nb / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = ld4(xb + 4 * i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) m = fmaxf(m, fabsf(ld1(x + threadIdx.x)));
+        if (threadIdx.x < (nb & 3)) m = fmaxf(m, fabsf(ld1(xb + 4 * n4 + threadIdx.x)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        if (v > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, v);      // only a workgroup that would raise the value
     }
 }
 
@@ -141,7 +198,7 @@ __global__ void bsplit_wgrad_reduce_kernel(const float* __restrict__ part, float
 // folded in: row class 1 (row 1) reads row 0 through tap r'=0 for itself AND for padded row -1: wf'[0] = wf[0] + wf[2];
 // row class 2 (row H-2): wf'[2] = wf[2] + wf[0].
 __global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int K, int C, int nMt, int nst, int bm_shift,
-                                         int np) {
+                                         int np, const float* __restrict__ amax = nullptr) {
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nMt * nst * 16 * BM, per_phase = (size_t)np * per_piece;
     // (3 row classes x per_piece entries; each entry writes its np pieces)
@@ -159,9 +216,16 @@ __global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __
             v = wk[(2 - rp) * 3 + (2 - sp)];
             if ((phase == 1 && rp == 0) || (phase == 2 && rp == 2)) v += wk[rp * 3 + (2 - sp)];   // + wf[2 - rp][sp]
         }
+        __bf16* out = A + (size_t)phase * per_phase;
+        if (np == 2) {     // (a folded row-class weight is at most twice the largest weight: still far inside the fp16 range)
+            _Float16 h, l;
+            split2h(v * pow2_scale(*amax), h, l);
+            reinterpret_cast<_Float16*>(out)[e] = h;
+            reinterpret_cast<_Float16*>(out)[per_piece + e] = l;
+            continue;
+        }
         __bf16 h, mm, l;
         split3(v, h, mm, l);
-        __bf16* out = A + (size_t)phase * per_phase;
         out[e] = h;
         if (np == 3) {
             out[per_piece + e] = mm;
@@ -431,6 +495,420 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
     }
 }
 
+// ---- "halo" form of the reflection-padded 3x3 stride-1 convolution (forward and data gradient), image width 32 or 64 -----------
+// The kernel above gathers every input element once per tap (9 loads, 9 splits, 9 LDS writes per element and workgroup).  Here a
+// pixel tile is RT = 128 / W full image rows, and per 16-channel chunk its (RT + 2) x (W + 2) window is loaded, split and written
+// to LDS ONCE; the nine taps read it at shifted addresses ([piece][k half][window pixel][8 bf16]: a tap is a constant added to the
+// lane's LDS address, 32 consecutive lanes still read 512 contiguous bytes).  Weights, accumulators, MFMA order and the two-stage
+// software pipeline are those of the kernel above (BM = 256: 8 waves of 64 x 64).
+//   forward        the window holds the reflection-padded input (the mirror is applied when the window is built);
+//   data gradient  the window holds dy with a ring of zeros; the contributions of the padded rows / columns -1 and H / W, which
+//                  fold onto rows / columns 1 and H-2 / W-2, become two extra window rows and columns of SUMS
+//                  (dy[2] + dy[0] for output row 1 through tap r' = 2, dy[H-3] + dy[H-1] for row H-2 through r' = 0; columns
+//                  alike; the corners sum four sources): a lane on row 1 / column 1 / ... reads the sum entry instead of the shifted
+//                  one.  One set of plain flipped weights serves every row (the kernel above needs three row classes).
+enum { BH_FWD = 0, BH_DGRAD = 1 };
+
+struct HaloArgs {
+    const void* X;       // [N][C][H][W], storage type TA (data gradient: dy, C = the convolution's output channels)
+    const void* A;       // packed weights [piece][M tile][chunk * 9 + tap][k half][256 rows][8 bf16]
+    const float* bias;   // [M] or null
+    void* Y;             // [N][M][H][W]
+    int N, C, H, M, nMt, nch, act;
+    float slope;
+    unsigned x_bytes, a_bytes;
+    const float* x_amax;   // PK_F16X2: largest magnitude of X (device), and of the weights (written by the pack kernel)
+    const float* w_amax;
+};
+
+// piece kinds: what an operand element becomes on its way to the matrix pipe
+enum { PK_BF16X3 = 0,      // fp32 tensors, three bf16 pieces, six products (exact terms above 2^-24)
+       PK_BF16 = 1,        // bf16 tensors as they are, one product
+       PK_F16X2 = 2 };     // fp32 tensors, two scaled fp16 pieces, three products
+
+template <int MODE, int PK, typename TA, int QW>
+__global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
+    constexpr int NP = PK == PK_BF16X3 ? 3 : (PK == PK_F16X2 ? 2 : 1);
+    static_assert((PK != PK_BF16 && sizeof(TA) == 4) || (PK == PK_BF16 && sizeof(TA) == 2), "pieces of fp32 tensors, or bf16 tensors as they are");
+    static_assert(QW == 32 || QW == 64, "image width");
+    constexpr unsigned ES = sizeof(TA);
+    constexpr bool DG = MODE == BH_DGRAD;
+    constexpr int BM = 256, NT = 512;
+    constexpr int RT = 128 / QW;                    // image rows of a pixel tile
+    constexpr int WR = RT + 2, WC = QW + 2;         // window = tile + a ring of one pixel
+    constexpr int HR = WR + (DG ? 2 : 0), QH = WC + (DG ? 2 : 0);     // + the two sum rows / columns of the data gradient
+    constexpr int NPX = HR * QH;
+    constexpr int NBASE = WR * WC, NRB = (NBASE * 4 + NT - 1) / NT;   // window entries x 4 channel quads, rounds over the threads
+    constexpr int NPATCH = DG ? 2 * WR + 2 * QH : 0, NRP = DG ? (NPATCH * 4 + NT - 1) / NT : 0;
+    constexpr unsigned ASTAGE = BM * 32;            // bytes of one stage of one piece of the weights
+    constexpr unsigned XPIECE = 2 * NPX * 16, XBUF = NP * XPIECE;
+    __shared__ __attribute__((aligned(16))) bf16x8 As[2][NP][2 * BM];    // [buffer][piece][half * BM + row]
+    __shared__ __attribute__((aligned(16))) bf16x8 Xs[2 * NP * 2 * NPX];  // [buffer][piece][half][window entry]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wp = wave & 1;
+    const int mt = blockIdx.x % a.nMt, pt = blockIdx.x / a.nMt;
+    const int TPI = a.H / RT;
+    const int n = pt / TPI, y0 = (pt - n * TPI) * RT;
+    const int HW = a.H * QW;
+    char* const xs_bytes = reinterpret_cast<char*>(&Xs[0]);
+
+    // ---- window builder tables: which source element(s) a thread loads per chunk and where their pieces go
+    unsigned bvo[NRB], blds[NRB];
+#pragma unroll
+    for (int i = 0; i < NRB; ++i) {
+        const int u = tid + i * NT;
+        const bool valid = u < NBASE * 4;
+        const int q = u / NBASE, e = u - q * NBASE, hb = e / WC, wb = e - hb * WC;
+        int iy = y0 - 1 + hb, ix = wb - 1;
+        bool ok = valid;
+        if (DG) {
+            ok = ok & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)QW);
+        } else {
+            iy = iy < 0 ? -iy : iy;
+            iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+            ix = ix < 0 ? -ix : ix;
+            ix = ix >= QW ? 2 * (QW - 1) - ix : ix;
+        }
+        bvo[i] = ok ? (unsigned)(q * 4 * HW + iy * QW + ix) * ES : BS_OOB;
+        blds[i] = valid ? (unsigned)(((q >> 1) * NPX + hb * QH + wb) * 16 + (q & 1) * 8) : 0xffffffffu;
+    }
+    unsigned pvo[DG ? NRP : 1][4], plds[DG ? NRP : 1];
+    if constexpr (DG) {
+        const bool use_lo = y0 <= 1 && 1 < y0 + RT;               // the tile holds row 1: sum row {2, 0}
+        const bool use_hi = y0 <= a.H - 2 && a.H - 2 < y0 + RT;   // the tile holds row H-2: sum row {H-3, H-1}
+#pragma unroll
+        for (int i = 0; i < NRP; ++i) {
+            const int u = tid + i * NT;
+            const bool valid = u < NPATCH * 4;
+            const int q = u / NPATCH, pe = u - q * NPATCH;
+            int h, w;
+            if (pe < 2 * WR) {
+                h = pe >> 1;
+                w = WC + (pe & 1);
+            } else {
+                const int p2 = pe - 2 * WR;
+                h = WR + p2 / QH;
+                w = p2 - (p2 / QH) * QH;
+            }
+            int r0, r1, c0, c1;
+            if (h < WR) {
+                r0 = y0 - 1 + h;
+                r0 = (unsigned)r0 < (unsigned)a.H ? r0 : -1;
+                r1 = -1;
+            } else if (h == WR) {
+                r0 = use_hi ? a.H - 3 : -1;
+                r1 = use_hi ? a.H - 1 : -1;
+            } else {
+                r0 = use_lo ? 2 : -1;
+                r1 = use_lo ? 0 : -1;
+            }
+            if (w < WC) {
+                c0 = w - 1;
+                c0 = (unsigned)c0 < (unsigned)QW ? c0 : -1;
+                c1 = -1;
+            } else if (w == WC) {
+                c0 = QW - 3;
+                c1 = QW - 1;
+            } else {
+                c0 = 2;
+                c1 = 0;
+            }
+            const int rr[4] = {r0, r0, r1, r1}, cc[4] = {c0, c1, c0, c1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                pvo[i][k] = (valid && rr[k] >= 0 && cc[k] >= 0) ? (unsigned)(q * 4 * HW + rr[k] * QW + cc[k]) * ES : BS_OOB;
+            plds[i] = valid ? (unsigned)(((q >> 1) * NPX + h * QH + w) * 16 + (q & 1) * 8) : 0xffffffffu;
+        }
+    }
+
+    // ---- LDS addresses of this lane's two pixel columns (j = 0, 1) of the B operand, per tap
+    unsigned boff[2], rowb[DG ? 2 : 1][3], colb[DG ? 2 : 1][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = wp * 64 + j * 32 + lo, ty = p / QW, tx = p - ty * QW;
+        boff[j] = (unsigned)((hi * NPX + ty * QH + tx) * 16);
+        if constexpr (DG) {
+            const int y = y0 + ty;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int rs = (y == 1 && t == 2) ? WR + 1 : ((y == a.H - 2 && t == 0) ? WR : ty + t);
+                const int cs = (tx == 1 && t == 2) ? WC + 1 : ((tx == QW - 2 && t == 0) ? WC : tx + t);
+                rowb[j][t] = (unsigned)(rs * QH * 16);
+                colb[j][t] = (unsigned)((hi * NPX + cs) * 16);
+            }
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)a.a_bytes, 0x00020000);
+    // an activation element as loaded: fp32 value; bf16 storage: the stored pattern, zero-extended (RAW: it goes to LDS unchanged)
+    auto ldraw = [&](unsigned voff, unsigned soff) -> unsigned {
+        if constexpr (ES == 4) return __builtin_amdgcn_raw_buffer_load_b32(rX, voff, soff, 0);
+        else return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rX, voff, soff, 0);
+    };
+    auto tofloat = [&](unsigned raw) -> float { return __uint_as_float(ES == 4 ? raw : raw << 16); };
+    const unsigned piece_bytes = (unsigned)a.nMt * (unsigned)(a.nch * 9) * ASTAGE;
+    const unsigned a_tile = (unsigned)mt * (unsigned)(a.nch * 9) * ASTAGE;
+    const int nst = a.nch * 9;
+
+    // write 4 consecutive channels of one window entry (8 bytes per piece)
+    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+    const float sx = PK == PK_F16X2 ? pow2_scale(*a.x_amax) : 1.f;
+    auto put_split = [&](unsigned lds, int buf, const float (&v)[4]) {
+        char* dst = xs_bytes + (unsigned)buf * XBUF + lds;
+        if constexpr (PK == PK_F16X2) {
+            hf4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 x, y;
+                split2h(v[j] * sx, x, y);
+                h[j] = x;
+                l[j] = y;
+            }
+            *reinterpret_cast<hf4*>(dst) = h;
+            *reinterpret_cast<hf4*>(dst + XPIECE) = l;
+        } else {
+            bf4 h, m, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (NP == 3) {
+                    __bf16 x, y, z;
+                    split3(v[j], x, y, z);
+                    h[j] = x;
+                    m[j] = y;
+                    l[j] = z;
+                } else {
+                    h[j] = (__bf16)v[j];
+                }
+            }
+            *reinterpret_cast<bf4*>(dst) = h;
+            if constexpr (NP == 3) {
+                *reinterpret_cast<bf4*>(dst + XPIECE) = m;
+                *reinterpret_cast<bf4*>(dst + 2 * XPIECE) = l;
+            }
+        }
+    };
+    unsigned tb[NRB][4];
+    auto base_load = [&](int ch) {       // (a chunk past the end: out-of-range offsets, zeros come back)
+        const bool live = ch < a.nch;
+        const unsigned so = live ? (unsigned)((n * a.C + ch * 16) * HW) * ES : 0u;
+#pragma unroll
+        for (int i = 0; i < NRB; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tb[i][j] = ldraw(live ? bvo[i] : BS_OOB, so + (unsigned)(j * HW) * ES);
+    };
+    auto base_write = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) {
+            if (blds[i] == 0xffffffffu) continue;
+            if constexpr (PK == PK_BF16) {     // stored bf16 patterns as they are
+                typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+                us4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (unsigned short)tb[i][j];
+                *reinterpret_cast<us4*>(xs_bytes + (unsigned)buf * XBUF + blds[i]) = v;
+            } else {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = tofloat(tb[i][j]);
+                put_split(blds[i], buf, v);
+            }
+        }
+    };
+    unsigned tp[DG ? NRP : 1][4][4];
+    auto patch_load = [&](int ch) {
+        if constexpr (DG) {
+            const bool live = ch < a.nch;
+            const unsigned so = live ? (unsigned)((n * a.C + ch * 16) * HW) * ES : 0u;
+#pragma unroll
+            for (int i = 0; i < NRP; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tp[i][k][j] = ldraw(live ? pvo[i][k] : BS_OOB, so + (unsigned)(j * HW) * ES);
+        }
+    };
+    auto patch_write = [&](int buf) {
+        if constexpr (DG) {
+#pragma unroll
+            for (int i = 0; i < NRP; ++i) {
+                if (plds[i] == 0xffffffffu) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = (tofloat(tp[i][0][j]) + tofloat(tp[i][1][j])) + (tofloat(tp[i][2][j]) + tofloat(tp[i][3][j]));
+                put_split(plds[i], buf, v);
+            }
+        }
+    };
+
+    struct Stage {
+        u32x4 ap[NP];
+    };
+    auto load = [&](Stage& r, int s) {
+        const bool live = s < nst;
+        const unsigned avo = live ? (unsigned)tid * 16u : BS_OOB;
+        const unsigned aso = a_tile + (unsigned)(live ? s : 0) * ASTAGE;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) r.ap[p] = __builtin_amdgcn_raw_buffer_load_b128(rA, avo, aso + p * piece_bytes, 0);
+    };
+    auto stash = [&](const Stage& r, int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(&As[buf][p][tid]) = r.ap[p];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    struct Operands {
+        bf16x8 A[NP][2], B[NP][2];
+    };
+    // operands of one stage: weights from As[abuf], pixels of tap (tr, ts) from window buffer xbuf
+    auto fetch = [&](Operands& o, int abuf, int xbuf, int tr, int ts) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) o.A[p][i] = As[abuf][p][hi * BM + wm * 64 + i * 32 + lo];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned ad;
+            if constexpr (DG) ad = rowb[j][tr] + colb[j][ts];
+            else ad = boff[j] + (unsigned)((tr * QH + ts) * 16);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                o.B[p][j] = *reinterpret_cast<const bf16x8*>(xs_bytes + ad + (unsigned)xbuf * XBUF + p * XPIECE);
+        }
+    };
+    auto mma = [&](const Operands& o) {
+        if constexpr (PK == PK_F16X2) {       // (l,h) (h,l) (h,h)
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, o.A[PA[q]][i]),
+                                                                            __builtin_bit_cast(f16x8, o.B[PB[q]][j]), acc[i][j], 0, 0, 0);
+        } else {
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = (NP == 3 ? 0 : 5); q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.A[PA[q]][i], o.B[PB[q]][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // issue order inside a stage (a hint): every MFMA is followed by its share of the other work
+    auto interleave = [&]() {
+        if constexpr (NP == 2) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+                if (q < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // LDS reads of the next stage first
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                   // VALU (split arithmetic of a window)
+                if (q >= 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // LDS writes
+                if (q >= 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);       // global loads
+            }
+        } else if constexpr (NP == 3) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+                if (q < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // LDS reads of the next stage first
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                   // VALU (split arithmetic of a window)
+                if (q >= 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // LDS writes
+                if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // global loads
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+            }
+        }
+    };
+
+    // window of chunk 0, then the weight pipeline of the kernel above, unrolled over a PAIR of chunks (18 stages) so that window
+    // buffer, tap, LDS weight buffer and register sets are all static.  Stage t of the pair: MFMAs of stage t out of registers |
+    // operand fetch of stage t+1 | weights of stage t+2 to LDS, of stage t+4 from memory | window of the next chunk:
+    //   t = 0 / 9    loads of the window proper                       (registers only)
+    //   t = 3 / 12   its split + LDS writes; loads of the sum rows / columns (data gradient)
+    //   t = 6 / 15   their split + LDS writes
+    // first reader: the fetch during t = 8 / 17; the buffer overwritten was last read by the fetch during t = 16 / 7.
+    base_load(0);
+    patch_load(0);
+    Stage rg[2];
+    Operands op[2];
+    load(rg[0], 0);
+    load(rg[1], 1);
+    base_write(0);
+    patch_write(0);
+    stash(rg[0], 0);
+    __syncthreads();
+    load(rg[0], 2);
+    fetch(op[0], 0, 0, 0, 0);
+    stash(rg[1], 1);
+    __syncthreads();
+    load(rg[1], 3);
+    for (int c = 0; c < a.nch; c += 2) {
+        const int s0 = c * 9;
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {
+            const int tn = (t + 1) % 18, tapn = tn % 9;
+#ifndef HALO_ABL
+#define HALO_ABL 0
+#endif
+            if (HALO_ABL != 3) fetch(op[(t + 1) & 1], (t + 1) & 1, tn / 9, tapn / 3, tapn % 3);    // operands of stage t+1
+            if (HALO_ABL != 4) mma(op[t & 1]);                                                  // stage t
+            if (HALO_ABL != 2) stash(rg[t & 1], t & 1);                                         // weights of stage t+2 (its buffer was read for stage t before the last barrier)
+            if (HALO_ABL != 2) load(rg[t & 1], s0 + t + 4);
+            if (t == 0) base_load(c + 1);
+            if (t == 9) base_load(c + 2);
+            if (t == 3 || t == 12) {
+                base_write(t == 3 ? 1 : 0);
+                patch_load(t == 3 ? c + 1 : c + 2);
+            }
+            if (t == 6 || t == 15) patch_write(t == 6 ? 1 : 0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);      // nothing moves across a stage boundary (MFMAs of the next stage would wait on its own LDS reads)
+            if (HALO_ABL != 1) __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // epilogue: acc[i][j][r] = Y[m0 + wm*64 + i*32 + (r/4)*8 + hi*4 + r%4][pixel wp*64 + j*32 + lo]; a tile is RT full rows of image n
+    const float isx = 1.f / sx, isw = PK == PK_F16X2 ? 1.f / pow2_scale(*a.w_amax) : 1.f;    // powers of two: exact
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const size_t yo = (size_t)n * a.M * HW + (size_t)y0 * QW + wp * 64 + j * 32 + lo;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * BM + wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+                if (m < a.M) {
+                    const float av = PK == PK_F16X2 ? (acc[i][j][r] * isx) * isw : acc[i][j][r];
+                    const float v = act_apply(av + (a.bias ? a.bias[m] : 0.f), a.act, a.slope);
+                    st1((TA*)a.Y + yo + (size_t)m * HW, v);
+                }
+            }
+    }
+}
+
 static int bsplit_check(const pcgan_conv_desc* d) {
     PCGAN_CHECK(d, "conv2d_bsplit: null descriptor");
     PCGAN_CHECK(d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16, "conv2d_bsplit: dtype %d", d->dtype);
@@ -454,6 +932,34 @@ static void launch_bsplit(const pcgan_conv_desc* d, int bm, dim3 grid, hipStream
     } else {
         if (bm == 256) hipLaunchKernelGGL((bsplit_conv_fwd_kernel<MODE, 256, 3, float>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((bsplit_conv_fwd_kernel<MODE, 128, 3, float>), grid, dim3(256), 0, st, a);
+    }
+}
+
+// the halo kernel takes a layer when a pixel tile is whole image rows and the chunks come in pairs; PCGAN_BSPLIT_HALO=0 keeps
+// every layer on the per-tap gather kernel (A/B measurement)
+static bool halo_enabled() {
+    static const int on = [] {
+        const char* e = getenv("PCGAN_BSPLIT_HALO");
+        return e && e[0] == '0' ? 0 : 1;
+    }();
+    return on != 0;
+}
+static bool halo_geometry(int chan, int rows_out, int H, int W) {
+    return (W == 32 || W == 64) && H >= 4 && H % (128 / W) == 0 && chan % 32 == 0 && rows_out % 256 == 0;
+}
+static bool halo_shape(int chan, int rows_out, int H, int W) { return halo_enabled() && halo_geometry(chan, rows_out, H, W); }
+
+template <int MODE>
+static void launch_halo(const pcgan_conv_desc* d, int W, dim3 grid, hipStream_t st, const HaloArgs& a, bool f16 = false) {
+    if (d->dtype == PCGAN_BF16) {
+        if (W == 32) hipLaunchKernelGGL((bsplit_halo_kernel<MODE, PK_BF16, bf16, 32>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((bsplit_halo_kernel<MODE, PK_BF16, bf16, 64>), grid, dim3(512), 0, st, a);
+    } else if (f16) {
+        if (W == 32) hipLaunchKernelGGL((bsplit_halo_kernel<MODE, PK_F16X2, float, 32>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((bsplit_halo_kernel<MODE, PK_F16X2, float, 64>), grid, dim3(512), 0, st, a);
+    } else {
+        if (W == 32) hipLaunchKernelGGL((bsplit_halo_kernel<MODE, PK_BF16X3, float, 32>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((bsplit_halo_kernel<MODE, PK_BF16X3, float, 64>), grid, dim3(512), 0, st, a);
     }
 }
 
@@ -508,6 +1014,15 @@ extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const void* x, 
     a.a_bytes = (unsigned)ab;
     const long ptiles = ((long)d->N * d->P * d->Q + 127) / 128;
     const dim3 grid((unsigned)(ptiles * a.nMt));
+    if (d->pad_mode == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && pcgan::halo_shape(d->C, d->K, d->H, d->W)) {
+        pcgan::HaloArgs h;
+        h.X = x; h.A = packed; h.bias = bias; h.Y = y;
+        h.N = d->N; h.C = d->C; h.H = d->H; h.M = d->K; h.nMt = a.nMt; h.nch = d->C / 16; h.act = act; h.slope = slope;
+        h.x_bytes = a.x_bytes; h.a_bytes = a.a_bytes; h.x_amax = h.w_amax = nullptr;
+        pcgan::launch_halo<pcgan::BH_FWD>(d, d->W, grid, (hipStream_t)s, h);
+        PCGAN_LAUNCH_CHECK();
+        return 0;
+    }
     if (d->pad_mode == 1) pcgan::launch_bsplit<pcgan::BS_FWD_REFLECT>(d, bm, grid, (hipStream_t)s, a);
     else pcgan::launch_bsplit<pcgan::BS_FWD_ZERO>(d, bm, grid, (hipStream_t)s, a);
     PCGAN_LAUNCH_CHECK();
@@ -560,6 +1075,16 @@ extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const void
     a.phase_bytes = (unsigned)per_phase;
     a.a_bytes = (unsigned)(3 * per_phase);
     a.nst_split = 0;
+    if (pcgan::halo_shape(d->K, d->C, d->H, d->W)) {      // plain flipped weights = row class 0 of the packed buffer
+        pcgan::HaloArgs h;
+        h.X = dy; h.A = packed; h.bias = nullptr; h.Y = dx;
+        h.N = d->N; h.C = d->K; h.H = d->H; h.M = d->C; h.nMt = a.nMt; h.nch = d->K / 16; h.act = PCGAN_ACT_NONE; h.slope = 0.f;
+        h.x_bytes = a.x_bytes; h.a_bytes = (unsigned)per_phase; h.x_amax = h.w_amax = nullptr;
+        const dim3 hgrid((unsigned)((long)d->N * d->H * d->W / 128 * a.nMt));
+        pcgan::launch_halo<pcgan::BH_DGRAD>(d, d->W, hgrid, (hipStream_t)s, h);
+        PCGAN_LAUNCH_CHECK();
+        return 0;
+    }
     const long rows[3] = {(long)d->H - 2, 1, 1};
     long t = 0;
     for (int p = 0; p < 3; ++p) {
@@ -651,6 +1176,98 @@ extern "C" int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const vo
     PCGAN_LAUNCH_CHECK();
     const size_t total = (size_t)d->K * d->C * 9;
     hipLaunchKernelGGL(pcgan::bsplit_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, dw, splits, total, accumulate);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fp16 two-piece route of the reflection-padded 3x3 convolution (forward + data gradient), fp32 tensors -------------------------
+// packed buffer: [2 pieces][M tile][stage][k half][256 rows][8 fp16] (data gradient: three row classes of it, the window kernel reads
+// the first) followed by 256 bytes whose first float is the weights' largest magnitude
+static size_t hsplit_body_bytes(const pcgan_conv_desc* d, int pass) {
+    const int rows = pass == PCGAN_PASS_FWD ? d->K : d->C, chan = pass == PCGAN_PASS_FWD ? d->C : d->K;
+    const size_t nMt = (rows + 255) / 256, nst = (size_t)(chan / 16) * 9;
+    return (pass == PCGAN_PASS_FWD ? 1 : 3) * 2 * nMt * nst * 32 * 256;
+}
+
+extern "C" int pcgan_conv2d_hsplit_supported(const pcgan_conv_desc* d, int pass) {
+    if (!d || d->dtype != PCGAN_F32 || d->stride != 1 || d->pad_mode != 1 || d->pad != 1 || d->R != 3 || d->S != 3) return 0;
+    if (d->P != d->H || d->Q != d->W || (size_t)d->N * (d->C > d->K ? d->C : d->K) * d->H * d->W * 4 >= 0x80000000ull) return 0;
+    if (pass == PCGAN_PASS_FWD) return pcgan::halo_geometry(d->C, d->K, d->H, d->W) && hsplit_body_bytes(d, pass) < 0x80000000ull;
+    if (pass == PCGAN_PASS_BWD_DATA) return pcgan::halo_geometry(d->K, d->C, d->H, d->W) && hsplit_body_bytes(d, pass) < 0x80000000ull;
+    return 0;
+}
+
+extern "C" size_t pcgan_conv2d_hsplit_packed_bytes(const pcgan_conv_desc* d, int pass) {
+    return pcgan_conv2d_hsplit_supported(d, pass) ? hsplit_body_bytes(d, pass) + 256 : 0;
+}
+
+extern "C" int pcgan_absmax(const void* x, size_t n, int dtype, float* out, pcgan_stream_t s) {
+    PCGAN_CHECK(x && out && n > 0, "absmax: null pointer or empty tensor");
+    PCGAN_CHECK(dtype == PCGAN_F32 || dtype == PCGAN_BF16, "absmax: dtype %d", dtype);
+    hipStream_t st = (hipStream_t)s;
+    PCGAN_CHECK(hipMemsetAsync(out, 0, sizeof(float), st) == hipSuccess, "absmax: memset failed");
+    const size_t want = (n / 4 + 255) / 256;
+    const dim3 grid((unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want)));
+    if (dtype == PCGAN_BF16) hipLaunchKernelGGL(pcgan::absmax_kernel<pcgan::bf16>, grid, dim3(256), 0, st, (const pcgan::bf16*)x, n, (unsigned*)out);
+    else hipLaunchKernelGGL(pcgan::absmax_kernel<float>, grid, dim3(256), 0, st, (const float*)x, n, (unsigned*)out);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_conv2d_hsplit_pack(const pcgan_conv_desc* d, int pass, const float* w, void* packed, pcgan_stream_t s) {
+    PCGAN_CHECK(pcgan_conv2d_hsplit_supported(d, pass), "conv2d_hsplit_pack: unsupported shape or pass");
+    PCGAN_CHECK(w && packed, "conv2d_hsplit_pack: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    const size_t body = hsplit_body_bytes(d, pass);
+    float* amax = (float*)((char*)packed + body);
+    if (pcgan_absmax(w, (size_t)d->K * d->C * 9, PCGAN_F32, amax, s)) return 1;
+    if (pass == PCGAN_PASS_FWD) {
+        const int nMt = (d->K + 255) / 256, nst = (d->C / 16) * 9;
+        const size_t per_piece = (size_t)nMt * nst * 16 * 256;
+        const int blocks = (int)((per_piece + 255) / 256 > 4096 ? 4096 : (per_piece + 255) / 256);
+        hipLaunchKernelGGL(pcgan::bsplit_pack_kernel, dim3(blocks), dim3(256), 0, st, w, (__bf16*)packed, d->K, d->C, 9, nMt, nst, 1, 2, amax);
+    } else {
+        const int nMt = (d->C + 255) / 256, nst = (d->K / 16) * 9;
+        const size_t total = 3 * (size_t)nMt * nst * 16 * 256;
+        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        hipLaunchKernelGGL(pcgan::bsplit_pack_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w, (__bf16*)packed, d->K, d->C, nMt, nst, 1, 2, amax);
+    }
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, const void* packed, const float* bias,
+                                       void* y, int act, float slope, pcgan_stream_t s) {
+    PCGAN_CHECK(pcgan_conv2d_hsplit_supported(d, PCGAN_PASS_FWD), "conv2d_fwd_hsplit: unsupported shape");
+    PCGAN_CHECK(x && x_amax && packed && y, "conv2d_fwd_hsplit: null pointer");
+    const size_t body = hsplit_body_bytes(d, PCGAN_PASS_FWD);
+    pcgan::HaloArgs h;
+    h.X = x; h.A = packed; h.bias = bias; h.Y = y;
+    h.N = d->N; h.C = d->C; h.H = d->H; h.M = d->K; h.nMt = (d->K + 255) / 256; h.nch = d->C / 16; h.act = act; h.slope = slope;
+    h.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
+    h.a_bytes = (unsigned)body;
+    h.x_amax = x_amax;
+    h.w_amax = (const float*)((const char*)packed + body);
+    const dim3 grid((unsigned)((long)d->N * d->H * d->W / 128 * h.nMt));
+    pcgan::launch_halo<pcgan::BH_FWD>(d, d->W, grid, (hipStream_t)s, h, true);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, const void* packed, void* dx,
+                                            pcgan_stream_t s) {
+    PCGAN_CHECK(pcgan_conv2d_hsplit_supported(d, PCGAN_PASS_BWD_DATA), "conv2d_bwd_data_hsplit: unsupported shape");
+    PCGAN_CHECK(dy && dy_amax && packed && dx, "conv2d_bwd_data_hsplit: null pointer");
+    const size_t body = hsplit_body_bytes(d, PCGAN_PASS_BWD_DATA);
+    pcgan::HaloArgs h;
+    h.X = dy; h.A = packed; h.bias = nullptr; h.Y = dx;
+    h.N = d->N; h.C = d->K; h.H = d->H; h.M = d->C; h.nMt = (d->C + 255) / 256; h.nch = d->K / 16; h.act = PCGAN_ACT_NONE; h.slope = 0.f;
+    h.x_bytes = (unsigned)((size_t)d->N * d->K * d->H * d->W * 4);
+    h.a_bytes = (unsigned)(body / 3);        // plain flipped weights = row class 0
+    h.x_amax = dy_amax;
+    h.w_amax = (const float*)((const char*)packed + body);
+    const dim3 grid((unsigned)((long)d->N * d->H * d->W / 128 * h.nMt));
+    pcgan::launch_halo<pcgan::BH_DGRAD>(d, d->W, grid, (hipStream_t)s, h, true);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

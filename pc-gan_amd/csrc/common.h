@@ -122,4 +122,17 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
     return r;
 }
 
+// largest v over the workgroup, thread 0 gets it (others: a partial value)
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+
 }  // namespace pcgan

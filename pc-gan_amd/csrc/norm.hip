@@ -363,7 +363,7 @@ template <int E, typename T>
 __global__ void __launch_bounds__(1024) instnorm_fwd_fused_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                                    T* __restrict__ y, float* __restrict__ mean_nc,
                                                                    float* __restrict__ m2_nc, int HW, float eps, int act,
-                                                                   float slope) {
+                                                                   float slope, unsigned* __restrict__ y_amax) {
     __shared__ float scratch[16];
     const size_t plane = blockIdx.x;
     const int NT = blockDim.x, n4 = HW >> 2;
@@ -390,6 +390,7 @@ __global__ void __launch_bounds__(1024) instnorm_fwd_fused_kernel(const T* __res
     const float sh = -mean * rstd;
     const T* rp = res ? res + plane * (size_t)HW : nullptr;
     T* yp = y + plane * (size_t)HW;
+    float am = 0.f;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         const int i = threadIdx.x + k * NT;
@@ -402,11 +403,19 @@ __global__ void __launch_bounds__(1024) instnorm_fwd_fused_kernel(const T* __res
             o.x = act_apply(o.x, act, slope); o.y = act_apply(o.y, act, slope);
             o.z = act_apply(o.z, act, slope); o.w = act_apply(o.w, act, slope);
             st4(yp + 4 * i, o);
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
     if (threadIdx.x == 0) {
         mean_nc[plane] = mean;
         m2_nc[plane] = m2;
+    }
+    // largest magnitude of y over the whole tensor (bit pattern of a non-negative float orders like an unsigned integer; the
+    // slot is zero before the launch): the fp16 route of the convolution that reads y scales by it (bf16x6_conv.hip)
+    if (y_amax) {
+        am = block_max(am, scratch);
+        // (8192 workgroups on one address: the atomic is issued only by a workgroup that would raise the value it reads)
+        if (threadIdx.x == 0 && __float_as_uint(am) > __atomic_load_n(y_amax, __ATOMIC_RELAXED)) atomicMax(y_amax, __float_as_uint(am));
     }
 }
 
@@ -415,7 +424,7 @@ __global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const T* __res
                                                                    const T* __restrict__ y, const float* __restrict__ mean_nc,
                                                                    const float* __restrict__ m2_nc, T* __restrict__ dx,
                                                                    float* __restrict__ dx_psum, int HW, float eps, int act,
-                                                                   float slope) {
+                                                                   float slope, unsigned* __restrict__ dx_amax) {
     __shared__ float scratch[16];
     const size_t plane = blockIdx.x;
     const int NT = blockDim.x, n4 = HW >> 2;
@@ -449,7 +458,7 @@ __global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const T* __res
     s2 = block_sum(s2, scratch);
     const float m1 = s1 / (float)HW, mm2 = s2 / (float)HW;
     T* op = dx + plane * (size_t)HW;
-    float ps = 0.f;
+    float ps = 0.f, am = 0.f;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         const int i = threadIdx.x + k * NT;
@@ -458,6 +467,7 @@ __global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const T* __res
                                          rstd * (g[k].z - m1 - xh[k].z * mm2), rstd * (g[k].w - m1 - xh[k].w * mm2));
             st4(op + 4 * i, o);
             ps += (o.x + o.y) + (o.z + o.w);
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
     // sum of dx over the plane, out of the registers that just stored it: the bias gradient of the convolution in front of
@@ -466,6 +476,10 @@ __global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const T* __res
     if (dx_psum) {
         ps = block_sum(ps, scratch);
         if (threadIdx.x == 0) dx_psum[plane] = ps;
+    }
+    if (dx_amax) {     // largest magnitude of dx over the whole tensor, as in the forward kernel
+        am = block_max(am, scratch);
+        if (threadIdx.x == 0 && __float_as_uint(am) > __atomic_load_n(dx_amax, __ATOMIC_RELAXED)) atomicMax(dx_amax, __float_as_uint(am));
     }
 }
 
@@ -571,26 +585,27 @@ extern "C" int pcgan_norm_bwd_apply(const void* dy, const void* x, const void* y
 
 template <typename T>
 static void launch_instnorm_fwd(int E, int NT, int planes, hipStream_t st, const void* x, const void* residual, void* y, float* mean_nc,
-                                float* m2_nc, int HW, float eps, int act, float slope) {
+                                float* m2_nc, int HW, float eps, int act, float slope, unsigned* amax) {
     const T* xp = (const T*)x;
     const T* rp = (const T*)residual;
     T* yp = (T*)y;
-    if (E == 1) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<1, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope);
-    else if (E == 4) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<4, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope);
-    else hipLaunchKernelGGL((instnorm_fwd_fused_kernel<16, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope);
+    if (E == 1) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<1, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope, amax);
+    else if (E == 4) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<4, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope, amax);
+    else hipLaunchKernelGGL((instnorm_fwd_fused_kernel<16, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope, amax);
 }
 
-extern "C" int pcgan_instnorm_fwd(const void* x, const void* residual, void* y, float* mean_nc, float* m2_nc, int N,
+extern "C" int pcgan_instnorm_fwd(const void* x, const void* residual, void* y, float* mean_nc, float* m2_nc, float* y_amax, int N,
                                   int C, int HW, float eps, int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(x && y && mean_nc && m2_nc && N > 0 && C > 0 && HW > 0, "instnorm_fwd: bad arguments");
     int NT, E;
     fused_plan(HW, &NT, &E);
     hipStream_t st = (hipStream_t)s;
+    PCGAN_CHECK(!y_amax || (E != 0 && dtype == PCGAN_F32), "instnorm_fwd: y_amax only from the register-resident fp32 kernel (pcgan_instnorm_fused)");
     if (E == 0) {  // plane does not fit the register-resident kernel: statistics pass + apply pass
         if (pcgan_plane_stats(x, mean_nc, m2_nc, N * C, HW, dtype, s)) return 1;
         return pcgan_norm_act_fwd(x, mean_nc, m2_nc, nullptr, nullptr, residual, y, N, C, HW, 1, eps, act, slope, dtype, s);
     }
-    PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_fwd<T>(E, NT, N * C, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope));
+    PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_fwd<T>(E, NT, N * C, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope, (unsigned*)y_amax));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -603,25 +618,26 @@ extern "C" int pcgan_instnorm_fused(int HW) {
 
 template <typename T>
 static void launch_instnorm_bwd(int E, int NT, int planes, hipStream_t st, const void* dy, const void* x, const void* y, const float* mean_nc,
-                                const float* m2_nc, void* dx, float* dx_psum, int HW, float eps, int act, float slope) {
+                                const float* m2_nc, void* dx, float* dx_psum, int HW, float eps, int act, float slope, unsigned* amax) {
     const T* dp = (const T*)dy;
     const T* xp = (const T*)x;
     const T* yp = (const T*)y;
     T* op = (T*)dx;
-    if (E == 1) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope);
-    else if (E == 4) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<4, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope);
-    else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<16, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope);
+    if (E == 1) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope, amax);
+    else if (E == 4) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<4, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope, amax);
+    else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<16, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope, amax);
 }
 
 extern "C" int pcgan_instnorm_bwd(const void* dy, const void* x, const void* y, const float* mean_nc,
-                                  const float* m2_nc, void* dx, float* dx_psum, float* ws_s1s2, int N, int C, int HW, float eps,
-                                  int act, float slope, int dtype, pcgan_stream_t s) {
+                                  const float* m2_nc, void* dx, float* dx_psum, float* dx_amax, float* ws_s1s2, int N, int C, int HW,
+                                  float eps, int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && x && mean_nc && m2_nc && dx, "instnorm_bwd: null pointer");
     PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "instnorm_bwd: activation mask needs y");
     int NT, E;
     fused_plan(HW, &NT, &E);
     hipStream_t st = (hipStream_t)s;
     PCGAN_CHECK(E != 0 || !dx_psum, "instnorm_bwd: plane sums of dx come out of the register-resident kernel only (pcgan_instnorm_fused)");
+    PCGAN_CHECK(!dx_amax || (E != 0 && dtype == PCGAN_F32), "instnorm_bwd: dx_amax only from the register-resident fp32 kernel (pcgan_instnorm_fused)");
     if (E == 0) {
         PCGAN_CHECK(ws_s1s2, "instnorm_bwd: the two-pass fallback needs 2*N*C floats of workspace");
         if (pcgan_norm_bwd_stats(dy, x, y, mean_nc, m2_nc, ws_s1s2, ws_s1s2 + (size_t)N * C, N, C, HW, 1, eps, act, slope, dtype, s))
@@ -629,7 +645,7 @@ extern "C" int pcgan_instnorm_bwd(const void* dy, const void* x, const void* y, 
         return pcgan_norm_bwd_apply(dy, x, y, mean_nc, m2_nc, nullptr, ws_s1s2, ws_s1s2 + (size_t)N * C, dx, nullptr, N, C,
                                     HW, 1, eps, act, slope, dtype, s);
     }
-    PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_bwd<T>(E, NT, N * C, st, dy, x, y, mean_nc, m2_nc, dx, dx_psum, HW, eps, act, slope));
+    PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_bwd<T>(E, NT, N * C, st, dy, x, y, mean_nc, m2_nc, dx, dx_psum, HW, eps, act, slope, (unsigned*)dx_amax));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

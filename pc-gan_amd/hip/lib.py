@@ -61,8 +61,8 @@ SIGNATURES = {
     'pcgan_bn_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     'pcgan_bn_fwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _i, _vp]),
     'pcgan_bn_bwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
-    'pcgan_instnorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
-    'pcgan_instnorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
+    'pcgan_instnorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
+    'pcgan_instnorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
     'pcgan_instnorm_fused': (_i, [_i]),
     'pcgan_sum_planes': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'pcgan_maxpool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -88,6 +88,12 @@ SIGNATURES = {
     'pcgan_conv2d_bsplit_wgrad_supported': (_i, [_dp]),
     'pcgan_conv2d_bsplit_wgrad_workspace_bytes': (_sz, [_dp]),
     'pcgan_conv2d_bwd_weight_bsplit': (_i, [_dp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    'pcgan_absmax': (_i, [_vp, _sz, _i, _vp, _vp]),
+    'pcgan_conv2d_hsplit_supported': (_i, [_dp, _i]),
+    'pcgan_conv2d_hsplit_packed_bytes': (_sz, [_dp, _i]),
+    'pcgan_conv2d_hsplit_pack': (_i, [_dp, _i, _vp, _vp, _vp]),
+    'pcgan_conv2d_fwd_hsplit': (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
+    'pcgan_conv2d_bwd_data_hsplit': (_i, [_dp, _vp, _vp, _vp, _vp, _vp]),
     'pcgan_image_transform_band': (_i, [_ip, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     'pcgan_image_transform': (_i, [_ip, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }

@@ -196,6 +196,49 @@ def invalidate_packed_weights():
 BF16X6 = os.environ.get('PCGAN_BF16X6', '1') == '1'
 PASS_FWD_BSPLIT = 100    # cache keys only
 PASS_BWD_BSPLIT = 101
+PASS_FWD_HSPLIT = 102
+PASS_BWD_HSPLIT = 103
+# Which split the fp32 residual convolutions (forward, data gradient) take on the matrix pipe: 'f16' = two scaled fp16 pieces, three
+# products (csrc/bf16x6_conv.hip, "fp16 route"); 'bf16' = three bf16 pieces, six products.  Same measured error, half the MFMAs.
+HSPLIT = os.environ.get('PCGAN_SPLIT', 'f16') == 'f16'
+
+
+AMAX_STATS = {'attached': 0, 'computed': 0}     # operand maxima handed over by the producing kernel / taken by an absmax pass
+_AMAX_ARENA = {}
+
+
+def _amax_slot(device):
+    """one zeroed float on the device for a producer's atomic max (a slot is used once; an arena of 65536 serves ~600 steps)"""
+    cur = torch.cuda.current_stream()
+    a = _AMAX_ARENA.get(device)
+    if a is None or a[1] >= a[0].numel():
+        buf = torch.zeros(1 << 16, dtype=torch.float32, device=device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        a = _AMAX_ARENA[device] = [buf, 0, ev, cur.cuda_stream, set()]
+    if cur.cuda_stream != a[3] and cur.cuda_stream not in a[4]:      # another stream: after the arena's zero fill
+        cur.wait_event(a[2])
+        a[4].add(cur.cuda_stream)
+    i = a[1]
+    a[1] += 1
+    return a[0][i:i + 1]
+
+
+def _attach_amax(t, slot):
+    t._pcgan_amax = (t._version, slot)
+
+
+def amax_of(x):
+    """[1] fp32 device tensor with the largest magnitude of x: the value its producer attached (`_pcgan_amax`, valid for the
+    tensor version it was attached at) or one pcgan_absmax pass."""
+    ent = x.__dict__.get('_pcgan_amax')
+    if ent is not None and ent[0] == x._version:
+        AMAX_STATS['attached'] += 1
+        return ent[1]
+    AMAX_STATS['computed'] += 1
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().pcgan_absmax(_p(x), x.numel(), _DTYPES[x.dtype], _p(out), _stream()), 'absmax')
+    return out
 
 
 def _packed_weights(lib, d, pass_, w, cache):
@@ -207,8 +250,9 @@ def _packed_weights(lib, d, pass_, w, cache):
         if ent[3] != cur.cuda_stream:      # packed on another stream (branch streams): order this use after the pack
             cur.wait_event(ent[2])
         return ent[1]
-    bsplit = pass_ in (PASS_FWD_BSPLIT, PASS_BWD_BSPLIT)
-    if pass_ == PASS_FWD_BSPLIT:
+    if pass_ in (PASS_FWD_HSPLIT, PASS_BWD_HSPLIT):
+        nb = int(lib.pcgan_conv2d_hsplit_packed_bytes(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HSPLIT else _L.PASS_BWD_DATA))
+    elif pass_ == PASS_FWD_BSPLIT:
         nb = int(lib.pcgan_conv2d_bsplit_packed_bytes(ctypes.byref(d)))
     elif pass_ == PASS_BWD_BSPLIT:
         nb = int(lib.pcgan_conv2d_bsplit_dgrad_packed_bytes(ctypes.byref(d)))
@@ -222,7 +266,10 @@ def _packed_weights(lib, d, pass_, w, cache):
                 cur.wait_stream(st)
     else:
         buf = _ws(nb, w.device)
-    if pass_ == PASS_FWD_BSPLIT:
+    if pass_ in (PASS_FWD_HSPLIT, PASS_BWD_HSPLIT):
+        _L.check(lib.pcgan_conv2d_hsplit_pack(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HSPLIT else _L.PASS_BWD_DATA, _p(w), _p(buf),
+                                              _stream()), 'conv2d_hsplit_pack')
+    elif pass_ == PASS_FWD_BSPLIT:
         _L.check(lib.pcgan_conv2d_bsplit_pack(ctypes.byref(d), _p(w), _p(buf), _stream()), 'conv2d_bsplit_pack')
     elif pass_ == PASS_BWD_BSPLIT:
         _L.check(lib.pcgan_conv2d_bsplit_dgrad_pack(ctypes.byref(d), _p(w), _p(buf), _stream()), 'conv2d_bsplit_dgrad_pack')
@@ -250,12 +297,17 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
     if pack_cache is not None:
         # (one tile shape, no split-K yet: only where whole 128 x 128 tiles fill the chip, i.e. the residual-block convolutions)
         bsplit = (BF16X6 or dt == BF16) and K % 128 == 0 and N * d.P * d.Q >= 16384 and lib.pcgan_conv2d_bsplit_supported(ctypes.byref(d))
-        pk = _packed_weights(lib, d, PASS_FWD_BSPLIT if bsplit else _L.PASS_FWD, w, pack_cache)
+        hsplit = bsplit and HSPLIT and dt == F32 and lib.pcgan_conv2d_hsplit_supported(ctypes.byref(d), _L.PASS_FWD)
+        pk = _packed_weights(lib, d, PASS_FWD_HSPLIT if hsplit else (PASS_FWD_BSPLIT if bsplit else _L.PASS_FWD), w, pack_cache)
+        xmax = amax_of(x) if hsplit else None
         ev = None
         if KERNEL_TIMER is not None and KERNEL_TIMER['key'] == (N, C, H, W, K, R, S, stride, pad, pad_mode):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        if bsplit:
+        if hsplit:
+            _L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), _p(x), _p(xmax), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
+                     'conv2d_fwd_hsplit')
+        elif bsplit:
             _L.check(lib.pcgan_conv2d_fwd_bsplit(ctypes.byref(d), _p(x), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
                      'conv2d_fwd_bsplit')
         else:
@@ -286,6 +338,11 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
     ws = _ws(nb, dy.device)
     if pack_cache is not None:
         if (BF16X6 or dt == BF16) and bias is None and C % 128 == 0 and N * H * W >= 16384 and lib.pcgan_conv2d_bsplit_dgrad_supported(ctypes.byref(d)):
+            if HSPLIT and dt == F32 and lib.pcgan_conv2d_hsplit_supported(ctypes.byref(d), _L.PASS_BWD_DATA):
+                pk = _packed_weights(lib, d, PASS_BWD_HSPLIT, w, pack_cache)
+                _L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), _p(dy), _p(amax_of(dy)), _p(pk), _p(dx), _stream()),
+                         'conv2d_bwd_data_hsplit')
+                return dx
             pk = _packed_weights(lib, d, PASS_BWD_BSPLIT, w, pack_cache)
             _L.check(lib.pcgan_conv2d_bwd_data_bsplit(ctypes.byref(d), _p(dy), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_bsplit')
             return dx
@@ -510,8 +567,13 @@ def instnorm_fwd(x, residual, eps, act, slope):
     y = torch.empty_like(x)
     mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
     m2 = torch.empty(N * C, dtype=torch.float32, device=x.device)
-    _L.check(_L.load().pcgan_instnorm_fwd(_p(x), _p(residual), _p(y), _p(mean), _p(m2), N, C, HW, float(eps), act,
-                                          float(slope), dt, _stream()), 'instnorm_fwd')
+    lib = _L.load()
+    # the largest magnitude of y for the fp16 route of the convolution that reads it (residual blocks: width 32 / 64 planes)
+    slot = _amax_slot(x.device) if HSPLIT and dt == F32 and x.shape[-1] in (32, 64) and lib.pcgan_instnorm_fused(HW) else None
+    _L.check(lib.pcgan_instnorm_fwd(_p(x), _p(residual), _p(y), _p(mean), _p(m2), _p(slot), N, C, HW, float(eps), act,
+                                    float(slope), dt, _stream()), 'instnorm_fwd')
+    if slot is not None:
+        _attach_amax(y, slot)
     return y, mean, m2
 
 
@@ -530,10 +592,13 @@ def instnorm_bwd(dy, x, y, mean, m2, eps, act, slope):
     fused = bool(lib.pcgan_instnorm_fused(HW))
     psum = torch.empty(N * C, dtype=torch.float32, device=x.device) if fused else None
     ws = None if fused else torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
-    _L.check(lib.pcgan_instnorm_bwd(_p(dy), _p(x), _p(y), _p(mean), _p(m2), _p(dx), _p(psum), _p(ws), N, C, HW, float(eps),
+    slot = _amax_slot(x.device) if fused and HSPLIT and dt == F32 and x.shape[-1] in (32, 64) else None
+    _L.check(lib.pcgan_instnorm_bwd(_p(dy), _p(x), _p(y), _p(mean), _p(m2), _p(dx), _p(psum), _p(slot), _p(ws), N, C, HW, float(eps),
                                     act, float(slope), dt, _stream()), 'instnorm_bwd')
     if psum is not None:
         dx._pcgan_plane_sums = psum
+    if slot is not None:
+        _attach_amax(dx, slot)
     return dx
 
 

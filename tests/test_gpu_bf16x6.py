@@ -48,6 +48,11 @@ def _run(dev, N, C, H, W, K, k, pad, pad_mode, act=0, bias=True, seed=0):
     (2, 48, 8, 8, 200, 1, 0, 0, 0),          # 1x1, two channel tiles
     (1, 128, 6, 6, 64, 3, 0, 0, 0),          # valid convolution (output 4x4)
     (2, 32, 12, 10, 512, 3, 1, 1, 1),        # two 256-row channel tiles (8-wave workgroups), ragged pixel tile
+    # shapes the window ("halo") kernel takes: width 32 / 64, whole image rows per pixel tile, channel chunks in pairs
+    (1, 32, 4, 32, 256, 3, 1, 1, 1),         # one tile per image: both mirror rows in its window
+    (3, 96, 12, 32, 256, 3, 1, 1, 0),        # three tiles per image, three chunk pairs
+    (2, 64, 8, 64, 512, 3, 1, 1, 2),         # width 64 (two rows per tile), two 256-row channel tiles
+    (1, 32, 64, 64, 256, 3, 1, 1, 0),        # the 256x256 configurations' plane
 ])
 def test_bsplit_forward_has_fp32_accuracy(dev, N, C, H, W, K, k, pad, mode, act):
     e6, e32 = _run(dev, N, C, H, W, K, k, pad, mode, act)
@@ -90,6 +95,11 @@ def test_host_switch_routes_large_convs_and_follows_the_weights(dev, monkeypatch
     (3, 64, 9, 7, 48),          # ragged tiles, 128-row tile variant, K not a multiple of 32
     (1, 512, 4, 4, 32),         # smallest grid (rows 0..3: both mirror rows adjacent), two 256-row tiles
     (2, 128, 6, 20, 16),        # one 16-channel K chunk
+    # the window kernel: sums for rows / columns 1 and H-2 / W-2 as extra window rows / columns
+    (1, 512, 4, 32, 32),        # one tile per image holds rows 1 and H-2; two 256-row tiles
+    (2, 256, 4, 64, 64),        # width 64: rows {0, 1} and {2, 3} in different tiles
+    (3, 256, 12, 32, 96),       # three tiles per image: first / middle / last differ in their sum rows
+    (1, 256, 64, 64, 32),       # the 256x256 configurations' plane
 ])
 def test_bsplit_reflect_data_gradient(dev, N, C, H, W, K):
     """dx of ReflectionPad2d(1) + Conv2d(3x3) through the split kernel against autograd in float64 and the fp32 kernel"""
@@ -145,3 +155,91 @@ def test_bsplit_weight_gradient(dev, N, C, H, W, K, acc):
     got = dw.double().cpu() - (base.double() if acc else 0)
     e = lambda t: float((t - ref).norm() / ref.norm())
     assert e(got) < 3e-6 and e(got) < 4 * e(dw32.double().cpu()) + 5e-7, (e(got), e(dw32.double().cpu()))
+
+
+# ---- the fp16 two-piece route (csrc/bf16x6_conv.hip "fp16 route"; C-ABI pcgan_conv2d_*_hsplit) ------------------------------------
+def _hsplit(dev, N, C, H, W, K, x, w, dgrad):
+    """forward (x = input) or data gradient (x = dy) through the fp16 route, and through the fp32 kernels of the product"""
+    from pcgan_amd.hip import lib as L, ops
+    lib = L.load()
+    d = ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 1)
+    pass_ = L.PASS_BWD_DATA if dgrad else L.PASS_FWD
+    assert lib.pcgan_conv2d_hsplit_supported(ctypes.byref(d), pass_)
+    xd, wd = x.to(dev), w.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    pk = torch.empty(lib.pcgan_conv2d_hsplit_packed_bytes(ctypes.byref(d), pass_), dtype=torch.uint8, device=dev)
+    L.check(lib.pcgan_conv2d_hsplit_pack(ctypes.byref(d), pass_, wd.data_ptr(), pk.data_ptr(), st), 'pack')
+    amax = torch.full((1,), float('nan'), device=dev)
+    L.check(lib.pcgan_absmax(xd.data_ptr(), xd.numel(), 0, amax.data_ptr(), st), 'absmax')
+    assert float(amax) == float(x.abs().max())
+    out = torch.full((N, C if dgrad else K, H, W), float('nan'), device=dev)
+    if dgrad:
+        L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), xd.data_ptr(), amax.data_ptr(), pk.data_ptr(), out.data_ptr(), st), 'dgrad')
+        ops_hs, ops.HSPLIT = ops.HSPLIT, False
+        try:
+            o32 = ops.conv2d_bwd_data(xd, wd, (H, W), 1, 1, 1)
+        finally:
+            ops.HSPLIT = ops_hs
+    else:
+        L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), xd.data_ptr(), amax.data_ptr(), pk.data_ptr(), None, out.data_ptr(), 0, 0.0, st), 'fwd')
+        o32 = ops.conv2d_fwd(xd, wd, None, 1, 1, 1)
+    torch.cuda.synchronize()
+    return out.cpu(), o32.cpu()
+
+
+HSPLIT_SHAPES = [
+    (2, 256, 32, 32, 256),      # the residual-block convolution
+    (1, 32, 4, 32, 256),        # one tile per image
+    (2, 64, 8, 64, 512),        # width 64, two 256-row tiles
+    (3, 96, 12, 32, 256),       # three tiles per image
+]
+
+
+@pytest.mark.parametrize('N,C,H,W,K', HSPLIT_SHAPES)
+@pytest.mark.parametrize('data', ['relu_normal', 'wide_range', 'tiny', 'huge'])
+def test_hsplit_forward_has_fp32_accuracy(dev, N, C, H, W, K, data):
+    g = torch.Generator().manual_seed(N + C + K)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    if data == 'relu_normal':
+        x = x.relu_()
+    elif data == 'wide_range':         # magnitudes over twelve decades inside one tensor
+        x = x * torch.pow(10.0, torch.rand(N, C, H, W, generator=g) * 12 - 9)
+        w = w * torch.pow(10.0, torch.rand(K, C, 3, 3, generator=g) * 6 - 3)
+    elif data == 'tiny':
+        x, w = x * 1e-30, w * 1e-6
+    else:
+        x, w = x * 1e12, w * 1e8
+    y, y32 = _hsplit(dev, N, C, H, W, K, x, w, False)
+    ref = R.conv2d(x.double(), w.double(), None, 1, 1, 1)
+    e = lambda t: float((t.double() - ref).norm() / ref.norm())
+    assert e(y) < 3e-6 and e(y) < 4 * e(y32) + 5e-7, (e(y), e(y32))
+
+
+@pytest.mark.parametrize('N,K,H,W,C', HSPLIT_SHAPES)
+@pytest.mark.parametrize('data', ['normal', 'wide_range'])
+def test_hsplit_reflect_data_gradient(dev, N, K, H, W, C, data):
+    g = torch.Generator().manual_seed(N + C + K + 1)
+    dy = torch.randn(N, K, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    if data == 'wide_range':
+        dy = dy * torch.pow(10.0, torch.rand(N, K, H, W, generator=g) * 12 - 9)
+    x = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
+    R.conv2d(x, w.double(), None, 1, 1, 1).backward(dy.double())
+    ref = x.grad
+    dx, dx32 = _hsplit(dev, N, C, H, W, K, dy, w, True)
+    e = lambda t: float((t.double() - ref).norm() / ref.norm())
+    assert e(dx) < 3e-6 and e(dx) < 4 * e(dx32) + 5e-7, (e(dx), e(dx32))
+
+
+def test_absmax_unaligned_and_ragged(dev):
+    from pcgan_amd.hip import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(10007, generator=g).to(dev)
+    out = torch.zeros(1, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for off, n in ((0, 10007), (1, 10006), (3, 5), (2, 4099), (5, 1)):
+        v = base[off:off + n]
+        L.check(lib.pcgan_absmax(v.data_ptr(), n, 0, out.data_ptr(), st), 'absmax')
+        assert float(out) == float(v.abs().max()), (off, n)
