@@ -169,14 +169,14 @@ int pcgan_bn_bwd_fused(const void* dy, const void* x, const void* y, const float
  * activation; mean / M2 are also returned for the backward and the running-stat update) and backward = one
  * read of dy, x (and y for the activation mask) + one write.  Planes that do not fit (HW % 4 != 0 or
  * HW > 65536) fall back to the two-pass kernels above; ws_s1s2 (2*N*C floats) is only used then. */
-int pcgan_instnorm_fwd(const void* x, const void* residual, void* y, float* mean_nc, float* m2_nc, float* y_amax, int N, int C,
+int pcgan_instnorm_fwd(const void* x, const void* residual, void* y, float* mean_nc, float* m2_nc, float* y_pmax, int N, int C,
                        int HW, float eps, int act, float slope, int dtype, pcgan_stream_t s);
 int pcgan_instnorm_bwd(const void* dy, const void* x, const void* y, const float* mean_nc, const float* m2_nc,
-                       void* dx, float* dx_psum, float* dx_amax, float* ws_s1s2, int N, int C, int HW, float eps, int act,
+                       void* dx, float* dx_psum, float* dx_pmax, float* ws_s1s2, int N, int C, int HW, float eps, int act,
                        float slope, int dtype, pcgan_stream_t s);
-/* y_amax / dx_amax (may be NULL; fp32 register-resident kernels only, see pcgan_instnorm_fused): one float, ZERO before the launch,
- * receives the largest magnitude of the output tensor (atomic max over the planes) -- what the fp16 route of the convolution that
- * consumes the tensor scales by (pcgan_conv2d_fwd_hsplit), without a separate pcgan_absmax pass. */
+/* y_pmax / dx_pmax (may be NULL; register-resident kernels only, see pcgan_instnorm_fused): [N*C] floats that receive the largest
+ * magnitude of each output plane -- the fp16 route of the convolution that consumes the tensor scales by the largest of them
+ * (pcgan_conv2d_fwd_hsplit with n_amax = N*C), without a separate pcgan_absmax pass over the tensor. */
 /* 1 when a plane of HW elements runs in the register-resident kernels.  Only then may pcgan_instnorm_bwd be given
  * dx_psum[N*C]: the sum of dx over each plane, taken from the registers that store dx.  The convolution in front of the
  * norm has its bias gradient = sum over n of these (reference: autograd of nn.Conv2d(bias=True) + nn.InstanceNorm2d,
@@ -282,8 +282,9 @@ int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const void* x, cons
  * tensors) with TWO fp16 pieces per operand and three products -- half the matrix instructions of the three-piece bf16 split at the
  * same measured error (scripts/micro/bf16_split: 5.3e-7 relative L2 at K = 2304, fp32 MFMA 6.1e-7).  fp16 has five exponent
  * bits: every operand tensor is scaled by the power of two that puts its largest magnitude into (2^13, 2^14], and the result is
- * scaled back exactly.  The largest magnitude is a DEVICE value (no host synchronisation): pcgan_absmax writes it, or the
- * producing kernel hands it over (pcgan_instnorm_* amax outputs).  It must be a true bound: a larger element would overflow.
+ * scaled back exactly.  The largest magnitude is a DEVICE value (no host synchronisation): x_amax[0 .. n_amax) holds partial
+ * maxima, the kernel takes the largest -- one float written by pcgan_absmax, or the per-plane maxima the producing kernel
+ * hands over (pcgan_instnorm_* pmax outputs).  It must be a true bound: a larger element would overflow.
  * pass = PCGAN_PASS_FWD | PCGAN_PASS_BWD_DATA; image width 32 or 64, 128 / width rows dividing the height, gathered channels a
  * multiple of 32, produced channels a multiple of 256.  packed: pcgan_conv2d_hsplit_packed_bytes(d, pass) bytes, valid for any
  * batch size; the pack call also stores the weights' largest magnitude in it. */
@@ -291,10 +292,10 @@ int pcgan_absmax(const void* x, size_t n, int dtype, float* out, pcgan_stream_t 
 int pcgan_conv2d_hsplit_supported(const pcgan_conv_desc* d, int pass);
 size_t pcgan_conv2d_hsplit_packed_bytes(const pcgan_conv_desc* d, int pass);
 int pcgan_conv2d_hsplit_pack(const pcgan_conv_desc* d, int pass, const float* w, void* packed, pcgan_stream_t s);
-int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, const void* packed, const float* bias,
-                            void* y, int act, float slope, pcgan_stream_t s);
-int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, const void* packed, void* dx,
-                                 pcgan_stream_t s);
+int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_amax, const void* packed,
+                            const float* bias, void* y, int act, float slope, pcgan_stream_t s);
+int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed,
+                                 void* dx, pcgan_stream_t s);
 
 #ifdef __cplusplus
 }

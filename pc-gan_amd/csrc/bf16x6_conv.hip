@@ -517,8 +517,9 @@ struct HaloArgs {
     int N, C, H, M, nMt, nch, act;
     float slope;
     unsigned x_bytes, a_bytes;
-    const float* x_amax;   // PK_F16X2: largest magnitude of X (device), and of the weights (written by the pack kernel)
+    const float* x_amax;   // PK_F16X2: x_namax partial maxima of |X| (device), and the weights' largest magnitude (pack kernel)
     const float* w_amax;
+    int x_namax;
 };
 
 // piece kinds: what an operand element becomes on its way to the matrix pipe
@@ -657,7 +658,13 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     // write 4 consecutive channels of one window entry (8 bytes per piece)
     typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
     typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
-    const float sx = PK == PK_F16X2 ? pow2_scale(*a.x_amax) : 1.f;
+    float sx = 1.f;
+    if constexpr (PK == PK_F16X2) {      // largest of the partial maxima the producer left (one per plane, or a single value)
+        float m = 0.f;
+        for (int i = tid; i < a.x_namax; i += NT) m = fmaxf(m, a.x_amax[i]);
+        sx = pow2_scale(block_max(m, reinterpret_cast<float*>(&As[0][0][0])));
+        __syncthreads();
+    }
     auto put_split = [&](unsigned lds, int buf, const float (&v)[4]) {
         char* dst = xs_bytes + (unsigned)buf * XBUF + lds;
         if constexpr (PK == PK_F16X2) {
@@ -1018,7 +1025,7 @@ extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const void* x, 
         pcgan::HaloArgs h;
         h.X = x; h.A = packed; h.bias = bias; h.Y = y;
         h.N = d->N; h.C = d->C; h.H = d->H; h.M = d->K; h.nMt = a.nMt; h.nch = d->C / 16; h.act = act; h.slope = slope;
-        h.x_bytes = a.x_bytes; h.a_bytes = a.a_bytes; h.x_amax = h.w_amax = nullptr;
+        h.x_bytes = a.x_bytes; h.a_bytes = a.a_bytes; h.x_amax = h.w_amax = nullptr; h.x_namax = 0;
         pcgan::launch_halo<pcgan::BH_FWD>(d, d->W, grid, (hipStream_t)s, h);
         PCGAN_LAUNCH_CHECK();
         return 0;
@@ -1079,7 +1086,7 @@ extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const void
         pcgan::HaloArgs h;
         h.X = dy; h.A = packed; h.bias = nullptr; h.Y = dx;
         h.N = d->N; h.C = d->K; h.H = d->H; h.M = d->C; h.nMt = a.nMt; h.nch = d->K / 16; h.act = PCGAN_ACT_NONE; h.slope = 0.f;
-        h.x_bytes = a.x_bytes; h.a_bytes = (unsigned)per_phase; h.x_amax = h.w_amax = nullptr;
+        h.x_bytes = a.x_bytes; h.a_bytes = (unsigned)per_phase; h.x_amax = h.w_amax = nullptr; h.x_namax = 0;
         const dim3 hgrid((unsigned)((long)d->N * d->H * d->W / 128 * a.nMt));
         pcgan::launch_halo<pcgan::BH_DGRAD>(d, d->W, hgrid, (hipStream_t)s, h);
         PCGAN_LAUNCH_CHECK();
@@ -1236,10 +1243,10 @@ extern "C" int pcgan_conv2d_hsplit_pack(const pcgan_conv_desc* d, int pass, cons
     return 0;
 }
 
-extern "C" int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, const void* packed, const float* bias,
-                                       void* y, int act, float slope, pcgan_stream_t s) {
+extern "C" int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_amax, const void* packed,
+                                       const float* bias, void* y, int act, float slope, pcgan_stream_t s) {
     PCGAN_CHECK(pcgan_conv2d_hsplit_supported(d, PCGAN_PASS_FWD), "conv2d_fwd_hsplit: unsupported shape");
-    PCGAN_CHECK(x && x_amax && packed && y, "conv2d_fwd_hsplit: null pointer");
+    PCGAN_CHECK(x && x_amax && n_amax > 0 && packed && y, "conv2d_fwd_hsplit: null pointer");
     const size_t body = hsplit_body_bytes(d, PCGAN_PASS_FWD);
     pcgan::HaloArgs h;
     h.X = x; h.A = packed; h.bias = bias; h.Y = y;
@@ -1247,6 +1254,7 @@ extern "C" int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, 
     h.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
     h.a_bytes = (unsigned)body;
     h.x_amax = x_amax;
+    h.x_namax = n_amax;
     h.w_amax = (const float*)((const char*)packed + body);
     const dim3 grid((unsigned)((long)d->N * d->H * d->W / 128 * h.nMt));
     pcgan::launch_halo<pcgan::BH_FWD>(d, d->W, grid, (hipStream_t)s, h, true);
@@ -1254,10 +1262,10 @@ extern "C" int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, 
     return 0;
 }
 
-extern "C" int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, const void* packed, void* dx,
-                                            pcgan_stream_t s) {
+extern "C" int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed,
+                                            void* dx, pcgan_stream_t s) {
     PCGAN_CHECK(pcgan_conv2d_hsplit_supported(d, PCGAN_PASS_BWD_DATA), "conv2d_bwd_data_hsplit: unsupported shape");
-    PCGAN_CHECK(dy && dy_amax && packed && dx, "conv2d_bwd_data_hsplit: null pointer");
+    PCGAN_CHECK(dy && dy_amax && n_amax > 0 && packed && dx, "conv2d_bwd_data_hsplit: null pointer");
     const size_t body = hsplit_body_bytes(d, PCGAN_PASS_BWD_DATA);
     pcgan::HaloArgs h;
     h.X = dy; h.A = packed; h.bias = nullptr; h.Y = dx;
@@ -1265,6 +1273,7 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void
     h.x_bytes = (unsigned)((size_t)d->N * d->K * d->H * d->W * 4);
     h.a_bytes = (unsigned)(body / 3);        // plain flipped weights = row class 0
     h.x_amax = dy_amax;
+    h.x_namax = n_amax;
     h.w_amax = (const float*)((const char*)packed + body);
     const dim3 grid((unsigned)((long)d->N * d->H * d->W / 128 * h.nMt));
     pcgan::launch_halo<pcgan::BH_DGRAD>(d, d->W, grid, (hipStream_t)s, h, true);

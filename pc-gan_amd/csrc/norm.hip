@@ -363,7 +363,7 @@ template <int E, typename T>
 __global__ void __launch_bounds__(1024) instnorm_fwd_fused_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                                    T* __restrict__ y, float* __restrict__ mean_nc,
                                                                    float* __restrict__ m2_nc, int HW, float eps, int act,
-                                                                   float slope, unsigned* __restrict__ y_amax) {
+                                                                   float slope, float* __restrict__ y_pmax) {
     __shared__ float scratch[16];
     const size_t plane = blockIdx.x;
     const int NT = blockDim.x, n4 = HW >> 2;
@@ -410,12 +410,11 @@ __global__ void __launch_bounds__(1024) instnorm_fwd_fused_kernel(const T* __res
         mean_nc[plane] = mean;
         m2_nc[plane] = m2;
     }
-    // largest magnitude of y over the whole tensor (bit pattern of a non-negative float orders like an unsigned integer; the
-    // slot is zero before the launch): the fp16 route of the convolution that reads y scales by it (bf16x6_conv.hip)
-    if (y_amax) {
+    // largest magnitude of y over this plane: the fp16 route of the convolution that reads y scales by the largest of them
+    // (bf16x6_conv.hip; a plain store per plane -- one atomic maximum for the tensor serialises 8192 workgroups on one address)
+    if (y_pmax) {
         am = block_max(am, scratch);
-        // (8192 workgroups on one address: the atomic is issued only by a workgroup that would raise the value it reads)
-        if (threadIdx.x == 0 && __float_as_uint(am) > __atomic_load_n(y_amax, __ATOMIC_RELAXED)) atomicMax(y_amax, __float_as_uint(am));
+        if (threadIdx.x == 0) y_pmax[plane] = am;
     }
 }
 
@@ -424,7 +423,7 @@ __global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const T* __res
                                                                    const T* __restrict__ y, const float* __restrict__ mean_nc,
                                                                    const float* __restrict__ m2_nc, T* __restrict__ dx,
                                                                    float* __restrict__ dx_psum, int HW, float eps, int act,
-                                                                   float slope, unsigned* __restrict__ dx_amax) {
+                                                                   float slope, float* __restrict__ dx_pmax) {
     __shared__ float scratch[16];
     const size_t plane = blockIdx.x;
     const int NT = blockDim.x, n4 = HW >> 2;
@@ -477,9 +476,9 @@ __global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const T* __res
         ps = block_sum(ps, scratch);
         if (threadIdx.x == 0) dx_psum[plane] = ps;
     }
-    if (dx_amax) {     // largest magnitude of dx over the whole tensor, as in the forward kernel
+    if (dx_pmax) {     // largest magnitude of dx over this plane, as in the forward kernel
         am = block_max(am, scratch);
-        if (threadIdx.x == 0 && __float_as_uint(am) > __atomic_load_n(dx_amax, __ATOMIC_RELAXED)) atomicMax(dx_amax, __float_as_uint(am));
+        if (threadIdx.x == 0) dx_pmax[plane] = am;
     }
 }
 
@@ -585,7 +584,7 @@ extern "C" int pcgan_norm_bwd_apply(const void* dy, const void* x, const void* y
 
 template <typename T>
 static void launch_instnorm_fwd(int E, int NT, int planes, hipStream_t st, const void* x, const void* residual, void* y, float* mean_nc,
-                                float* m2_nc, int HW, float eps, int act, float slope, unsigned* amax) {
+                                float* m2_nc, int HW, float eps, int act, float slope, float* amax) {
     const T* xp = (const T*)x;
     const T* rp = (const T*)residual;
     T* yp = (T*)y;
@@ -594,18 +593,18 @@ static void launch_instnorm_fwd(int E, int NT, int planes, hipStream_t st, const
     else hipLaunchKernelGGL((instnorm_fwd_fused_kernel<16, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope, amax);
 }
 
-extern "C" int pcgan_instnorm_fwd(const void* x, const void* residual, void* y, float* mean_nc, float* m2_nc, float* y_amax, int N,
+extern "C" int pcgan_instnorm_fwd(const void* x, const void* residual, void* y, float* mean_nc, float* m2_nc, float* y_pmax, int N,
                                   int C, int HW, float eps, int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(x && y && mean_nc && m2_nc && N > 0 && C > 0 && HW > 0, "instnorm_fwd: bad arguments");
     int NT, E;
     fused_plan(HW, &NT, &E);
     hipStream_t st = (hipStream_t)s;
-    PCGAN_CHECK(!y_amax || (E != 0 && dtype == PCGAN_F32), "instnorm_fwd: y_amax only from the register-resident fp32 kernel (pcgan_instnorm_fused)");
+    PCGAN_CHECK(!y_pmax || E != 0, "instnorm_fwd: plane maxima come out of the register-resident kernel only (pcgan_instnorm_fused)");
     if (E == 0) {  // plane does not fit the register-resident kernel: statistics pass + apply pass
         if (pcgan_plane_stats(x, mean_nc, m2_nc, N * C, HW, dtype, s)) return 1;
         return pcgan_norm_act_fwd(x, mean_nc, m2_nc, nullptr, nullptr, residual, y, N, C, HW, 1, eps, act, slope, dtype, s);
     }
-    PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_fwd<T>(E, NT, N * C, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope, (unsigned*)y_amax));
+    PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_fwd<T>(E, NT, N * C, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope, y_pmax));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -618,7 +617,7 @@ extern "C" int pcgan_instnorm_fused(int HW) {
 
 template <typename T>
 static void launch_instnorm_bwd(int E, int NT, int planes, hipStream_t st, const void* dy, const void* x, const void* y, const float* mean_nc,
-                                const float* m2_nc, void* dx, float* dx_psum, int HW, float eps, int act, float slope, unsigned* amax) {
+                                const float* m2_nc, void* dx, float* dx_psum, int HW, float eps, int act, float slope, float* amax) {
     const T* dp = (const T*)dy;
     const T* xp = (const T*)x;
     const T* yp = (const T*)y;
@@ -629,7 +628,7 @@ static void launch_instnorm_bwd(int E, int NT, int planes, hipStream_t st, const
 }
 
 extern "C" int pcgan_instnorm_bwd(const void* dy, const void* x, const void* y, const float* mean_nc,
-                                  const float* m2_nc, void* dx, float* dx_psum, float* dx_amax, float* ws_s1s2, int N, int C, int HW,
+                                  const float* m2_nc, void* dx, float* dx_psum, float* dx_pmax, float* ws_s1s2, int N, int C, int HW,
                                   float eps, int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && x && mean_nc && m2_nc && dx, "instnorm_bwd: null pointer");
     PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "instnorm_bwd: activation mask needs y");
@@ -637,7 +636,7 @@ extern "C" int pcgan_instnorm_bwd(const void* dy, const void* x, const void* y, 
     fused_plan(HW, &NT, &E);
     hipStream_t st = (hipStream_t)s;
     PCGAN_CHECK(E != 0 || !dx_psum, "instnorm_bwd: plane sums of dx come out of the register-resident kernel only (pcgan_instnorm_fused)");
-    PCGAN_CHECK(!dx_amax || (E != 0 && dtype == PCGAN_F32), "instnorm_bwd: dx_amax only from the register-resident fp32 kernel (pcgan_instnorm_fused)");
+    PCGAN_CHECK(E != 0 || !dx_pmax, "instnorm_bwd: plane maxima come out of the register-resident kernel only (pcgan_instnorm_fused)");
     if (E == 0) {
         PCGAN_CHECK(ws_s1s2, "instnorm_bwd: the two-pass fallback needs 2*N*C floats of workspace");
         if (pcgan_norm_bwd_stats(dy, x, y, mean_nc, m2_nc, ws_s1s2, ws_s1s2 + (size_t)N * C, N, C, HW, 1, eps, act, slope, dtype, s))
@@ -645,7 +644,7 @@ extern "C" int pcgan_instnorm_bwd(const void* dy, const void* x, const void* y, 
         return pcgan_norm_bwd_apply(dy, x, y, mean_nc, m2_nc, nullptr, ws_s1s2, ws_s1s2 + (size_t)N * C, dx, nullptr, N, C,
                                     HW, 1, eps, act, slope, dtype, s);
     }
-    PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_bwd<T>(E, NT, N * C, st, dy, x, y, mean_nc, m2_nc, dx, dx_psum, HW, eps, act, slope, (unsigned*)dx_amax));
+    PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_bwd<T>(E, NT, N * C, st, dy, x, y, mean_nc, m2_nc, dx, dx_psum, HW, eps, act, slope, dx_pmax));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

@@ -194,6 +194,7 @@ def invalidate_packed_weights():
 # operand split exactly into three bf16 pieces, six piece products per term (csrc/bf16x6_conv.hip): fp32-level error at
 # 1.5x the speed of the fp32 MFMA kernels.  PCGAN_BF16X6=0 routes them back to the fp32 MFMA implicit GEMM (A/B runs).
 BF16X6 = os.environ.get('PCGAN_BF16X6', '1') == '1'
+BSPLIT_MIN_PIXELS = 16384    # output pixels (N*P*Q) from which the one-tile-shape split kernels fill the chip (tests lower it)
 PASS_FWD_BSPLIT = 100    # cache keys only
 PASS_BWD_BSPLIT = 101
 PASS_FWD_HSPLIT = 102
@@ -204,33 +205,15 @@ HSPLIT = os.environ.get('PCGAN_SPLIT', 'f16') == 'f16'
 
 
 AMAX_STATS = {'attached': 0, 'computed': 0}     # operand maxima handed over by the producing kernel / taken by an absmax pass
-_AMAX_ARENA = {}
 
 
-def _amax_slot(device):
-    """one zeroed float on the device for a producer's atomic max (a slot is used once; an arena of 65536 serves ~600 steps)"""
-    cur = torch.cuda.current_stream()
-    a = _AMAX_ARENA.get(device)
-    if a is None or a[1] >= a[0].numel():
-        buf = torch.zeros(1 << 16, dtype=torch.float32, device=device)
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        a = _AMAX_ARENA[device] = [buf, 0, ev, cur.cuda_stream, set()]
-    if cur.cuda_stream != a[3] and cur.cuda_stream not in a[4]:      # another stream: after the arena's zero fill
-        cur.wait_event(a[2])
-        a[4].add(cur.cuda_stream)
-    i = a[1]
-    a[1] += 1
-    return a[0][i:i + 1]
-
-
-def _attach_amax(t, slot):
-    t._pcgan_amax = (t._version, slot)
+def _attach_amax(t, pmax):
+    t._pcgan_amax = (t._version, pmax)
 
 
 def amax_of(x):
-    """[1] fp32 device tensor with the largest magnitude of x: the value its producer attached (`_pcgan_amax`, valid for the
-    tensor version it was attached at) or one pcgan_absmax pass."""
+    """fp32 device tensor of partial maxima of |x| (the consumer takes the largest): the per-plane maxima its producer attached
+    (`_pcgan_amax`, valid for the tensor version they were attached at) or the single value of one pcgan_absmax pass."""
     ent = x.__dict__.get('_pcgan_amax')
     if ent is not None and ent[0] == x._version:
         AMAX_STATS['attached'] += 1
@@ -296,7 +279,7 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
     ws = _ws(nb, x.device)
     if pack_cache is not None:
         # (one tile shape, no split-K yet: only where whole 128 x 128 tiles fill the chip, i.e. the residual-block convolutions)
-        bsplit = (BF16X6 or dt == BF16) and K % 128 == 0 and N * d.P * d.Q >= 16384 and lib.pcgan_conv2d_bsplit_supported(ctypes.byref(d))
+        bsplit = (BF16X6 or dt == BF16) and K % 128 == 0 and N * d.P * d.Q >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_supported(ctypes.byref(d))
         hsplit = bsplit and HSPLIT and dt == F32 and lib.pcgan_conv2d_hsplit_supported(ctypes.byref(d), _L.PASS_FWD)
         pk = _packed_weights(lib, d, PASS_FWD_HSPLIT if hsplit else (PASS_FWD_BSPLIT if bsplit else _L.PASS_FWD), w, pack_cache)
         xmax = amax_of(x) if hsplit else None
@@ -305,7 +288,7 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         if hsplit:
-            _L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), _p(x), _p(xmax), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
+            _L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), _p(x), _p(xmax), xmax.numel(), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
                      'conv2d_fwd_hsplit')
         elif bsplit:
             _L.check(lib.pcgan_conv2d_fwd_bsplit(ctypes.byref(d), _p(x), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
@@ -337,10 +320,11 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
     nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_BWD_DATA)
     ws = _ws(nb, dy.device)
     if pack_cache is not None:
-        if (BF16X6 or dt == BF16) and bias is None and C % 128 == 0 and N * H * W >= 16384 and lib.pcgan_conv2d_bsplit_dgrad_supported(ctypes.byref(d)):
+        if (BF16X6 or dt == BF16) and bias is None and C % 128 == 0 and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_dgrad_supported(ctypes.byref(d)):
             if HSPLIT and dt == F32 and lib.pcgan_conv2d_hsplit_supported(ctypes.byref(d), _L.PASS_BWD_DATA):
                 pk = _packed_weights(lib, d, PASS_BWD_HSPLIT, w, pack_cache)
-                _L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), _p(dy), _p(amax_of(dy)), _p(pk), _p(dx), _stream()),
+                dmax = amax_of(dy)
+                _L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(dx), _stream()),
                          'conv2d_bwd_data_hsplit')
                 return dx
             pk = _packed_weights(lib, d, PASS_BWD_BSPLIT, w, pack_cache)
@@ -370,7 +354,7 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=N
         dw = accumulate_into
     else:
         dw = torch.empty((K, C, R, S), dtype=torch.float32, device=x.device)
-    if (BF16X6 or dt == BF16) and K in (128, 256) and N * H * W >= 16384 and lib.pcgan_conv2d_bsplit_wgrad_supported(ctypes.byref(d)):
+    if (BF16X6 or dt == BF16) and K in (128, 256) and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_wgrad_supported(ctypes.byref(d)):
         ws = _ws(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
         _L.check(lib.pcgan_conv2d_bwd_weight_bsplit(ctypes.byref(d), _p(x), _p(dy), _p(dw), int(accumulate_into is not None),
                                                     _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight_bsplit')
@@ -569,7 +553,8 @@ def instnorm_fwd(x, residual, eps, act, slope):
     m2 = torch.empty(N * C, dtype=torch.float32, device=x.device)
     lib = _L.load()
     # the largest magnitude of y for the fp16 route of the convolution that reads it (residual blocks: width 32 / 64 planes)
-    slot = _amax_slot(x.device) if HSPLIT and dt == F32 and x.shape[-1] in (32, 64) and lib.pcgan_instnorm_fused(HW) else None
+    slot = (torch.empty(N * C, dtype=torch.float32, device=x.device)
+            if HSPLIT and dt == F32 and x.shape[-1] in (32, 64) and lib.pcgan_instnorm_fused(HW) else None)
     _L.check(lib.pcgan_instnorm_fwd(_p(x), _p(residual), _p(y), _p(mean), _p(m2), _p(slot), N, C, HW, float(eps), act,
                                     float(slope), dt, _stream()), 'instnorm_fwd')
     if slot is not None:
@@ -592,7 +577,7 @@ def instnorm_bwd(dy, x, y, mean, m2, eps, act, slope):
     fused = bool(lib.pcgan_instnorm_fused(HW))
     psum = torch.empty(N * C, dtype=torch.float32, device=x.device) if fused else None
     ws = None if fused else torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
-    slot = _amax_slot(x.device) if fused and HSPLIT and dt == F32 and x.shape[-1] in (32, 64) else None
+    slot = torch.empty(N * C, dtype=torch.float32, device=x.device) if fused and HSPLIT and dt == F32 and x.shape[-1] in (32, 64) else None
     _L.check(lib.pcgan_instnorm_bwd(_p(dy), _p(x), _p(y), _p(mean), _p(m2), _p(dx), _p(psum), _p(slot), _p(ws), N, C, HW, float(eps),
                                     act, float(slope), dt, _stream()), 'instnorm_bwd')
     if psum is not None:

@@ -33,9 +33,9 @@ def timeit(name, fn, flop=GF):
         best = min(best, s.elapsed_time(e) / 50)
     print('%-28s %.4f ms  %.1f TFLOP/s' % (name, best, flop / best))
 timeit('absmax (33.5 MB)', lambda: L.check(lib.pcgan_absmax(x.data_ptr(), x.numel(), 0, amax.data_ptr(), st), 'absmax'), 0.0)
-timeit('fwd fp16x3', lambda: L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), x.data_ptr(), amax.data_ptr(), pkf.data_ptr(), None, y.data_ptr(), 0, 0.0, st), 'f'))
+timeit('fwd fp16x3', lambda: L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), x.data_ptr(), amax.data_ptr(), 1, pkf.data_ptr(), None, y.data_ptr(), 0, 0.0, st), 'f'))
 L.check(lib.pcgan_absmax(dy.data_ptr(), dy.numel(), 0, amax.data_ptr(), st), 'absmax')
-timeit('dgrad fp16x3', lambda: L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), dy.data_ptr(), amax.data_ptr(), pkb.data_ptr(), y.data_ptr(), st), 'b'))
+timeit('dgrad fp16x3', lambda: L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), dy.data_ptr(), amax.data_ptr(), 1, pkb.data_ptr(), y.data_ptr(), st), 'b'))
 for hs, name in ((False, 'bf16x6'), (True, 'fp16x3 via ops (with absmax)')):
     ops.HSPLIT = hs
     cf, cb = {}, {}

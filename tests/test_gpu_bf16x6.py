@@ -174,14 +174,14 @@ def _hsplit(dev, N, C, H, W, K, x, w, dgrad):
     assert float(amax) == float(x.abs().max())
     out = torch.full((N, C if dgrad else K, H, W), float('nan'), device=dev)
     if dgrad:
-        L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), xd.data_ptr(), amax.data_ptr(), pk.data_ptr(), out.data_ptr(), st), 'dgrad')
+        L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), xd.data_ptr(), amax.data_ptr(), 1, pk.data_ptr(), out.data_ptr(), st), 'dgrad')
         ops_hs, ops.HSPLIT = ops.HSPLIT, False
         try:
             o32 = ops.conv2d_bwd_data(xd, wd, (H, W), 1, 1, 1)
         finally:
             ops.HSPLIT = ops_hs
     else:
-        L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), xd.data_ptr(), amax.data_ptr(), pk.data_ptr(), None, out.data_ptr(), 0, 0.0, st), 'fwd')
+        L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), xd.data_ptr(), amax.data_ptr(), 1, pk.data_ptr(), None, out.data_ptr(), 0, 0.0, st), 'fwd')
         o32 = ops.conv2d_fwd(xd, wd, None, 1, 1, 1)
     torch.cuda.synchronize()
     return out.cpu(), o32.cpu()

@@ -89,12 +89,20 @@ def test_fullsize_conv_properties(case, dev):
     assert_close(dw8, w8.grad, 1e-4, name + ' weight gradient (%d images) vs oracle' % lo)
 
 
-def test_fullsize_step_vs_oracle(tmp_path, dev):
+@pytest.mark.parametrize('route', ['as_routed', 'split_kernels'])
+def test_fullsize_step_vs_oracle(tmp_path, dev, route, monkeypatch):
     """One optimize_parameters() with the FULL networks of config 2 (9-block G ngf 64, 3-layer D ndf 64, ResNet-18 E
-    and AlexNet IP at 224) on a batch of 2: losses and fake_B against the oracle's CPU step from the same weights."""
+    and AlexNet IP at 224) on a batch of 2: losses and fake_B against the oracle's CPU step from the same weights.
+    'split_kernels': the residual convolutions on the matrix-pipe split kernels they take at the benchmark's batch size (the host
+    routes them there from 16384 output pixels; a batch of 2 has 2048) -- with the default fp16 route the operand maxima must come
+    from the instance-norm kernels, not from extra passes."""
     import bench
     from oracle import networks_ref as N
     from oracle import step_ref as S
+    from pcgan_amd.hip import ops
+    if route == 'split_kernels':
+        monkeypatch.setattr(ops, 'BSPLIT_MIN_PIXELS', 0)
+    amax0 = dict(ops.AMAX_STATS)
     torch.manual_seed(0)
     model, opt = bench.build_model(0, 2, 128, str(tmp_path), seed=3)
     G = N.ResnetGeneratorRef(3, 3, 1, 64, 'instance', 9)
@@ -114,3 +122,6 @@ def test_fullsize_step_vs_oracle(tmp_path, dev):
         assert abs(got[k] - v) <= 2e-4 * max(1.0, abs(v)), 'loss %s: hip %.7g oracle %.7g' % (k, got[k], v)
     assert_close(model.fake_B, oracle.fake_B.detach(), 2e-4, 'fake_B (full-size generator)')
     assert_close(model.rec_A, oracle.rec_A.detach(), 2e-4, 'rec_A (full-size generator)')
+    if route == 'split_kernels' and ops.HSPLIT:
+        # 18 convolutions x (2 forward passes + their data gradients)
+        assert ops.AMAX_STATS['attached'] - amax0['attached'] >= 60 and ops.AMAX_STATS['computed'] == amax0['computed'], ops.AMAX_STATS

@@ -243,6 +243,19 @@ def test_instance_norm_fused(shape, act, res, dev):
     assert_close(m2, m2_ref, 1e-5, 'fused M2')
     dx = ops.instnorm_bwd(dy.to(dev), xd, y, mean, m2, 1e-5, act, 0.0)
     assert_close(dx, x64.grad, 5e-5, 'fused instnorm bwd')
+    # width-32 / 64 planes (the residual blocks): both kernels also hand out the largest magnitude of every output plane --
+    # exactly the values stored -- for the fp16 route of the convolution that consumes the tensor (ops.amax_of)
+    for t in (y, dx):
+        ent = t.__dict__.get('_pcgan_amax')
+        assert (ent is not None) == (ops.HSPLIT and shape[3] in (32, 64))
+        if ent is not None:
+            assert torch.equal(ent[1], t.abs().amax(dim=(2, 3)).reshape(-1)), 'plane maxima'
+            before = dict(ops.AMAX_STATS)
+            assert ops.amax_of(t) is ent[1] and ops.AMAX_STATS['attached'] == before['attached'] + 1
+            t.add_(1.0)        # an in-place change outdates them: one absmax pass instead
+            assert float(ops.amax_of(t)) == float(t.abs().max()) and ops.AMAX_STATS['computed'] == before['computed'] + 1
+            t.sub_(1.0)
+    dx = ops.instnorm_bwd(dy.to(dev), xd, y, mean, m2, 1e-5, act, 0.0)
     # the register-resident backward also hands out the per-plane sums of dx; channel_sum (the bias gradient of the
     # convolution in front of the norm) finishes from them instead of re-reading dx -- same value as the full pass
     HW = shape[2] * shape[3]
