@@ -296,6 +296,14 @@ int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, const float
                             const float* bias, void* y, int act, float slope, pcgan_stream_t s);
 int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed,
                                  void* dx, pcgan_stream_t s);
+/* weight gradient on the same route (256 output channels, width a multiple of 16): both operands are split on their way to LDS, so
+ * there is no packed copy of dy; ws (pcgan_conv2d_hsplit_wgrad_workspace_bytes) holds the reflection-padded x and the partial sums of
+ * the splits of the pixel reduction, which are combined in a fixed order.  accumulate != 0 adds into dw like pcgan_conv2d_bwd_weight. */
+int pcgan_conv2d_hsplit_wgrad_supported(const pcgan_conv_desc* d);
+size_t pcgan_conv2d_hsplit_wgrad_workspace_bytes(const pcgan_conv_desc* d);
+int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_xamax, const void* dy,
+                                   const float* dy_amax, int n_dyamax, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                                   pcgan_stream_t s);
 
 #ifdef __cplusplus
 }

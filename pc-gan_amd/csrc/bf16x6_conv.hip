@@ -916,6 +916,204 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     }
 }
 
+// ---- fp16 two-piece route, weight gradient of the reflection-padded 3x3 convolution ---------------------------------------------
+// dW[k][(c, r, s)] = sum over (n, y, x) of dy[n][k][y][x] * xpad[n][c][y + r][x + s]: rows = output channels (256), columns = (c, tap),
+// reduction over pixels in stages of 16 consecutive x.  Both operands are split on their way to LDS (no packed copy of dy):
+//   A  dy[n][row][y][x0 + 8 half .. + 8): two 16-byte loads per thread, two 16-byte LDS writes (one per piece);
+//   B  xpad[n][c][y + r][x0 + s + 4 q .. + 4): four 4-byte loads (the tap column shifts the alignment), two 8-byte LDS writes;
+// 12 MFMAs and 8 ds_read_b128 per wave and stage; blockIdx.y takes a range of stages and writes a raw partial sum, combined in
+// a fixed order by bsplit_wgrad_reduce_kernel.
+struct HWgradArgs {
+    const float* XP;       // reflection-padded input [N][C][H + 2][W + 2]
+    const float* DY;       // [N][256][H][W]
+    float* part;           // [splits][256][C * 9]
+    int N, C, H, W, nst, nst_split;
+    unsigned xp_bytes, dy_bytes;
+    const float* x_amax;
+    const float* dy_amax;
+    int x_namax, dy_namax;
+};
+
+__global__ void __launch_bounds__(512) hsplit_wgrad_kernel(HWgradArgs a) {
+    constexpr int BM = 256, NT = 512;
+    __shared__ __attribute__((aligned(16))) bf16x8 As[2][2][2 * BM];     // [buffer][piece][half * 256 + row]
+    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][2][256];        // [buffer][piece][half * 128 + column]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wp = wave & 1;
+    const int C9 = a.C * 9, Hp = a.H + 2, Wp = a.W + 2, HW = a.H * a.W;
+
+    float sx, sdy;
+    {
+        float m = 0.f, g = 0.f;
+        for (int i = tid; i < a.x_namax; i += NT) m = fmaxf(m, a.x_amax[i]);
+        for (int i = tid; i < a.dy_namax; i += NT) g = fmaxf(g, a.dy_amax[i]);
+        float* scratch = reinterpret_cast<float*>(&As[0][0][0]);
+        sx = pow2_scale(block_max(m, scratch));
+        sdy = pow2_scale(block_max(g, scratch));
+        __syncthreads();
+    }
+
+    // A loader: row = tid / 2, half = tid % 2;  B loader: column = tid % 128, pixel quad q = tid / 128
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const unsigned avo = (unsigned)(arow * HW + ahalf * 8) * 4u;
+    const int bcol = tid & 127, bq = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int col = blockIdx.x * 128 + bcol;
+    unsigned bvo = BS_OOB;
+    if (col < C9) {
+        const int c = col / 9, tap = col - c * 9, r = tap / 3, s = tap - r * 3;
+        bvo = (unsigned)((c * Hp + r) * Wp + s) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.DY), 0, (int)a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.XP), 0, (int)a.xp_bytes, 0x00020000);
+
+    const int st0 = (int)blockIdx.y * a.nst_split;
+    const int nst_here = min(a.nst_split, a.nst - st0);
+    // position of the next stage to LOAD (scalar): image, row, first column
+    int ln, ly, lx;
+    {
+        const int e0 = st0 * 16;
+        ln = e0 / HW;
+        const int rem = e0 - ln * HW;
+        ly = rem / a.W;
+        lx = rem - ly * a.W;
+    }
+    struct Stage {
+        u32x4 a0, a1;      // 8 consecutive dy values of this thread's row
+        unsigned b[4];     // 4 consecutive x values of this thread's column
+    };
+    int lcount = 0;
+    auto load = [&](Stage& r) {
+        const bool live = lcount < nst_here;
+        const unsigned aso = (unsigned)(ln * BM * HW + ly * a.W + lx) * 4u;
+        const unsigned bso = (unsigned)(((ln * a.C) * Hp + ly) * Wp + lx + bq * 4) * 4u;
+        const unsigned av = live ? avo : BS_OOB, bv = live ? bvo : BS_OOB;
+        r.a0 = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso, 0);
+        r.a1 = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso + 16, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.b[j] = __builtin_amdgcn_raw_buffer_load_b32(rX, bv, bso + j * 4, 0);
+        ++lcount;
+        lx += 16;
+        if (lx == a.W) {
+            lx = 0;
+            if (++ly == a.H) {
+                ly = 0;
+                ++ln;
+            }
+        }
+    };
+    typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+    auto stash = [&](const Stage& r, int buf) {
+        f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 x, y;
+            split2h(__uint_as_float(j < 4 ? r.a0[j] : r.a1[j - 4]) * sdy, x, y);
+            h[j] = x;
+            l[j] = y;
+        }
+        As[buf][0][ahalf * BM + arow] = __builtin_bit_cast(bf16x8, h);
+        As[buf][1][ahalf * BM + arow] = __builtin_bit_cast(bf16x8, l);
+        hf4 bh, bl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            _Float16 x, y;
+            split2h(__uint_as_float(r.b[j]) * sx, x, y);
+            bh[j] = x;
+            bl[j] = y;
+        }
+        // pixels 4 q .. 4 q + 3 of the stage: k half q / 2, offset (q % 2) * 4 inside the column's 8-wide half
+        *reinterpret_cast<hf4*>(reinterpret_cast<_Float16*>(&Bs[buf][0][(bq >> 1) * 128 + bcol]) + (bq & 1) * 4) = bh;
+        *reinterpret_cast<hf4*>(reinterpret_cast<_Float16*>(&Bs[buf][1][(bq >> 1) * 128 + bcol]) + (bq & 1) * 4) = bl;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    struct Operands {
+        bf16x8 A[2][2], B[2][2];
+    };
+    auto fetch = [&](Operands& o, int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                o.A[p][i] = As[buf][p][hi * BM + wm * 64 + i * 32 + lo];
+                o.B[p][i] = Bs[buf][p][hi * 128 + wp * 64 + i * 32 + lo];
+            }
+    };
+    auto mma = [&](const Operands& o) {      // (l,h) (h,l) (h,h)
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, o.A[PA[q]][i]),
+                                                                        __builtin_bit_cast(f16x8, o.B[PB[q]][j]), acc[i][j], 0, 0, 0);
+    };
+    auto interleave = [&]() {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+            if (q < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // LDS reads of the next stage first
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                   // split arithmetic
+            if (q >= 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // LDS writes
+            if (q >= 4 && q < 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // global loads
+        }
+    };
+
+    // the software pipeline of the convolution kernels above: global loads three stages ahead, LDS one, operands in registers
+    Stage rg[2];
+    Operands op[2];
+    load(rg[0]);
+    load(rg[1]);
+    stash(rg[0], 0);
+    __syncthreads();
+    load(rg[0]);
+    fetch(op[0], 0);
+    stash(rg[1], 1);
+    __syncthreads();
+    load(rg[1]);
+    const int nst2 = (nst_here + 1) & ~1;
+    for (int s = 0; s < nst2; s += 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fetch(op[(t + 1) & 1], (t + 1) & 1);     // operands of stage s+t+1
+            mma(op[t]);                              // stage s+t
+            stash(rg[t], t);                         // stage s+t+2
+            load(rg[t]);                             // stage s+t+4
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // epilogue: acc[i][j][r] = part[split][row wm*64 + i*32 + (r/4)*8 + hi*4 + r%4][column wp*64 + j*32 + lo]
+    const float isx = 1.f / sx, isd = 1.f / sdy;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cg = blockIdx.x * 128 + wp * 64 + j * 32 + lo;
+        if (cg >= C9) continue;
+        float* out = a.part + (size_t)blockIdx.y * BM * C9 + cg;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+                out[(size_t)m * C9] = (acc[i][j][r] * isx) * isd;
+            }
+    }
+}
+
+
 static int bsplit_check(const pcgan_conv_desc* d) {
     PCGAN_CHECK(d, "conv2d_bsplit: null descriptor");
     PCGAN_CHECK(d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16, "conv2d_bsplit: dtype %d", d->dtype);
@@ -1277,6 +1475,63 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void
     h.w_amax = (const float*)((const char*)packed + body);
     const dim3 grid((unsigned)((long)d->N * d->H * d->W / 128 * h.nMt));
     pcgan::launch_halo<pcgan::BH_DGRAD>(d, d->W, grid, (hipStream_t)s, h, true);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+// weight gradient on the fp16 route: reflection pad of x (workspace), the kernel above over splits of the pixel reduction, reduce
+extern "C" int pcgan_conv2d_hsplit_wgrad_supported(const pcgan_conv_desc* d) {
+    return d && d->dtype == PCGAN_F32 && d->stride == 1 && d->pad_mode == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && d->K == 256 &&
+           d->W % 16 == 0 && d->H >= 2 && d->P == d->H && d->Q == d->W && (size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4 < 0x80000000ull &&
+           (size_t)d->N * d->K * d->H * d->W * 4 < 0x80000000ull;
+}
+
+static inline int hsplit_wgrad_splits(const pcgan_conv_desc* d, int* nst_split) {
+    const int nst = d->N * d->H * d->W / 16;
+    const long tiles = (d->C * 9 + 127) / 128;
+    long want = 256 / tiles;          // one round of resident workgroups
+    if (want < 1) want = 1;
+    if (want > nst / 8) want = nst / 8 > 0 ? nst / 8 : 1;
+    *nst_split = (int)((nst + want - 1) / want);
+    return (nst + *nst_split - 1) / *nst_split;
+}
+
+extern "C" size_t pcgan_conv2d_hsplit_wgrad_workspace_bytes(const pcgan_conv_desc* d) {
+    if (!pcgan_conv2d_hsplit_wgrad_supported(d)) return 0;
+    int per;
+    const int splits = hsplit_wgrad_splits(d, &per);
+    return pcgan::align_up((size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4, 256) + (size_t)splits * 256 * d->C * 9 * 4;
+}
+
+extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_xamax, const void* dy,
+                                              const float* dy_amax, int n_dyamax, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                                              pcgan_stream_t s) {
+    PCGAN_CHECK(pcgan_conv2d_hsplit_wgrad_supported(d), "conv2d_bwd_weight_hsplit: unsupported shape");
+    PCGAN_CHECK(x && dy && dw && x_amax && dy_amax && n_xamax > 0 && n_dyamax > 0 && ws &&
+                    ws_bytes >= pcgan_conv2d_hsplit_wgrad_workspace_bytes(d), "conv2d_bwd_weight_hsplit: null pointer or small workspace");
+    hipStream_t st = (hipStream_t)s;
+    int per;
+    const int splits = hsplit_wgrad_splits(d, &per);
+    const size_t xpad_bytes = pcgan::align_up((size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4, 256);
+    float* xpad = (float*)ws;
+    float* part = (float*)((char*)ws + xpad_bytes);
+    PCGAN_CHECK(d->N * d->C <= 65535, "conv2d_bwd_weight_hsplit: more than 65535 planes");
+    const int per_plane = (d->H + 2) * (d->W + 2);
+    hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel<float>, dim3((per_plane + 255) / 256, d->N * d->C), dim3(256), 0, st, (const float*)x, xpad,
+                       d->H, d->W, 1);
+    PCGAN_LAUNCH_CHECK();
+    pcgan::HWgradArgs a;
+    a.XP = xpad; a.DY = (const float*)dy; a.part = part;
+    a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W;
+    a.nst = d->N * d->H * d->W / 16;
+    a.nst_split = per;
+    a.xp_bytes = (unsigned)((size_t)d->N * d->C * per_plane * 4);
+    a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->H * d->W * 4);
+    a.x_amax = x_amax; a.x_namax = n_xamax; a.dy_amax = dy_amax; a.dy_namax = n_dyamax;
+    hipLaunchKernelGGL(pcgan::hsplit_wgrad_kernel, dim3((unsigned)((d->C * 9 + 127) / 128), (unsigned)splits), dim3(512), 0, st, a);
+    PCGAN_LAUNCH_CHECK();
+    const size_t total = (size_t)d->K * d->C * 9;
+    hipLaunchKernelGGL(pcgan::bsplit_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, dw, splits, total, accumulate);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

@@ -217,6 +217,7 @@ def amax_of(x):
     ent = x.__dict__.get('_pcgan_amax')
     if ent is not None and ent[0] == x._version:
         AMAX_STATS['attached'] += 1
+        ent[1].record_stream(torch.cuda.current_stream())     # (may be the parameter-gradient side stream or a branch stream)
         return ent[1]
     AMAX_STATS['computed'] += 1
     out = torch.empty(1, dtype=torch.float32, device=x.device)
@@ -354,6 +355,12 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=N
         dw = accumulate_into
     else:
         dw = torch.empty((K, C, R, S), dtype=torch.float32, device=x.device)
+    if (HSPLIT and BF16X6 and dt == F32 and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_hsplit_wgrad_supported(ctypes.byref(d))):
+        ws = _ws(lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
+        xmax, dmax = amax_of(x), amax_of(dy)
+        _L.check(lib.pcgan_conv2d_bwd_weight_hsplit(ctypes.byref(d), _p(x), _p(xmax), xmax.numel(), _p(dy), _p(dmax), dmax.numel(), _p(dw),
+                                                    int(accumulate_into is not None), _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight_hsplit')
+        return dw
     if (BF16X6 or dt == BF16) and K in (128, 256) and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_wgrad_supported(ctypes.byref(d)):
         ws = _ws(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
         _L.check(lib.pcgan_conv2d_bwd_weight_bsplit(ctypes.byref(d), _p(x), _p(dy), _p(dw), int(accumulate_into is not None),

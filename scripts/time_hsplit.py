@@ -41,3 +41,10 @@ for hs, name in ((False, 'bf16x6'), (True, 'fp16x3 via ops (with absmax)')):
     cf, cb = {}, {}
     timeit('fwd ' + name, lambda: ops.conv2d_fwd(x, w, None, 1, 1, 1, pack_cache=cf))
     timeit('dgrad ' + name, lambda: ops.conv2d_bwd_data(dy, w, (HH, HH), 1, 1, 1, pack_cache=cb))
+wsw = torch.empty(lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+dw = torch.empty(256, 256, 3, 3, device=dev)
+xm = x.abs().amax(dim=(2, 3)).reshape(-1).contiguous()
+dm = dy.abs().amax(dim=(2, 3)).reshape(-1).contiguous()
+timeit('wgrad fp16x3 (pad+main+reduce)', lambda: L.check(lib.pcgan_conv2d_bwd_weight_hsplit(ctypes.byref(d), x.data_ptr(), xm.data_ptr(), xm.numel(), dy.data_ptr(), dm.data_ptr(), dm.numel(), dw.data_ptr(), 0, wsw.data_ptr(), wsw.numel(), st), 'w'))
+ops.HSPLIT = False
+timeit('wgrad bf16x6 (pad+pack+main+reduce)', lambda: ops.conv2d_bwd_weight(x, dy, (256, 256, 3, 3), 1, 1, 1))

@@ -243,3 +243,47 @@ def test_absmax_unaligned_and_ragged(dev):
         v = base[off:off + n]
         L.check(lib.pcgan_absmax(v.data_ptr(), n, 0, out.data_ptr(), st), 'absmax')
         assert float(out) == float(v.abs().max()), (off, n)
+
+
+@pytest.mark.parametrize('N,C,H,W,acc', [
+    (2, 256, 32, 32, False),     # the residual-block convolution
+    (3, 40, 6, 16, True),        # ragged column tile (360 columns), accumulate into an existing gradient
+    (1, 16, 4, 16, False),       # smallest grid
+    (2, 64, 8, 64, True),        # width 64
+])
+@pytest.mark.parametrize('data', ['normal', 'wide_range'])
+def test_hsplit_weight_gradient(dev, N, C, H, W, acc, data):
+    """dW of ReflectionPad2d(1) + Conv2d(3x3, 256 output channels) on the fp16 route against autograd in float64 and the fp32 kernel"""
+    from pcgan_amd.hip import lib as L, ops
+    K = 256
+    g = torch.Generator().manual_seed(N * 100 + C + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    dy = torch.randn(N, K, H, W, generator=g)
+    if data == 'wide_range':
+        x = x * torch.pow(10.0, torch.rand(N, C, H, W, generator=g) * 8 - 6)
+        dy = dy * torch.pow(10.0, torch.rand(N, K, H, W, generator=g) * 12 - 14)
+    w = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    R.conv2d(x.double(), w, None, 1, 1, 1).backward(dy.double())
+    ref = w.grad
+    d = ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 1)
+    lib = L.load()
+    assert lib.pcgan_conv2d_hsplit_wgrad_supported(ctypes.byref(d))
+    xd, dyd = x.to(dev), dy.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    base = torch.randn(K, C, 3, 3, generator=g) * float(ref.abs().max()) if acc else None
+    dw = base.to(dev).clone() if acc else torch.full((K, C, 3, 3), float('nan'), device=dev)
+    # operand maxima as partial values (per plane), as the instance-norm kernels hand them over
+    xmax = xd.abs().amax(dim=(2, 3)).reshape(-1).contiguous()
+    dmax = dyd.abs().amax(dim=(2, 3)).reshape(-1).contiguous()
+    L.check(lib.pcgan_conv2d_bwd_weight_hsplit(ctypes.byref(d), xd.data_ptr(), xmax.data_ptr(), xmax.numel(), dyd.data_ptr(), dmax.data_ptr(),
+                                               dmax.numel(), dw.data_ptr(), int(acc), ws.data_ptr(), ws.numel(), st), 'wgrad')
+    old, ops.HSPLIT = ops.HSPLIT, False
+    try:
+        dw32 = ops.conv2d_bwd_weight(xd, dyd, (K, C, 3, 3), 1, 1, 1)
+    finally:
+        ops.HSPLIT = old
+    torch.cuda.synchronize()
+    got = dw.double().cpu() - (base.double() if acc else 0.0)
+    e = lambda t: float((t - ref).norm() / ref.norm())
+    assert e(got) < (3e-6 if not acc else 1e-5) and (acc or e(got) < 4 * e(dw32.double().cpu()) + 5e-7), (e(got), e(dw32.double().cpu()))
