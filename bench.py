@@ -32,17 +32,21 @@ GFLOP_PER_IMG_FULL = 183.95      # 2 G + 4 D + 3 E + 2 IP fwd an
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 BF16_SPLIT_PRODUCTS = 6          # bf16 piece products that stand for one fp32 product (csrc/bf16x6_conv.hip)
+F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16 MFMA (v_mfma_f32_32x32x16_f16): same rate as bf16
+F16_SPLIT_PRODUCTS = 3           # fp16 piece products that stand for one fp32 product (the default route, "fp16 route" in bf16x6_conv.hip)
 PER_GPU_BATCH = 32
 SIZE = 128
 TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_dominant_kernel_traffic.json')   # written from the --pmc passes of this round
 
 
-def measured_traffic():
+def measured_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from this round's separate rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE cannot share a pass), committed under profiles/; None when the file is absent."""
+    WRITE_SIZE cannot share a pass), committed under profiles/; None when the file is absent or describes another kernel."""
     try:
         with open(TRAFFIC_FILE) as f:
             t = json.load(f)
+        if t.get('kernel') != kernel:
+            return None
         return {'bytes_per_launch': int(t['fetch_bytes'] + t['write_bytes']), 'fetch_bytes': int(t['fetch_bytes']),
                 'write_bytes': int(t['write_bytes']), 'algorithmic_bytes': int(t['algorithmic_bytes']), 'source': t['source']}
     except (OSError, KeyError, ValueError):
@@ -184,11 +188,18 @@ def main():
     assert conv_launches > 0, 'the residual convolution was not launched inside the timed region'
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12
     split = ops.BF16X6
+    hsplit = split and ops.HSPLIT
     bf16 = args.dtype == 'bf16'
     if bf16:
         # bf16 storage, one bf16 product per term: 16x the fp32 MFMA rate makes the kernel HBM / gather bound -> HBM roofline
         kname = ('bsplit_conv_fwd_kernel<BS_FWD_REFLECT,256,1,bf16> (bf16 activations and weights, v_mfma_f32_32x32x16_bf16, fp32 accumulate) '
                  '256->256 3x3 reflect @32x32, bs32')
+    elif hsplit:
+        # the dominant kernel runs the fp32 contraction as 3 fp16 piece products per term (two scaled fp16 pieces per operand) on
+        # the f16 matrix pipe: its MFMA roofline in ALGORITHMIC (fp32) FLOP is the dense f16 peak / 3
+        peak = F16_MFMA_PEAK_TFLOPS / F16_SPLIT_PRODUCTS
+        kname = ('bsplit_halo_kernel<BH_FWD,PK_F16X2,float,32> (two scaled fp16 pieces per operand, 3 x v_mfma_f32_32x32x16_f16 per K=16 '
+                 'step, 256 x 128 tile, input window split once per 16-channel chunk) 256->256 3x3 reflect @32x32, bs32')
     elif split:
         # the dominant kernel runs the fp32 contraction as 6 bf16 piece products per term on the bf16 matrix pipe: its MFMA
         # roofline in ALGORITHMIC (fp32) FLOP is the dense bf16 peak / 6
@@ -198,7 +209,7 @@ def main():
     else:
         peak = FP32_MFMA_PEAK_TFLOPS
         kname = 'igemm2_kernel<1,128,128,16> (FWD_REFLECT, 128x128 tile, 16-channel K stages) 256->256 3x3 reflect @32x32, bs32'
-    traffic = measured_traffic() if (split and not bf16) else None
+    traffic = measured_traffic('bsplit_halo_kernel<0, 2, float, 32>' if hsplit else 'bsplit_halo_kernel<0, 0, float, 32>') if (split and not bf16) else None
     if bf16:
         alg_bytes = 2 * PER_GPU_BATCH * 256 * 32 * 32 * 2 + 256 * 256 * 9 * 2     # x + y as bf16, bf16 weights
         roof = {'bound': 'hbm', 'kernel': kname, 'achieved': round(alg_bytes / (conv_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
@@ -219,7 +230,8 @@ def main():
                      'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                      'frac': round(achieved / peak, 4), 'ms_per_launch': round(conv_ms, 4),
                      'launches_timed': conv_launches, 'flop_per_launch': conv_flop,
-                     'peak_basis': ('dense bf16 MFMA %.0f TFLOP/s / %d piece products per fp32 product' % (BF16_MFMA_PEAK_TFLOPS, BF16_SPLIT_PRODUCTS))
+                     'peak_basis': ('dense f16 MFMA %.0f TFLOP/s / %d piece products per fp32 product' % (F16_MFMA_PEAK_TFLOPS, F16_SPLIT_PRODUCTS))
+                     if hsplit else ('dense bf16 MFMA %.0f TFLOP/s / %d piece products per fp32 product' % (BF16_MFMA_PEAK_TFLOPS, BF16_SPLIT_PRODUCTS))
                      if split else 'fp32 MFMA v_mfma_f32_32x32x2_f32',
                      'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                      # memory-side bytes per launch from this round's separate rocprofv3 --pmc passes (profiles/README.md);
@@ -228,10 +240,10 @@ def main():
         'losses': {k: round(v, 5) for k, v in losses.items()},
     }
     if world == 1 and not args.no_experiment and ops.BF16X6 and not bf16:
-        # NOT the headline: the same K steps once more with the 108 residual-convolution launches routed back to the fp32 MFMA
-        # implicit GEMM (PCGAN_BF16X6=0), i.e. round 1's default path -- the A/B behind the default
-        ops.BF16X6 = False
-        try:
+        # NOT the headline: the same K steps once more with the 108 residual-convolution launches on the two other routes -- the
+        # exact three-piece bf16 split (PCGAN_SPLIT=bf16, the default before the fp16 route) and the fp32 MFMA implicit GEMM
+        # (PCGAN_BF16X6=0, round 1's default) -- the A/B behind the default
+        def rerun(what, switch):
             for i in range(args.warmup):
                 step(i)
             torch.cuda.synchronize()
@@ -241,13 +253,18 @@ def main():
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
             l2 = model.get_current_losses()
-            assert all(v == v and abs(v) < 1e6 for v in l2.values()), 'non-finite loss on the fp32 MFMA route: %r' % l2
-            out['route_fp32_mfma'] = {
-                'value': round(PER_GPU_BATCH * args.steps / dt2, 3), 'unit': 'images/sec', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
-                'default': False, 'switch': 'PCGAN_BF16X6=0',
-                'what': 'the residual convolutions on v_mfma_f32_32x32x2_f32 (round-1 default) instead of the exact bf16 split'}
+            assert all(v == v and abs(v) < 1e6 for v in l2.values()), 'non-finite loss (%s): %r' % (switch, l2)
+            return {'value': round(PER_GPU_BATCH * args.steps / dt2, 3), 'unit': 'images/sec', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
+                    'default': False, 'switch': switch, 'what': what}
+        saved = (ops.BF16X6, ops.HSPLIT)
+        try:
+            if ops.HSPLIT:
+                ops.HSPLIT = False
+                out['route_bf16x6'] = rerun('the residual convolutions on the exact three-piece bf16 split, 6 products', 'PCGAN_SPLIT=bf16')
+            ops.BF16X6 = False
+            out['route_fp32_mfma'] = rerun('the residual convolutions on v_mfma_f32_32x32x2_f32 (round-1 default)', 'PCGAN_BF16X6=0')
         finally:
-            ops.BF16X6 = True
+            ops.BF16X6, ops.HSPLIT = saved
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

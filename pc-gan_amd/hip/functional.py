@@ -44,12 +44,15 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.cfg = (stride, pad, pad_mode, act, slope)
         ctx.has_bias = b is not None
         ctx.params = (w, b)          # the Parameter objects (for their fused gradient buffers)
+        ctx.x_amax = x.__dict__.get('_pcgan_amax')     # operand maxima its producer left (fp16 route): a saved tensor comes back without them
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
+        if ctx.x_amax is not None and ctx.x_amax[0] == x._version and '_pcgan_amax' not in x.__dict__:
+            x._pcgan_amax = ctx.x_amax
         stride, pad, pad_mode, act, slope = ctx.cfg
         dy = _c(dy)
         if act != ACT_NONE:

@@ -17,8 +17,18 @@ def _p(t):
     return _vp(t.data_ptr()) if t is not None else _vp(0)
 
 
+_DEVICE_INDEX = []
+
+
+def _raw_stream():
+    """the current HIP stream handle as an integer (torch.cuda.current_stream() builds a Stream object: ~9 us, 650 calls per step)"""
+    if not _DEVICE_INDEX:
+        _DEVICE_INDEX.append(torch.cuda.current_device())     # one process drives one GPU
+    return torch._C._cuda_getCurrentRawStream(_DEVICE_INDEX[0])
+
+
 def _stream():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    return _vp(_raw_stream())
 
 
 def _chk(*tensors):
@@ -208,7 +218,7 @@ AMAX_STATS = {'attached': 0, 'computed': 0}     # operand maxima handed over by 
 
 
 def _attach_amax(t, pmax):
-    t._pcgan_amax = (t._version, pmax)
+    t._pcgan_amax = (t._version, pmax, _raw_stream())
 
 
 def amax_of(x):
@@ -217,7 +227,8 @@ def amax_of(x):
     ent = x.__dict__.get('_pcgan_amax')
     if ent is not None and ent[0] == x._version:
         AMAX_STATS['attached'] += 1
-        ent[1].record_stream(torch.cuda.current_stream())     # (may be the parameter-gradient side stream or a branch stream)
+        if ent[2] != _raw_stream():      # consumed on another stream than it was produced on (parameter-gradient side stream)
+            ent[1].record_stream(torch.cuda.current_stream())
         return ent[1]
     AMAX_STATS['computed'] += 1
     out = torch.empty(1, dtype=torch.float32, device=x.device)
@@ -228,12 +239,12 @@ def amax_of(x):
 def _packed_weights(lib, d, pass_, w, cache):
     key = (pass_, d.stride, d.pad, d.pad_mode, d.dtype)
     stamp = (_PACK_EPOCH[0], w._version, w.data_ptr(), tuple(w.shape))
-    cur = torch.cuda.current_stream()
     ent = cache.get(key)
     if ent is not None and ent[0] == stamp:
-        if ent[3] != cur.cuda_stream:      # packed on another stream (branch streams): order this use after the pack
-            cur.wait_event(ent[2])
+        if ent[3] != _raw_stream():      # packed on another stream (branch streams): order this use after the pack
+            torch.cuda.current_stream().wait_event(ent[2])
         return ent[1]
+    cur = torch.cuda.current_stream()
     if pass_ in (PASS_FWD_HSPLIT, PASS_BWD_HSPLIT):
         nb = int(lib.pcgan_conv2d_hsplit_packed_bytes(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HSPLIT else _L.PASS_BWD_DATA))
     elif pass_ == PASS_FWD_BSPLIT:
@@ -384,7 +395,8 @@ def channel_sum(x, accumulate_into=None):
     if psum is not None and psum.numel() == N * C and psum.device == x.device:
         # x is the dx an instance-norm backward just produced: its plane sums exist already (instnorm_bwd)
         PLANE_SUM_STATS['fused'] += 1
-        psum.record_stream(torch.cuda.current_stream())     # (may be the parameter-gradient side stream)
+        if getattr(x, '_pcgan_plane_sums_stream', None) != _raw_stream():     # (the parameter-gradient side stream)
+            psum.record_stream(torch.cuda.current_stream())
         _L.check(_L.load().pcgan_sum_planes(_p(psum), _p(out), N, C, int(accumulate_into is not None), _stream()), 'sum_planes')
         return out
     PLANE_SUM_STATS['full'] += 1
@@ -589,6 +601,7 @@ def instnorm_bwd(dy, x, y, mean, m2, eps, act, slope):
                                     act, float(slope), dt, _stream()), 'instnorm_bwd')
     if psum is not None:
         dx._pcgan_plane_sums = psum
+        dx._pcgan_plane_sums_stream = _raw_stream()
     if slot is not None:
         _attach_amax(dx, slot)
     return dx
