@@ -135,8 +135,11 @@ int pcgan_in_running_update(const float* mean_nc, const float* m2_nc, float* run
  * pcgan_plane_stats and the kernel divides by HW) or i = c (per_plane=0, batch norm or
  * eval-mode running statistics: `var` is the variance).  gamma/beta/residual may be NULL. */
 int pcgan_norm_act_fwd(const void* x, const float* mean, const float* var, const float* gamma,
-                       const float* beta, const void* residual, void* y, int N, int C, int HW,
+                       const float* beta, const void* residual, void* y, float* y_pmax, int N, int C, int HW,
                        int per_plane, float eps, int act, float slope, int dtype, pcgan_stream_t s);
+/* y_pmax / dx_pmax ([N*C], may be NULL) here and y_cmax / dx_cmax ([C], may be NULL) of the fused BatchNorm calls below receive
+ * the largest magnitude of each output plane / channel: partial maxima for the fp16 route of the convolution that consumes the
+ * tensor (pcgan_conv2d_fwd_packed_hsplit: x_amax, n_amax) -- no separate pcgan_absmax pass. */
 /* backward statistics per plane: s1[nc] = sum g, s2[nc] = sum g*xhat where
  * g = dy * act'(y) (y = forward output, used only for the activation mask; may be NULL
  * when act == NONE). */
@@ -148,7 +151,7 @@ int pcgan_norm_bwd_stats(const void* dy, const void* x, const void* y, const flo
  * (pcgan_bn_bwd_reduce) which also yields dgamma, dbeta. */
 int pcgan_norm_bwd_apply(const void* dy, const void* x, const void* y, const float* mean,
                          const float* var, const float* gamma, const float* s1, const float* s2,
-                         void* dx, void* d_residual, int N, int C, int HW, int per_plane, float eps,
+                         void* dx, void* d_residual, float* dx_pmax, int N, int C, int HW, int per_plane, float eps,
                          int act, float slope, int dtype, pcgan_stream_t s);
 int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, float* s2_c, int N, int C,
                         pcgan_stream_t s);
@@ -158,11 +161,11 @@ int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, flo
  * (models/networks.py:24-26, 756-771; models/resnet.py:58-71).  mean_c / var_c (biased) are kept for the backward pass;
  * backward returns s1_c = d(beta), s2_c = d(gamma) and dx (dx / dres may be NULL). */
 int pcgan_bn_fwd_fused(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
-                       float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches, int N,
-                       int C, int HW, float momentum, float eps, int act, float slope, int dtype, pcgan_stream_t s);
+                       float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches, float* y_cmax,
+                       int N, int C, int HW, float momentum, float eps, int act, float slope, int dtype, pcgan_stream_t s);
 int pcgan_bn_bwd_fused(const void* dy, const void* x, const void* y, const float* mean_c, const float* var_c,
-                       const float* gamma, void* dx, void* dres, float* s1_c, float* s2_c, int N, int C, int HW, float eps,
-                       int act, float slope, int dtype, pcgan_stream_t s);
+                       const float* gamma, void* dx, void* dres, float* s1_c, float* s2_c, float* dx_cmax, int N, int C, int HW,
+                       float eps, int act, float slope, int dtype, pcgan_stream_t s);
 
 /* Fused instance norm (the generator's 23 norm sites per pass, models/networks.py:580-601,633,646): the
  * (n,c) plane stays in registers, so forward = one read + one write (statistics + normalise + residual +
@@ -288,7 +291,10 @@ int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const void* x, cons
  * pass = PCGAN_PASS_FWD | PCGAN_PASS_BWD_DATA; image width 32 or 64, 128 / width rows dividing the height, gathered channels a
  * multiple of 32, produced channels a multiple of 256.  packed: pcgan_conv2d_hsplit_packed_bytes(d, pass) bytes, valid for any
  * batch size; the pack call also stores the weights' largest magnitude in it. */
-int pcgan_absmax(const void* x, size_t n, int dtype, float* out, pcgan_stream_t s);
+/* out[0 .. slots) = partial maxima of |x| (one per workgroup, 1 <= slots <= 1024; no atomics, nothing to clear beforehand);
+ * pcgan_absmax_slots(n) = the count that keeps the pass bandwidth-bound.  Weight tensors use exactly 64 slots. */
+int pcgan_absmax_slots(size_t n);
+int pcgan_absmax(const void* x, size_t n, int dtype, float* out, int slots, pcgan_stream_t s);
 int pcgan_conv2d_hsplit_supported(const pcgan_conv_desc* d, int pass);
 size_t pcgan_conv2d_hsplit_packed_bytes(const pcgan_conv_desc* d, int pass);
 int pcgan_conv2d_hsplit_pack(const pcgan_conv_desc* d, int pass, const float* w, void* packed, pcgan_stream_t s);
@@ -296,6 +302,18 @@ int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, const float
                             const float* bias, void* y, int act, float slope, pcgan_stream_t s);
 int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed,
                                  void* dx, pcgan_stream_t s);
+/* Every other convolution whose gathered channel count is a multiple of 16 (<= 25 taps, more than 32 produced channels; any
+ * stride; forward with zero / reflection padding, data gradient with zero padding -- incl. nn.ConvTranspose2d forward,
+ * models/networks.py:584-602, 734-763; models/resnet.py): the fp16 two-piece form of pcgan_conv2d_fwd_packed /
+ * pcgan_conv2d_bwd_data_packed.  Same packed weights (pcgan_conv2d_pack_weights), workspace and semantics; w_amax[0 .. 64) =
+ * partial maxima of |weight| (pcgan_absmax over w with 64 slots). */
+int pcgan_conv2d_hgemm_supported(const pcgan_conv_desc* d, int pass);
+int pcgan_conv2d_fwd_packed_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_amax, const float* packed,
+                                   const float* w_amax, const float* bias, void* y, int act, float slope, void* ws, size_t ws_bytes,
+                                   pcgan_stream_t s);
+int pcgan_conv2d_bwd_data_packed_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax,
+                                        const float* packed, const float* w_amax, const float* bias, void* dx, void* ws,
+                                        size_t ws_bytes, pcgan_stream_t s);
 /* weight gradient on the same route (256 output channels, width a multiple of 16): both operands are split on their way to LDS, so
  * there is no packed copy of dy; ws (pcgan_conv2d_hsplit_wgrad_workspace_bytes) holds the reflection-padded x and the partial sums of
  * the splits of the pixel reduction, which are combined in a fixed order.  accumulate != 0 adds into dw like pcgan_conv2d_bwd_weight. */

@@ -42,25 +42,6 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r1 - (float)m);
 }
 
-// Two fp16 pieces, x * 2^e = h + l (11 + 11 significand bits), products (l,h) (h,l) (h,h): HALF the matrix instructions of the
-// three-piece bf16 split.  scripts/micro/bf16_split, K = 2304 against float64: relative L2 error 5.3e-7 (fp32 MFMA 6.1e-7, bf16 x 6
-// 7.0e-7).  fp16 has 5 exponent bits, so each operand tensor is scaled by a power of two that puts its largest magnitude in
-// (2^13, 2^14] (the largest magnitude is computed on the device: pcgan_absmax, or handed over by the producing kernel); the
-// accumulators are scaled back (exactly) in the epilogue.  An element below 2^-17 of the tensor's largest loses its low piece
-// (error <= 2^-39 of the largest magnitude per element).
-__device__ __forceinline__ float pow2_scale(float amax) {
-    if (!(amax > 0.f)) return 1.f;
-    int e;
-    frexpf(amax, &e);                     // amax = m * 2^e, m in [0.5, 1)
-    e = 14 - e;
-    e = e < -100 ? -100 : (e > 100 ? 100 : e);
-    return ldexpf(1.f, e);
-}
-__device__ __forceinline__ void split2h(float x, _Float16& h, _Float16& l) {
-    h = (_Float16)x;
-    l = (_Float16)(x - (float)h);
-}
-
 struct BsplitArgs {
     const void* X;       // [N][C][H][W], storage type TA
     const void* A;       // packed weights, see above
@@ -85,6 +66,7 @@ enum { BS_FWD_ZERO = 0, BS_FWD_REFLECT = 1, BS_DGRAD_REFLECT = 2, BS_WGRAD = 3 }
 // np = 2: two fp16 pieces of w * pow2_scale(*amax) (the fp16 route)
 __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int M, int C, int T, int nMt, int nst,
                                    int bm_shift, int np, const float* __restrict__ amax = nullptr) {
+    const float wscale = np == 2 ? pow2_scale(max_of_partials(amax, WEIGHT_AMAX_SLOTS)) : 1.f;
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nMt * nst * 16 * BM;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_piece; i += (size_t)gridDim.x * blockDim.x) {
@@ -95,7 +77,7 @@ __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restri
         const float v = m < M ? w[((size_t)m * C + c) * T + tap] : 0.f;
         if (np == 2) {
             _Float16 h, l;
-            split2h(v * pow2_scale(*amax), h, l);
+            split2h(v * wscale, h, l);
             reinterpret_cast<_Float16*>(A)[i] = h;
             reinterpret_cast<_Float16*>(A)[per_piece + i] = l;
             continue;
@@ -110,16 +92,22 @@ __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restri
     }
 }
 
-// largest magnitude of a tensor, as the bit pattern of a non-negative float (ordered like an unsigned integer); *out zeroed before
+// partial maxima of |x|: out[blockIdx.x] = the largest magnitude this workgroup saw (consumers take the largest of the partials)
 template <typename TA>
-__global__ void __launch_bounds__(256) absmax_kernel(const TA* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+__global__ void __launch_bounds__(256) absmax_kernel(const TA* __restrict__ x, size_t n, float* __restrict__ out) {
     float m = 0.f;
     // scalar head up to a 16-byte boundary (a weight tensor may be a view into the optimizer's flat buffer), vector body, scalar tail
     size_t head = ((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) / sizeof(TA);
     head = head < n ? head : n;
     const TA* xb = x + head;
-    const size_t nb = n - head, n4 = nb / 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t nb = n - head, n4 = nb / 4, stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {       // four independent 16-byte loads in flight per thread
+        const float4 a = ld4(xb + 4 * i), b = ld4(xb + 4 * (i + stride)), c = ld4(xb + 4 * (i + 2 * stride)), d = ld4(xb + 4 * (i + 3 * stride));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+    }
+    for (; i < n4; i += stride) {
         const float4 v = ld4(xb + 4 * i);
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
@@ -127,15 +115,9 @@ __global__ void __launch_bounds__(256) absmax_kernel(const TA* __restrict__ x, s
         if (threadIdx.x < head) m = fmaxf(m, fabsf(ld1(x + threadIdx.x)));
         if (threadIdx.x < (nb & 3)) m = fmaxf(m, fabsf(ld1(xb + 4 * n4 + threadIdx.x)));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    __shared__ float red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-        if (v > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, v);      // only a workgroup that would raise the value
-    }
+    __shared__ float red[16];
+    m = block_max(m, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = m;
 }
 
 // ---- weight gradient as the same GEMM with the roles turned: rows = output channels k (operand A = dy, re-split per call), columns
@@ -199,6 +181,7 @@ __global__ void bsplit_wgrad_reduce_kernel(const float* __restrict__ part, float
 // row class 2 (row H-2): wf'[2] = wf[2] + wf[0].
 __global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int K, int C, int nMt, int nst, int bm_shift,
                                          int np, const float* __restrict__ amax = nullptr) {
+    const float wscale = np == 2 ? pow2_scale(max_of_partials(amax, WEIGHT_AMAX_SLOTS)) : 1.f;
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nMt * nst * 16 * BM, per_phase = (size_t)np * per_piece;
     // (3 row classes x per_piece entries; each entry writes its np pieces)
@@ -219,7 +202,7 @@ __global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __
         __bf16* out = A + (size_t)phase * per_phase;
         if (np == 2) {     // (a folded row-class weight is at most twice the largest weight: still far inside the fp16 range)
             _Float16 h, l;
-            split2h(v * pow2_scale(*amax), h, l);
+            split2h(v * wscale, h, l);
             reinterpret_cast<_Float16*>(out)[e] = h;
             reinterpret_cast<_Float16*>(out)[per_piece + e] = l;
             continue;
@@ -658,11 +641,12 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     // write 4 consecutive channels of one window entry (8 bytes per piece)
     typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
     typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
-    float sx = 1.f;
+    float sx = 1.f, sw = 1.f;
     if constexpr (PK == PK_F16X2) {      // largest of the partial maxima the producer left (one per plane, or a single value)
         float m = 0.f;
         for (int i = tid; i < a.x_namax; i += NT) m = fmaxf(m, a.x_amax[i]);
         sx = pow2_scale(block_max(m, reinterpret_cast<float*>(&As[0][0][0])));
+        sw = pow2_scale(block_max(tid < WEIGHT_AMAX_SLOTS ? a.w_amax[tid] : 0.f, reinterpret_cast<float*>(&As[0][0][0])));
         __syncthreads();
     }
     auto put_split = [&](unsigned lds, int buf, const float (&v)[4]) {
@@ -898,7 +882,7 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     }
 
     // epilogue: acc[i][j][r] = Y[m0 + wm*64 + i*32 + (r/4)*8 + hi*4 + r%4][pixel wp*64 + j*32 + lo]; a tile is RT full rows of image n
-    const float isx = 1.f / sx, isw = PK == PK_F16X2 ? 1.f / pow2_scale(*a.w_amax) : 1.f;    // powers of two: exact
+    const float isx = 1.f / sx, isw = 1.f / sw;    // powers of two: exact
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const size_t yo = (size_t)n * a.M * HW + (size_t)y0 * QW + wp * 64 + j * 32 + lo;
@@ -1387,7 +1371,7 @@ extern "C" int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const vo
 
 // ---- fp16 two-piece route of the reflection-padded 3x3 convolution (forward + data gradient), fp32 tensors -------------------------
 // packed buffer: [2 pieces][M tile][stage][k half][256 rows][8 fp16] (data gradient: three row classes of it, the window kernel reads
-// the first) followed by 256 bytes whose first float is the weights' largest magnitude
+// the first) followed by 256 bytes: 64 partial maxima of |w|
 static size_t hsplit_body_bytes(const pcgan_conv_desc* d, int pass) {
     const int rows = pass == PCGAN_PASS_FWD ? d->K : d->C, chan = pass == PCGAN_PASS_FWD ? d->C : d->K;
     const size_t nMt = (rows + 255) / 256, nst = (size_t)(chan / 16) * 9;
@@ -1406,15 +1390,18 @@ extern "C" size_t pcgan_conv2d_hsplit_packed_bytes(const pcgan_conv_desc* d, int
     return pcgan_conv2d_hsplit_supported(d, pass) ? hsplit_body_bytes(d, pass) + 256 : 0;
 }
 
-extern "C" int pcgan_absmax(const void* x, size_t n, int dtype, float* out, pcgan_stream_t s) {
-    PCGAN_CHECK(x && out && n > 0, "absmax: null pointer or empty tensor");
+extern "C" int pcgan_absmax_slots(size_t n) {
+    const size_t want = (n / 4 + 1023) / 1024;       // ~4 vector loads per thread
+    return (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+}
+
+extern "C" int pcgan_absmax(const void* x, size_t n, int dtype, float* out, int slots, pcgan_stream_t s) {
+    PCGAN_CHECK(x && out && n > 0 && slots > 0 && slots <= 1024, "absmax: null pointer, empty tensor or bad slot count");
     PCGAN_CHECK(dtype == PCGAN_F32 || dtype == PCGAN_BF16, "absmax: dtype %d", dtype);
     hipStream_t st = (hipStream_t)s;
-    PCGAN_CHECK(hipMemsetAsync(out, 0, sizeof(float), st) == hipSuccess, "absmax: memset failed");
-    const size_t want = (n / 4 + 255) / 256;
-    const dim3 grid((unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want)));
-    if (dtype == PCGAN_BF16) hipLaunchKernelGGL(pcgan::absmax_kernel<pcgan::bf16>, grid, dim3(256), 0, st, (const pcgan::bf16*)x, n, (unsigned*)out);
-    else hipLaunchKernelGGL(pcgan::absmax_kernel<float>, grid, dim3(256), 0, st, (const float*)x, n, (unsigned*)out);
+    const dim3 grid((unsigned)slots);
+    if (dtype == PCGAN_BF16) hipLaunchKernelGGL(pcgan::absmax_kernel<pcgan::bf16>, grid, dim3(256), 0, st, (const pcgan::bf16*)x, n, out);
+    else hipLaunchKernelGGL(pcgan::absmax_kernel<float>, grid, dim3(256), 0, st, (const float*)x, n, out);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -1424,8 +1411,9 @@ extern "C" int pcgan_conv2d_hsplit_pack(const pcgan_conv_desc* d, int pass, cons
     PCGAN_CHECK(w && packed, "conv2d_hsplit_pack: null pointer");
     hipStream_t st = (hipStream_t)s;
     const size_t body = hsplit_body_bytes(d, pass);
-    float* amax = (float*)((char*)packed + body);
-    if (pcgan_absmax(w, (size_t)d->K * d->C * 9, PCGAN_F32, amax, s)) return 1;
+    float* amax = (float*)((char*)packed + body);     // the 256-byte tail: WEIGHT_AMAX_SLOTS partial maxima
+    hipLaunchKernelGGL(pcgan::absmax_kernel<float>, dim3(pcgan::WEIGHT_AMAX_SLOTS), dim3(256), 0, st, w, (size_t)d->K * d->C * 9, amax);
+    PCGAN_LAUNCH_CHECK();
     if (pass == PCGAN_PASS_FWD) {
         const int nMt = (d->K + 255) / 256, nst = (d->C / 16) * 9;
         const size_t per_piece = (size_t)nMt * nst * 16 * 256;

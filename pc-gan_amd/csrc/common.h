@@ -122,6 +122,33 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
     return r;
 }
 
+// Two fp16 pieces, x * 2^e = h + l (11 + 11 significand bits), products (l,h) (h,l) (h,h): HALF the matrix instructions of the
+// three-piece bf16 split.  scripts/micro/bf16_split, K = 2304 against float64: relative L2 error 5.3e-7 (fp32 MFMA 6.1e-7, bf16 x 6
+// 7.0e-7).  fp16 has 5 exponent bits, so each operand tensor is scaled by a power of two that puts its largest magnitude in
+// (2^13, 2^14] (the largest magnitude is computed on the device: pcgan_absmax, or handed over by the producing kernel); the
+// accumulators are scaled back (exactly) in the epilogue.  An element below 2^-17 of the tensor's largest loses its low piece
+// (error <= 2^-39 of the largest magnitude per element).
+__device__ __forceinline__ float pow2_scale(float amax) {
+    if (!(amax > 0.f)) return 1.f;
+    int e;
+    frexpf(amax, &e);                     // amax = m * 2^e, m in [0.5, 1)
+    e = 14 - e;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return ldexpf(1.f, e);
+}
+// largest of n partial maxima (n small: every thread reads them all)
+__device__ __forceinline__ float max_of_partials(const float* __restrict__ p, int n) {
+    float m = 0.f;
+    for (int i = 0; i < n; ++i) m = fmaxf(m, p[i]);
+    return m;
+}
+static constexpr int WEIGHT_AMAX_SLOTS = 64;     // partial maxima kept for a weight tensor
+
+__device__ __forceinline__ void split2h(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)(x - (float)h);
+}
+
 // largest v over the workgroup, thread 0 gets it (others: a partial value)
 __device__ __forceinline__ float block_max(float v, float* scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

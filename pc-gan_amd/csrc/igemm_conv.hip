@@ -170,6 +170,10 @@ struct IgemmArgs {
     float* Ypart; // [ksplit][N][M][Yh][Yw] partial sums (then reduced + bias + activation by splitk_reduce)
     int tstart[17];  // igemm2_kernel: first pixel tile of each phase in the linearised grid (no empty workgroups)
     PhaseArgs ph[16];
+    // fp16 two-piece form (hgemm_kernel): partial maxima of |X| and the largest |weight| (device); hsplit selects the kernel
+    const float* x_amax;
+    const float* w_amax;
+    int x_namax, hsplit;
 };
 
 struct Geom {
@@ -805,6 +809,266 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// fp16 two-piece form of the chunked-K kernel (fp32 tensors; forward with zero / reflection padding and the plain data gradient,
+// any stride, <= 25 taps, channel count a multiple of 16): the same gather tables, K order, phases and split-K as igemm2_kernel,
+// but both operands are scaled by a power of two and split into two fp16 pieces on their way to LDS (x * 2^e = h + l, common.h
+// pow2_scale / split2h) and a 16-deep K stage is THREE v_mfma_f32_32x32x16_f16 per 32 x 32 block -- (l,h) (h,l) (h,h) -- instead of
+// eight v_mfma_f32_32x32x2_f32.  Measured error at the fp32 kernel's level (scripts/micro/bf16_split: 5.3e-7 at K = 2304, fp32
+// MFMA 6.1e-7).  a.x_amax[0 .. x_namax) are partial maxima of |X| (device), a.w_amax the largest |weight|.
+//   LDS images [piece][k half][row or pixel][8 fp16]: every operand read is one conflict-free ds_read_b128;
+//   per wave and stage (128 x 128 tile): 12 MFMA, 8 LDS reads; weights 2 x 16-byte loads, pixels 8 x 4-byte gathers per thread;
+//   global loads two stages ahead in registers, LDS one stage ahead, operands of the next stage read under this stage's MFMAs.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE, int BM, int BP>
+__global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
+    static_assert(MODE == MODE_FWD_ZERO || MODE == MODE_FWD_REFLECT || MODE == MODE_BWD, "forward and plain data gradient");
+    constexpr int WM = (BM == 128 || (BM == 64 && BP == 64)) ? 2 : 1;
+    constexpr int WP = 4 / WM;
+    constexpr int WMT = BM / WM, WPT = BP / WP;
+    constexpr int MI = WMT / 32, PJ = WPT / 32;
+    constexpr int KPT = BP / 16;        // channels of its pixel a thread gathers per stage (8 or 4)
+    constexpr int ACH = BM * 4 / 256;   // float4 of the weight tile per thread (2 or 1)
+    constexpr int TROWS = NTAP_FWD + 1; // + one all-out-of-range row for dead stages
+    __shared__ __attribute__((aligned(16))) f16x8 As[2][2][2 * BM];     // [buffer][piece][k half * BM + row]
+    __shared__ __attribute__((aligned(16))) f16x8 Bs[2][2][2 * BP];     // [buffer][piece][k half * BP + pixel]
+    __shared__ unsigned offT[TROWS][BP];
+    __shared__ __attribute__((aligned(16))) float biasS[BM];
+
+    const int nMt = (a.M + BM - 1) / BM;
+    const int mt = blockIdx.x % nMt;
+    int pt = blockIdx.x / nMt;
+    int phase = 0;
+    while (phase + 1 < a.nphase && pt >= a.tstart[phase + 1]) ++phase;
+    pt -= a.tstart[phase];
+    const PhaseArgs& P = a.ph[phase];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WP, wp = wave % WP;
+    const int Ptot = P.Ptot, Kp = P.Kp;
+    const int m0 = mt * BM, p0 = pt * BP;
+    const int ph_nS = P.nS;
+    const int T = P.nR * ph_nS;
+    const int HgWg4 = a.Hg * a.Wg * 4;
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(P.A, (unsigned)a.M * (unsigned)Kp * 4u);
+
+    // operand scales (largest of the partial maxima the producer left)
+    float sx, sw;
+    {
+        float m = 0.f;
+        for (int i = tid; i < a.x_namax; i += 256) m = fmaxf(m, a.x_amax[i]);
+        sx = pow2_scale(block_max(m, biasS));
+        sw = pow2_scale(block_max(tid < WEIGHT_AMAX_SLOTS ? a.w_amax[tid] : 0.f, biasS));
+        __syncthreads();
+    }
+    // gather-offset table of this workgroup's BP pixels (as in igemm2_kernel)
+    const int pl = tid % BP;
+    {
+        const int pg = p0 + pl;
+        const bool pvalid = pg < Ptot;
+        int gn = 0, py = 0, px = 0;
+        if (pvalid) pix_coord(a, P, pg, gn, py, px);
+        const unsigned vbase = (unsigned)gn * (unsigned)a.Cg * (unsigned)(a.Hg * a.Wg);
+        for (int t = tid / BP; t <= T; t += 256 / BP) {
+            const int ri = t / ph_nS, sj = t - ri * ph_nS;
+            const int r = P.r0 + ri * a.tstep, sxx = P.s0 + sj * a.tstep;
+            const bool live = pvalid && t < T;
+            const unsigned y = axis_entry<MODE>(py, py + a.pad, true, r, a.Hg, a.sl, a.pad);
+            const unsigned x = axis_entry<MODE>(px, px + a.pad, true, sxx, a.Wg, a.sl, a.pad);
+            offT[t][pl] = (live && y != 0xffffffffu && x != 0xffffffffu) ? (vbase + y * (unsigned)a.Wg + x) * 4u : OOB;
+        }
+        if (tid < BM) biasS[tid] = (a.bias != nullptr && m0 + tid < a.M) ? a.bias[m0 + tid] : 0.f;
+    }
+    const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);
+    __syncthreads();
+
+    const int nst_all = Kp >> 4;
+    const int nst_per = a.ksplit > 1 ? (nst_all + a.ksplit - 1) / a.ksplit : nst_all;
+    const int st_begin = a.ksplit > 1 ? (int)blockIdx.z * nst_per : 0;
+    const int st_end = st_begin + nst_per < nst_all ? st_begin + nst_per : nst_all;
+    const int nst_here = st_end > st_begin ? st_end - st_begin : 0;
+
+    // load-side iterator (scalar): tap, first channel and weight column of the next stage to load
+    int it_tap, it_c, it_k0, it_left = nst_here;
+    {
+        const int cc0 = st_begin / T;
+        it_tap = st_begin - cc0 * T;
+        it_c = cc0 * 16;
+        it_k0 = st_begin * 16;
+    }
+    unsigned a_base[ACH];
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) {
+        const int q = tid + 256 * j;
+        const int row = q >> 2, kc = (q & 3) * 4;
+        a_base[j] = (m0 + row < a.M) ? (unsigned)((m0 + row) * Kp + kc) * 4u : OOB;
+    }
+    struct Stage {
+        u32x4 av[ACH];      // 4 consecutive k of this thread's weight row(s)
+        unsigned bv[KPT];   // KPT consecutive channels of this thread's pixel
+    };
+    auto load = [&](Stage& r) {
+        const bool live = it_left > 0;
+        const unsigned vo = offT[live ? it_tap : T][pl];
+        const unsigned so = (unsigned)((it_c + ksub * KPT) * HgWg4);
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) r.av[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, live ? a_base[j] : OOB, (unsigned)it_k0 * 4u, 0);
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) r.bv[i] = __builtin_amdgcn_raw_buffer_load_b32(rX, vo, so + (unsigned)(i * HgWg4), 0);
+        --it_left;
+        const int t1 = it_tap + 1;
+        const bool wr = t1 == T;
+        it_tap = wr ? 0 : t1;
+        it_c += wr ? 16 : 0;
+        it_k0 += 16;
+    };
+    auto stash = [&](const Stage& r, int buf) {
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) {
+            const int q = tid + 256 * j;
+            const int row = q >> 2, kc = (q & 3) * 4;
+            f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 x, y;
+                split2h(__uint_as_float(r.av[j][e]) * sw, x, y);
+                h[e] = x;
+                l[e] = y;
+            }
+            _Float16* d0 = reinterpret_cast<_Float16*>(&As[buf][0][(kc >> 3) * BM + row]) + (kc & 4);
+            _Float16* d1 = reinterpret_cast<_Float16*>(&As[buf][1][(kc >> 3) * BM + row]) + (kc & 4);
+            *reinterpret_cast<f16x4*>(d0) = h;
+            *reinterpret_cast<f16x4*>(d1) = l;
+        }
+        if constexpr (KPT == 8) {
+            f16x8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 x, y;
+                split2h(__uint_as_float(r.bv[e]) * sx, x, y);
+                h[e] = x;
+                l[e] = y;
+            }
+            Bs[buf][0][ksub * BP + pl] = h;
+            Bs[buf][1][ksub * BP + pl] = l;
+        } else {
+            f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 x, y;
+                split2h(__uint_as_float(r.bv[e]) * sx, x, y);
+                h[e] = x;
+                l[e] = y;
+            }
+            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(&Bs[buf][0][(ksub >> 1) * BP + pl]) + (ksub & 1) * 4) = h;
+            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(&Bs[buf][1][(ksub >> 1) * BP + pl]) + (ksub & 1) * 4) = l;
+        }
+    };
+
+    f32x16 acc[MI][PJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < PJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    struct Operands {
+        f16x8 A[2][MI], B[2][PJ];
+    };
+    auto fetch = [&](Operands& o, int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) o.A[p][i] = As[buf][p][hi * BM + wm * WMT + i * 32 + lo];
+#pragma unroll
+            for (int j = 0; j < PJ; ++j) o.B[p][j] = Bs[buf][p][hi * BP + wp * WPT + j * 32 + lo];
+        }
+    };
+    auto mma = [&](const Operands& o) {      // (l,h) (h,l) (h,h): smallest terms first
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < PJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.A[PA[q]][i], o.B[PB[q]][j], acc[i][j], 0, 0, 0);
+    };
+    auto interleave = [&]() {
+        constexpr int NM = 3 * MI * PJ, NRD = 2 * (MI + PJ);
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, (NRD + NM - 1) / NM, 0);          // LDS reads of the next stage first
+            __builtin_amdgcn_sched_group_barrier(0x002, 48 / NM + 1, 0);                  // split arithmetic
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                            // LDS writes
+            __builtin_amdgcn_sched_group_barrier(0x020, (ACH + KPT + NM - 1) / NM, 0);    // global loads
+        }
+    };
+
+    if (nst_here > 0) {
+        Stage rg[2];
+        Operands op[2];
+        load(rg[0]);
+        load(rg[1]);
+        stash(rg[0], 0);
+        __syncthreads();
+        load(rg[0]);
+        fetch(op[0], 0);
+        stash(rg[1], 1);
+        __syncthreads();
+        load(rg[1]);
+        const int nst2 = (nst_here + 1) & ~1;      // an odd count is rounded up: the dead stage gathered zeros
+        for (int s = 0; s < nst2; s += 2) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fetch(op[t ^ 1], t ^ 1);           // operands of stage s+t+1
+                mma(op[t]);                        // stage s+t
+                stash(rg[t], t);                   // stage s+t+2
+                load(rg[t]);                       // stage s+t+4
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // epilogue (as igemm2_kernel): scale back (powers of two: exact), bias + activation or raw partial sum of a K split
+    const float isx = 1.f / sx, isw = 1.f / sw;
+    const int YhYw = a.Yh * a.Yw;
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        const int pix = p0 + wp * WPT + j * 32 + lo;
+        if (pix >= Ptot) continue;
+        int n, oy, ox;
+        pix_coord(a, P, pix, n, oy, ox);
+        if (a.ksplit > 1) {
+            float* Yp = a.Ypart + ((size_t)blockIdx.z * a.N + n) * a.M * YhYw + oy * a.Yw + ox;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (m < a.M) Yp[(size_t)m * YhYw] = (acc[i][j][r] * isx) * isw;
+                }
+            continue;
+        }
+        float* Yp = (float*)a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m0 + ml < a.M) Yp[(size_t)(m0 + ml) * YhYw] = act_apply((acc[i][j][r] * isx) * isw + biasS[ml], a.act, a.slope);
+            }
     }
 }
 
@@ -2196,6 +2460,17 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
             PCGAN_CHECK(a.ph[i].nR * a.ph[i].nS <= (MODE == MODE_BWD_REFLECT ? NTAP_MIR : NTAP_FWD) && (a.ph[i].Kp % 16) == 0,
                         "igemm: chunked K order: bad phase");
     }
+    if (a.hsplit && cg16 && MODE != MODE_BWD_REFLECT && a.dtype == PCGAN_F32 && bm >= 64) {
+        // fp16 two-piece form of the same launch (same tiles, phases, K splits)
+        constexpr int HMODE = MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE;
+        if (bm == 128 && bp == 128) hipLaunchKernelGGL((hgemm_kernel<HMODE, 128, 128>), grid2, dim3(256), 0, st, a);
+        else if (bm == 128) hipLaunchKernelGGL((hgemm_kernel<HMODE, 128, 64>), grid2, dim3(256), 0, st, a);
+        else if (bp == 128) hipLaunchKernelGGL((hgemm_kernel<HMODE, 64, 128>), grid2, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((hgemm_kernel<HMODE, 64, 64>), grid2, dim3(256), 0, st, a);
+        PCGAN_LAUNCH_CHECK();
+        if (ks > 1 && launch_splitk_reduce(a.dtype, st, part_ws, a.Y, a.bias, ks, out_elems, a.M, a.Yh * a.Yw, a.act, a.slope)) return 2;
+        return 0;
+    }
 #define LI(BMV, BPV)                                                                                   \
     do {                                                                                               \
         if (cg16) LAUNCH_TA(a.dtype, igemm2_kernel, grid2, a, MODE, BMV, BPV, 16);                      \
@@ -2350,9 +2625,16 @@ static int pack_fwd(const pcgan_conv_desc* d, const float* w, float* A, hipStrea
     return 0;
 }
 
+// operand maxima of the fp16 two-piece form (null: the fp32 MFMA kernels)
+struct HsplitOpt {
+    const float* x_amax;
+    int n_amax;
+    const float* w_amax;
+};
+
 static int conv2d_fwd_impl(const pcgan_conv_desc* d, const void* x, const float* w, const float* packed,
                            const float* bias, void* y, int act, float slope, void* ws, size_t ws_bytes,
-                           pcgan_stream_t s) {
+                           pcgan_stream_t s, const HsplitOpt* hs = nullptr) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(x && (w || packed) && y, "conv2d_fwd: null pointer");
     PCGAN_CHECK(ws && ws_bytes >= pcgan_conv2d_workspace_bytes(d, PCGAN_PASS_FWD),
@@ -2371,6 +2653,9 @@ static int conv2d_fwd_impl(const pcgan_conv_desc* d, const void* x, const float*
     a.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * esz(d));
     a.nphase = 1;
     a.chunked = chunked_k(d->C, d->K, d->R, d->S) ? 1 : (cg4_k(d->C, d->K, d->R, d->S) ? 2 : 0);
+    if (hs) {
+        a.hsplit = 1; a.x_amax = hs->x_amax; a.x_namax = hs->n_amax; a.w_amax = hs->w_amax;
+    }
     PhaseArgs& p = a.ph[0];
     p.A = A; p.Kp = RS * Cgp; p.Hs = d->P; p.Ws = d->Q; p.fy = 0; p.fx = 0;
     if (d->K <= 4) {  // small-M path reads the weights as [k][4] / [c][ri][8][4]
@@ -2398,7 +2683,7 @@ extern "C" int pcgan_conv2d_fwd_packed(const pcgan_conv_desc* d, const void* x, 
 }
 
 static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const void* dy, const float* w, const float* packed,
-                                const float* bias, void* dx, void* ws, size_t ws_bytes, pcgan_stream_t s) {
+                                const float* bias, void* dx, void* ws, size_t ws_bytes, pcgan_stream_t s, const HsplitOpt* hs = nullptr) {
     if (check_desc(d)) return 1;
     const bool pack_only = dx == nullptr;   // pcgan_conv2d_pack_weights: run the repack launches into `packed` only
     PCGAN_CHECK(pack_only ? (w && packed) : (dy && (w || packed)), "conv2d_bwd_data: null pointer");
@@ -2434,6 +2719,9 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const void* dy, const 
     a.act = PCGAN_ACT_NONE; a.slope = 0.f;
     a.chunked = chunked ? 1 : (cg4_k(d->K, d->C, d->R, d->S) ? 2 : 0);
     a.rowfold = rowfold;
+    if (hs) {
+        a.hsplit = 1; a.x_amax = hs->x_amax; a.x_namax = hs->n_amax; a.w_amax = hs->w_amax;
+    }
     a.x_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * esz(d));
 
     if (rowfold) {
@@ -2556,6 +2844,34 @@ extern "C" int pcgan_conv2d_bwd_data_packed(const pcgan_conv_desc* d, const void
     if (check_desc(d)) return 1;
     PCGAN_CHECK(packed && dx, "conv2d_bwd_data_packed: null pointer");
     return conv2d_bwd_data_impl(d, dy, nullptr, packed, bias, dx, ws, ws_bytes, s);
+}
+
+// ---- fp16 two-piece form of the packed calls (fp32 tensors, hgemm_kernel): same packed weights, workspace and results layout as
+// pcgan_conv2d_fwd_packed / pcgan_conv2d_bwd_data_packed; x_amax[0 .. n_amax) partial maxima of |x| (pcgan_absmax or a producer's
+// plane maxima) and w_amax[0 .. 64) partial maxima of |weight| (pcgan_absmax with 64 slots), both on the device
+extern "C" int pcgan_conv2d_hgemm_supported(const pcgan_conv_desc* d, int pass) {
+    if (!d || d->dtype != PCGAN_F32) return 0;
+    if (pass == PCGAN_PASS_FWD) return chunked_k(d->C, d->K, d->R, d->S) && d->K > 32;
+    if (pass == PCGAN_PASS_BWD_DATA) return d->pad_mode == 0 && chunked_k(d->K, d->C, d->R, d->S) && d->C > 32;
+    return 0;
+}
+extern "C" int pcgan_conv2d_fwd_packed_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_amax, const float* packed,
+                                              const float* w_amax, const float* bias, void* y, int act, float slope, void* ws,
+                                              size_t ws_bytes, pcgan_stream_t s) {
+    if (check_desc(d)) return 1;
+    PCGAN_CHECK(pcgan_conv2d_hgemm_supported(d, PCGAN_PASS_FWD), "conv2d_fwd_packed_hsplit: unsupported shape");
+    PCGAN_CHECK(packed && x_amax && n_amax > 0 && w_amax, "conv2d_fwd_packed_hsplit: null pointer");
+    const HsplitOpt hs = {x_amax, n_amax, w_amax};
+    return conv2d_fwd_impl(d, x, nullptr, packed, bias, y, act, slope, ws, ws_bytes, s, &hs);
+}
+extern "C" int pcgan_conv2d_bwd_data_packed_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax,
+                                                   const float* packed, const float* w_amax, const float* bias, void* dx, void* ws,
+                                                   size_t ws_bytes, pcgan_stream_t s) {
+    if (check_desc(d)) return 1;
+    PCGAN_CHECK(pcgan_conv2d_hgemm_supported(d, PCGAN_PASS_BWD_DATA), "conv2d_bwd_data_packed_hsplit: unsupported shape");
+    PCGAN_CHECK(packed && dx && dy_amax && n_amax > 0 && w_amax, "conv2d_bwd_data_packed_hsplit: null pointer");
+    const HsplitOpt hs = {dy_amax, n_amax, w_amax};
+    return conv2d_bwd_data_impl(d, dy, nullptr, packed, bias, dx, ws, ws_bytes, s, &hs);
 }
 
 extern "C" size_t pcgan_conv2d_packed_bytes(const pcgan_conv_desc* d, int pass) {

@@ -108,6 +108,7 @@ struct NormArgs {
     const float* s2;
     void* out;              // T (norm_act_fwd, norm_bwd_apply) or float (norm_bwd_stats)
     void* out2;
+    float* pmax;            // norm_act_fwd / norm_bwd_apply: [N*C] largest magnitude of each plane of `out`, or null
     int N, C, HW, per_plane, act;
     float eps, slope, inv_cnt;
 };
@@ -132,6 +133,7 @@ __global__ void __launch_bounds__(256) norm_act_fwd_kernel(NormArgs a) {
     const T* xp = (const T*)a.x + plane * (size_t)a.HW;
     const T* rp = a.residual ? (const T*)a.residual + plane * (size_t)a.HW : nullptr;
     T* yp = (T*)a.out + plane * (size_t)a.HW;
+    float am = 0.f;
     if ((a.HW & 3) == 0) {
         for (int i = threadIdx.x; i < (a.HW >> 2); i += blockDim.x) {
             float4 v = ld4(xp + 4 * i);
@@ -143,13 +145,21 @@ __global__ void __launch_bounds__(256) norm_act_fwd_kernel(NormArgs a) {
             v.x = act_apply(v.x, a.act, a.slope); v.y = act_apply(v.y, a.act, a.slope);
             v.z = act_apply(v.z, a.act, a.slope); v.w = act_apply(v.w, a.act, a.slope);
             st4(yp + 4 * i, v);
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
     } else {
         for (int i = threadIdx.x; i < a.HW; i += blockDim.x) {
             float v = ld1(xp + i) * sc + sh;
             if (rp) v += ld1(rp + i);
-            st1(yp + i, act_apply(v, a.act, a.slope));
+            v = act_apply(v, a.act, a.slope);
+            st1(yp + i, v);
+            am = fmaxf(am, fabsf(v));
         }
+    }
+    if (a.pmax) {      // plane maximum for the fp16 route of the convolution that reads y (see instnorm_fwd_fused_kernel)
+        __shared__ float scratch[16];
+        am = block_max(am, scratch);
+        if (threadIdx.x == 0) a.pmax[plane] = am;
     }
 }
 
@@ -210,12 +220,20 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(NormArgs a) {
     const T* yp = (a.act != PCGAN_ACT_NONE) ? (const T*)a.y + plane * (size_t)a.HW : nullptr;
     T* op = (T*)a.out + plane * (size_t)a.HW;
     T* rp = a.out2 ? (T*)a.out2 + plane * (size_t)a.HW : nullptr;
+    float am = 0.f;
     for (int i = threadIdx.x; i < a.HW; i += blockDim.x) {
         float g = ld1(dp + i);
         if (yp) g *= act_grad_from_out(ld1(yp + i), a.act, a.slope);
         const float xh = (ld1(xp + i) - mean) * rstd;
-        st1(op + i, k * (g - m1 - xh * m2));
+        const float o = k * (g - m1 - xh * m2);
+        st1(op + i, o);
+        am = fmaxf(am, fabsf(o));
         if (rp) st1(rp + i, g);
+    }
+    if (a.pmax) {
+        __shared__ float scratch[16];
+        am = block_max(am, scratch);
+        if (threadIdx.x == 0) a.pmax[plane] = am;
     }
 }
 
@@ -259,7 +277,7 @@ __global__ void __launch_bounds__(256) bn_fwd_fused_kernel(const T* __restrict__
                                                            T* __restrict__ y, float* __restrict__ mean_c,
                                                            float* __restrict__ var_c, float* running_mean, float* running_var,
                                                            long long* batches, int N, int C, int HW, float momentum, float eps,
-                                                           int act, float slope) {
+                                                           int act, float slope, float* __restrict__ y_cmax) {
     __shared__ float scratch[16];
     const int c = blockIdx.x;
     const int cnt = N * HW;
@@ -289,6 +307,7 @@ __global__ void __launch_bounds__(256) bn_fwd_fused_kernel(const T* __restrict__
     }
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float sc = rsqrtf(var + eps) * g, sh = b - mean * sc;
+    float am = 0.f;
     bn_for_each<V>(N, C, HW, c, [&](size_t i) {
         float v[V], r[V];
         ldv<V>(x + i, v);
@@ -298,9 +317,14 @@ __global__ void __launch_bounds__(256) bn_fwd_fused_kernel(const T* __restrict__
             float t = v[e] * sc + sh;
             if (res) t += r[e];
             v[e] = act_apply(t, act, slope);
+            am = fmaxf(am, fabsf(v[e]));
         }
         stv<V>(y + i, v);
     });
+    if (y_cmax) {      // largest magnitude of this channel of y (partial maxima for the fp16 route of the next convolution)
+        am = block_max(am, scratch);
+        if (threadIdx.x == 0) y_cmax[c] = am;
+    }
 }
 
 template <int V, typename T>
@@ -309,7 +333,7 @@ __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const T* __restrict__
                                                            const float* __restrict__ var_c, const float* __restrict__ gamma,
                                                            T* __restrict__ dx, T* __restrict__ dres,
                                                            float* __restrict__ s1_c, float* __restrict__ s2_c, int N, int C,
-                                                           int HW, float eps, int act, float slope) {
+                                                           int HW, float eps, int act, float slope, float* __restrict__ dx_cmax) {
     __shared__ float scratch[16];
     const int c = blockIdx.x;
     const int cnt = N * HW;
@@ -337,6 +361,7 @@ __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const T* __restrict__
     if (!dx && !dres) return;
     const float m1 = s1 / (float)cnt, m2 = s2 / (float)cnt;
     const float kk = rstd * (gamma ? gamma[c] : 1.f);
+    float am = 0.f;
     bn_for_each<V>(N, C, HW, c, [&](size_t i) {
         float d[V], xv[V], yv[V], o[V], gr[V];
         ldv<V>(dy + i, d);
@@ -348,10 +373,15 @@ __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const T* __restrict__
             if (act != PCGAN_ACT_NONE) g *= act_grad_from_out(yv[e], act, slope);
             gr[e] = g;
             o[e] = kk * (g - m1 - ((xv[e] - mean) * rstd) * m2);
+            am = fmaxf(am, fabsf(o[e]));
         }
         if (dx) stv<V>(dx + i, o);
         if (dres) stv<V>(dres + i, gr);
     });
+    if (dx && dx_cmax) {
+        am = block_max(am, scratch);
+        if (threadIdx.x == 0) dx_cmax[c] = am;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -530,12 +560,12 @@ extern "C" int pcgan_in_running_update(const float* mean_nc, const float* m2_nc,
 }
 
 extern "C" int pcgan_norm_act_fwd(const void* x, const float* mean, const float* var, const float* gamma,
-                                  const float* beta, const void* residual, void* y, int N, int C, int HW,
+                                  const float* beta, const void* residual, void* y, float* y_pmax, int N, int C, int HW,
                                   int per_plane, float eps, int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(x && mean && var && y && N > 0 && C > 0 && HW > 0, "norm_act_fwd: bad arguments");
     NormArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.residual = residual; a.out = y;
+    a.x = x; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.residual = residual; a.out = y; a.pmax = y_pmax;
     a.N = N; a.C = C; a.HW = HW; a.per_plane = per_plane; a.eps = eps; a.act = act; a.slope = slope;
     PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(norm_act_fwd_kernel<T>, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s, a));
     PCGAN_LAUNCH_CHECK();
@@ -567,14 +597,14 @@ extern "C" int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float
 
 extern "C" int pcgan_norm_bwd_apply(const void* dy, const void* x, const void* y, const float* mean,
                                     const float* var, const float* gamma, const float* s1, const float* s2,
-                                    void* dx, void* d_residual, int N, int C, int HW, int per_plane, float eps,
+                                    void* dx, void* d_residual, float* dx_pmax, int N, int C, int HW, int per_plane, float eps,
                                     int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && x && mean && var && s1 && s2 && dx, "norm_bwd_apply: null pointer");
     PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "norm_bwd_apply: activation mask needs y");
     NormArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.y = y; a.dy = dy; a.mean = mean; a.var = var; a.gamma = gamma; a.s1 = s1; a.s2 = s2;
-    a.out = dx; a.out2 = d_residual;
+    a.out = dx; a.out2 = d_residual; a.pmax = dx_pmax;
     a.N = N; a.C = C; a.HW = HW; a.per_plane = per_plane; a.eps = eps; a.act = act; a.slope = slope;
     a.inv_cnt = 1.f / (per_plane ? (float)HW : (float)N * (float)HW);
     PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s, a));
@@ -602,7 +632,7 @@ extern "C" int pcgan_instnorm_fwd(const void* x, const void* residual, void* y, 
     PCGAN_CHECK(!y_pmax || E != 0, "instnorm_fwd: plane maxima come out of the register-resident kernel only (pcgan_instnorm_fused)");
     if (E == 0) {  // plane does not fit the register-resident kernel: statistics pass + apply pass
         if (pcgan_plane_stats(x, mean_nc, m2_nc, N * C, HW, dtype, s)) return 1;
-        return pcgan_norm_act_fwd(x, mean_nc, m2_nc, nullptr, nullptr, residual, y, N, C, HW, 1, eps, act, slope, dtype, s);
+        return pcgan_norm_act_fwd(x, mean_nc, m2_nc, nullptr, nullptr, residual, y, nullptr, N, C, HW, 1, eps, act, slope, dtype, s);
     }
     PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_fwd<T>(E, NT, N * C, st, x, residual, y, mean_nc, m2_nc, HW, eps, act, slope, y_pmax));
     PCGAN_LAUNCH_CHECK();
@@ -641,7 +671,7 @@ extern "C" int pcgan_instnorm_bwd(const void* dy, const void* x, const void* y, 
         PCGAN_CHECK(ws_s1s2, "instnorm_bwd: the two-pass fallback needs 2*N*C floats of workspace");
         if (pcgan_norm_bwd_stats(dy, x, y, mean_nc, m2_nc, ws_s1s2, ws_s1s2 + (size_t)N * C, N, C, HW, 1, eps, act, slope, dtype, s))
             return 1;
-        return pcgan_norm_bwd_apply(dy, x, y, mean_nc, m2_nc, nullptr, ws_s1s2, ws_s1s2 + (size_t)N * C, dx, nullptr, N, C,
+        return pcgan_norm_bwd_apply(dy, x, y, mean_nc, m2_nc, nullptr, ws_s1s2, ws_s1s2 + (size_t)N * C, dx, nullptr, nullptr, N, C,
                                     HW, 1, eps, act, slope, dtype, s);
     }
     PCGAN_DTYPE_SWITCH(dtype, T, launch_instnorm_bwd<T>(E, NT, N * C, st, dy, x, y, mean_nc, m2_nc, dx, dx_psum, HW, eps, act, slope, dx_pmax));
@@ -652,43 +682,45 @@ extern "C" int pcgan_instnorm_bwd(const void* dy, const void* x, const void* y, 
 template <typename T>
 static void launch_bn_fwd(bool v4, hipStream_t st, const void* x, const float* gamma, const float* beta, const void* residual, void* y,
                           float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches, int N, int C, int HW,
-                          float momentum, float eps, int act, float slope) {
+                          float momentum, float eps, int act, float slope, float* y_cmax) {
     if (v4)
         hipLaunchKernelGGL((bn_fwd_fused_kernel<4, T>), dim3(C), dim3(256), 0, st, (const T*)x, gamma, beta, (const T*)residual, (T*)y, mean_c,
-                           var_c, running_mean, running_var, batches, N, C, HW, momentum, eps, act, slope);
+                           var_c, running_mean, running_var, batches, N, C, HW, momentum, eps, act, slope, y_cmax);
     else
         hipLaunchKernelGGL((bn_fwd_fused_kernel<1, T>), dim3(C), dim3(256), 0, st, (const T*)x, gamma, beta, (const T*)residual, (T*)y, mean_c,
-                           var_c, running_mean, running_var, batches, N, C, HW, momentum, eps, act, slope);
+                           var_c, running_mean, running_var, batches, N, C, HW, momentum, eps, act, slope, y_cmax);
 }
 
 extern "C" int pcgan_bn_fwd_fused(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
                                   float* mean_c, float* var_c, float* running_mean, float* running_var, long long* batches,
-                                  int N, int C, int HW, float momentum, float eps, int act, float slope, int dtype, pcgan_stream_t s) {
+                                  float* y_cmax, int N, int C, int HW, float momentum, float eps, int act, float slope, int dtype,
+                                  pcgan_stream_t s) {
     PCGAN_CHECK(x && y && mean_c && var_c && N > 0 && C > 0 && HW > 0 && (long long)N * HW > 1, "bn_fwd_fused: bad arguments");
     PCGAN_DTYPE_SWITCH(dtype, T, launch_bn_fwd<T>((HW & 3) == 0, (hipStream_t)s, x, gamma, beta, residual, y, mean_c, var_c, running_mean,
-                                                  running_var, batches, N, C, HW, momentum, eps, act, slope));
+                                                  running_var, batches, N, C, HW, momentum, eps, act, slope, y_cmax));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
 
 template <typename T>
 static void launch_bn_bwd(bool v4, hipStream_t st, const void* dy, const void* x, const void* y, const float* mean_c, const float* var_c,
-                          const float* gamma, void* dx, void* dres, float* s1_c, float* s2_c, int N, int C, int HW, float eps, int act, float slope) {
+                          const float* gamma, void* dx, void* dres, float* s1_c, float* s2_c, int N, int C, int HW, float eps, int act, float slope,
+                          float* dx_cmax) {
     if (v4)
         hipLaunchKernelGGL((bn_bwd_fused_kernel<4, T>), dim3(C), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, mean_c, var_c, gamma,
-                           (T*)dx, (T*)dres, s1_c, s2_c, N, C, HW, eps, act, slope);
+                           (T*)dx, (T*)dres, s1_c, s2_c, N, C, HW, eps, act, slope, dx_cmax);
     else
         hipLaunchKernelGGL((bn_bwd_fused_kernel<1, T>), dim3(C), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, mean_c, var_c, gamma,
-                           (T*)dx, (T*)dres, s1_c, s2_c, N, C, HW, eps, act, slope);
+                           (T*)dx, (T*)dres, s1_c, s2_c, N, C, HW, eps, act, slope, dx_cmax);
 }
 
 extern "C" int pcgan_bn_bwd_fused(const void* dy, const void* x, const void* y, const float* mean_c, const float* var_c,
-                                  const float* gamma, void* dx, void* dres, float* s1_c, float* s2_c, int N, int C, int HW,
+                                  const float* gamma, void* dx, void* dres, float* s1_c, float* s2_c, float* dx_cmax, int N, int C, int HW,
                                   float eps, int act, float slope, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && x && mean_c && var_c && s1_c && s2_c && N > 0 && C > 0 && HW > 0, "bn_bwd_fused: bad arguments");
     PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "bn_bwd_fused: activation mask needs y");
     PCGAN_DTYPE_SWITCH(dtype, T, launch_bn_bwd<T>((HW & 3) == 0, (hipStream_t)s, dy, x, y, mean_c, var_c, gamma, dx, dres, s1_c, s2_c, N, C, HW,
-                                                  eps, act, slope));
+                                                  eps, act, slope, dx_cmax));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

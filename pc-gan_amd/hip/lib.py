@@ -55,12 +55,12 @@ SIGNATURES = {
     'pcgan_plane_stats': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'pcgan_bn_merge': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     'pcgan_in_running_update': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
-    'pcgan_norm_act_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
+    'pcgan_norm_act_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
     'pcgan_norm_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
-    'pcgan_norm_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
+    'pcgan_norm_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
     'pcgan_bn_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
-    'pcgan_bn_fwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _i, _vp]),
-    'pcgan_bn_bwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
+    'pcgan_bn_fwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _i, _vp]),
+    'pcgan_bn_bwd_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
     'pcgan_instnorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
     'pcgan_instnorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _vp]),
     'pcgan_instnorm_fused': (_i, [_i]),
@@ -88,12 +88,16 @@ SIGNATURES = {
     'pcgan_conv2d_bsplit_wgrad_supported': (_i, [_dp]),
     'pcgan_conv2d_bsplit_wgrad_workspace_bytes': (_sz, [_dp]),
     'pcgan_conv2d_bwd_weight_bsplit': (_i, [_dp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
-    'pcgan_absmax': (_i, [_vp, _sz, _i, _vp, _vp]),
+    'pcgan_absmax_slots': (_i, [_sz]),
+    'pcgan_absmax': (_i, [_vp, _sz, _i, _vp, _i, _vp]),
     'pcgan_conv2d_hsplit_supported': (_i, [_dp, _i]),
     'pcgan_conv2d_hsplit_packed_bytes': (_sz, [_dp, _i]),
     'pcgan_conv2d_hsplit_pack': (_i, [_dp, _i, _vp, _vp, _vp]),
     'pcgan_conv2d_fwd_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp]),
     'pcgan_conv2d_bwd_data_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp]),
+    'pcgan_conv2d_hgemm_supported': (_i, [_dp, _i]),
+    'pcgan_conv2d_fwd_packed_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
+    'pcgan_conv2d_bwd_data_packed_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pcgan_conv2d_hsplit_wgrad_supported': (_i, [_dp]),
     'pcgan_conv2d_hsplit_wgrad_workspace_bytes': (_sz, [_dp]),
     'pcgan_conv2d_bwd_weight_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),

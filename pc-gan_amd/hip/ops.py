@@ -196,8 +196,17 @@ _PACK_EPOCH = [0]
 KERNEL_TIMER = None
 
 
-def invalidate_packed_weights():
-    _PACK_EPOCH[0] += 1
+def invalidate_packed_weights(params=None):
+    """packed copies (and weight maxima) of `params` -- or, without a list, of every weight tensor -- are out of date"""
+    if params is None:
+        _PACK_EPOCH[0] += 1
+        return
+    for p in params:     # the optimizer that wrote them: nets it does not own (the frozen encoder, AlexNet) keep their packs
+        p._pcgan_wepoch = p.__dict__.get('_pcgan_wepoch', 0) + 1
+
+
+def _weight_stamp(w):
+    return (_PACK_EPOCH[0], w.__dict__.get('_pcgan_wepoch', 0), w._version, w.data_ptr(), tuple(w.shape))
 
 
 # The residual-block convolutions (forward, data gradient, weight gradient) run on the bf16 matrix pipe with every fp32
@@ -212,9 +221,18 @@ PASS_BWD_HSPLIT = 103
 # Which split the fp32 residual convolutions (forward, data gradient) take on the matrix pipe: 'f16' = two scaled fp16 pieces, three
 # products (csrc/bf16x6_conv.hip, "fp16 route"); 'bf16' = three bf16 pieces, six products.  Same measured error, half the MFMAs.
 HSPLIT = os.environ.get('PCGAN_SPLIT', 'f16') == 'f16'
+# ... and whether every other convolution with a multiple of 16 gathered channels runs the fp16 two-piece form of the packed
+# implicit GEMM (csrc/igemm_conv.hip hgemm_kernel) instead of the fp32 MFMA one
+HGEMM = os.environ.get('PCGAN_HGEMM', '1') == '1'
 
 
 AMAX_STATS = {'attached': 0, 'computed': 0}     # operand maxima handed over by the producing kernel / taken by an absmax pass
+
+
+def _want_maxima(dt, C):
+    """does a norm kernel leave the plane / channel maxima of its output for the fp16 route of the next convolution?
+    (fp32 tensors whose channel count a matrix-pipe convolution can gather: a multiple of 16)"""
+    return HSPLIT and dt == F32 and C % 16 == 0
 
 
 def _attach_amax(t, pmax):
@@ -231,14 +249,39 @@ def amax_of(x):
             ent[1].record_stream(torch.cuda.current_stream())
         return ent[1]
     AMAX_STATS['computed'] += 1
-    out = torch.empty(1, dtype=torch.float32, device=x.device)
-    _L.check(_L.load().pcgan_absmax(_p(x), x.numel(), _DTYPES[x.dtype], _p(out), _stream()), 'absmax')
+    lib = _L.load()
+    slots = int(lib.pcgan_absmax_slots(x.numel()))
+    out = torch.empty(slots, dtype=torch.float32, device=x.device)
+    _L.check(lib.pcgan_absmax(_p(x), x.numel(), _DTYPES[x.dtype], _p(out), slots, _stream()), 'absmax')
+    return out
+
+
+WEIGHT_AMAX_SLOTS = 64     # csrc/common.h
+
+
+def _weight_amax(lib, w, cache):
+    """[64] partial maxima of |w| on the device, kept with the packed weights (same validity stamp)"""
+    stamp = _weight_stamp(w)
+    ent = cache.get('wamax')
+    if ent is not None and ent[0] == stamp:
+        if ent[3] != _raw_stream():
+            torch.cuda.current_stream().wait_event(ent[2])
+        return ent[1]
+    cur = torch.cuda.current_stream()
+    if ent is not None and ent[3] != cur.cuda_stream:
+        for st in list(_side.values()) + list(_branch.values()):
+            cur.wait_stream(st)
+    out = ent[1] if ent is not None else torch.empty(WEIGHT_AMAX_SLOTS, dtype=torch.float32, device=w.device)
+    _L.check(lib.pcgan_absmax(_p(w), w.numel(), F32, _p(out), WEIGHT_AMAX_SLOTS, _stream()), 'absmax')
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    cache['wamax'] = (stamp, out, ev, cur.cuda_stream)
     return out
 
 
 def _packed_weights(lib, d, pass_, w, cache):
     key = (pass_, d.stride, d.pad, d.pad_mode, d.dtype)
-    stamp = (_PACK_EPOCH[0], w._version, w.data_ptr(), tuple(w.shape))
+    stamp = _weight_stamp(w)
     ent = cache.get(key)
     if ent is not None and ent[0] == stamp:
         if ent[3] != _raw_stream():      # packed on another stream (branch streams): order this use after the pack
@@ -299,7 +342,12 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
         if KERNEL_TIMER is not None and KERNEL_TIMER['key'] == (N, C, H, W, K, R, S, stride, pad, pad_mode):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        if hsplit:
+        hgemm = (not bsplit) and HSPLIT and HGEMM and dt == F32 and lib.pcgan_conv2d_hgemm_supported(ctypes.byref(d), _L.PASS_FWD)
+        if hgemm:
+            xmax, wmax = amax_of(x), _weight_amax(lib, w, pack_cache)
+            _L.check(lib.pcgan_conv2d_fwd_packed_hsplit(ctypes.byref(d), _p(x), _p(xmax), xmax.numel(), _p(pk), _p(wmax), _p(bias), _p(y), act,
+                                                        float(slope), _p(ws), ws.numel(), _stream()), 'conv2d_fwd_packed_hsplit')
+        elif hsplit:
             _L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), _p(x), _p(xmax), xmax.numel(), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
                      'conv2d_fwd_hsplit')
         elif bsplit:
@@ -343,6 +391,11 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
             _L.check(lib.pcgan_conv2d_bwd_data_bsplit(ctypes.byref(d), _p(dy), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_bsplit')
             return dx
         pk = _packed_weights(lib, d, _L.PASS_BWD_DATA, w, pack_cache)
+        if HSPLIT and HGEMM and dt == F32 and lib.pcgan_conv2d_hgemm_supported(ctypes.byref(d), _L.PASS_BWD_DATA):
+            dmax, wmax = amax_of(dy), _weight_amax(lib, w, pack_cache)
+            _L.check(lib.pcgan_conv2d_bwd_data_packed_hsplit(ctypes.byref(d), _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(wmax), _p(bias), _p(dx),
+                                                             _p(ws), ws.numel(), _stream()), 'conv2d_bwd_data_packed_hsplit')
+            return dx
         _L.check(lib.pcgan_conv2d_bwd_data_packed(ctypes.byref(d), _p(dy), _p(pk), _p(bias), _p(dx), _p(ws),
                                                   ws.numel(), _stream()), 'conv2d_bwd_data_packed')
         return dx
@@ -488,9 +541,12 @@ def norm_act_fwd(x, mean, var, gamma, beta, residual, per_plane, eps, act, slope
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     y = torch.empty_like(x)
-    _L.check(_L.load().pcgan_norm_act_fwd(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(residual), _p(y), N, C,
+    pmax = torch.empty(N * C, dtype=torch.float32, device=x.device) if _want_maxima(dt, C) else None
+    _L.check(_L.load().pcgan_norm_act_fwd(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(residual), _p(y), _p(pmax), N, C,
                                           HW, int(per_plane), float(eps), act, float(slope), dt, _stream()),
              'norm_act_fwd')
+    if pmax is not None:
+        _attach_amax(y, pmax)
     return y
 
 
@@ -522,9 +578,12 @@ def norm_bwd_apply(dy, x, y, mean, var, gamma, s1, s2, per_plane, eps, act, slop
     HW = x.numel() // (N * C)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_residual_grad else None
+    pmax = torch.empty(N * C, dtype=torch.float32, device=x.device) if _want_maxima(dt, C) else None
     _L.check(_L.load().pcgan_norm_bwd_apply(_p(dy), _p(x), _p(y), _p(mean), _p(var), _p(gamma), _p(s1), _p(s2),
-                                            _p(dx), _p(dres), N, C, HW, int(per_plane), float(eps), act,
+                                            _p(dx), _p(dres), _p(pmax), N, C, HW, int(per_plane), float(eps), act,
                                             float(slope), dt, _stream()), 'norm_bwd_apply')
+    if pmax is not None:
+        _attach_amax(dx, pmax)
     return dx, dres
 
 
@@ -542,9 +601,12 @@ def bn_fwd_fused(x, gamma, beta, residual, running_mean, running_var, batches, m
     var = torch.empty(C, dtype=torch.float32, device=x.device)
     if batches is not None:
         assert batches.dtype == torch.int64 and batches.is_cuda
+    cmax = torch.empty(C, dtype=torch.float32, device=x.device) if _want_maxima(dt, C) else None
     _L.check(_L.load().pcgan_bn_fwd_fused(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(mean), _p(var), _p(running_mean),
-                                          _p(running_var), _p(batches), N, C, HW, float(momentum), float(eps), act, float(slope),
+                                          _p(running_var), _p(batches), _p(cmax), N, C, HW, float(momentum), float(eps), act, float(slope),
                                           dt, _stream()), 'bn_fwd_fused')
+    if cmax is not None:
+        _attach_amax(y, cmax)
     return y, mean, var
 
 
@@ -557,8 +619,11 @@ def bn_bwd_fused(dy, x, y, mean, var, gamma, eps, act, slope, want_dx, want_dres
     dres = torch.empty_like(x) if want_dres else None
     s1 = torch.empty(C, dtype=torch.float32, device=x.device)
     s2 = torch.empty(C, dtype=torch.float32, device=x.device)
-    _L.check(_L.load().pcgan_bn_bwd_fused(_p(dy), _p(x), _p(y), _p(mean), _p(var), _p(gamma), _p(dx), _p(dres), _p(s1), _p(s2),
+    cmax = torch.empty(C, dtype=torch.float32, device=x.device) if want_dx and _want_maxima(dt, C) else None
+    _L.check(_L.load().pcgan_bn_bwd_fused(_p(dy), _p(x), _p(y), _p(mean), _p(var), _p(gamma), _p(dx), _p(dres), _p(s1), _p(s2), _p(cmax),
                                           N, C, HW, float(eps), act, float(slope), dt, _stream()), 'bn_bwd_fused')
+    if cmax is not None:
+        _attach_amax(dx, cmax)
     return dx, dres, s1, s2
 
 
@@ -572,8 +637,7 @@ def instnorm_fwd(x, residual, eps, act, slope):
     m2 = torch.empty(N * C, dtype=torch.float32, device=x.device)
     lib = _L.load()
     # the largest magnitude of y for the fp16 route of the convolution that reads it (residual blocks: width 32 / 64 planes)
-    slot = (torch.empty(N * C, dtype=torch.float32, device=x.device)
-            if HSPLIT and dt == F32 and x.shape[-1] in (32, 64) and lib.pcgan_instnorm_fused(HW) else None)
+    slot = torch.empty(N * C, dtype=torch.float32, device=x.device) if _want_maxima(dt, C) and lib.pcgan_instnorm_fused(HW) else None
     _L.check(lib.pcgan_instnorm_fwd(_p(x), _p(residual), _p(y), _p(mean), _p(m2), _p(slot), N, C, HW, float(eps), act,
                                     float(slope), dt, _stream()), 'instnorm_fwd')
     if slot is not None:
@@ -596,7 +660,7 @@ def instnorm_bwd(dy, x, y, mean, m2, eps, act, slope):
     fused = bool(lib.pcgan_instnorm_fused(HW))
     psum = torch.empty(N * C, dtype=torch.float32, device=x.device) if fused else None
     ws = None if fused else torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
-    slot = torch.empty(N * C, dtype=torch.float32, device=x.device) if fused and HSPLIT and dt == F32 and x.shape[-1] in (32, 64) else None
+    slot = torch.empty(N * C, dtype=torch.float32, device=x.device) if fused and _want_maxima(dt, C) else None
     _L.check(lib.pcgan_instnorm_bwd(_p(dy), _p(x), _p(y), _p(mean), _p(m2), _p(dx), _p(psum), _p(slot), _p(ws), N, C, HW, float(eps),
                                     act, float(slope), dt, _stream()), 'instnorm_bwd')
     if psum is not None:
@@ -710,9 +774,10 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
                                        float(beta1), float(beta2), float(eps), int(step), _stream()), 'adam_step')
 
 
-def adam_step_dev(param, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1, beta2, eps):
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1, beta2, eps, params=None):
+    """params: the parameter tensors that are views of `param` (their packed copies go out of date; None: everybody's)"""
     _chk(param, grad, exp_avg, exp_avg_sq, lr_dev)
-    invalidate_packed_weights()
+    invalidate_packed_weights(params)
     _L.check(_L.load().pcgan_adam_step_dev(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(),
                                            _p(lr_dev), _vp(step_dev.data_ptr()), float(beta1), float(beta2),
                                            float(eps), _stream()), 'adam_step_dev')

@@ -88,7 +88,7 @@ class FusedAdam(torch.optim.Optimizer):
                 p.grad = gv
         if self.flat.is_cuda:
             ops.adam_step_dev(self.flat, self.gflat, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev,
-                              g['betas'][0], g['betas'][1], g['eps'])
+                              g['betas'][0], g['betas'][1], g['eps'], params=[p for p, _ in self._views])
         else:
             raise RuntimeError('FusedAdam: parameters are on %s; the HIP path needs a GPU (no CPU fallback)'
                                % self.flat.device)

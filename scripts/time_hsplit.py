@@ -14,12 +14,13 @@ lib = L.load()
 st = torch.cuda.current_stream().cuda_stream
 d = ops.make_desc(NB, 256, HH, HH, 256, 3, 3, 1, 1, 1)
 y = torch.empty_like(x)
-amax = torch.zeros(1, device=dev)
+SL = lib.pcgan_absmax_slots(x.numel())
+amax = torch.zeros(SL, device=dev)
 pkf = torch.empty(lib.pcgan_conv2d_hsplit_packed_bytes(ctypes.byref(d), 0), dtype=torch.uint8, device=dev)
 pkb = torch.empty(lib.pcgan_conv2d_hsplit_packed_bytes(ctypes.byref(d), 1), dtype=torch.uint8, device=dev)
 L.check(lib.pcgan_conv2d_hsplit_pack(ctypes.byref(d), 0, w.data_ptr(), pkf.data_ptr(), st), 'pack')
 L.check(lib.pcgan_conv2d_hsplit_pack(ctypes.byref(d), 1, w.data_ptr(), pkb.data_ptr(), st), 'pack')
-L.check(lib.pcgan_absmax(x.data_ptr(), x.numel(), 0, amax.data_ptr(), st), 'absmax')
+L.check(lib.pcgan_absmax(x.data_ptr(), x.numel(), 0, amax.data_ptr(), SL, st), 'absmax')
 def timeit(name, fn, flop=GF):
     for _ in range(5):
         fn()
@@ -32,10 +33,10 @@ def timeit(name, fn, flop=GF):
         e.record(); torch.cuda.synchronize()
         best = min(best, s.elapsed_time(e) / 50)
     print('%-28s %.4f ms  %.1f TFLOP/s' % (name, best, flop / best))
-timeit('absmax (33.5 MB)', lambda: L.check(lib.pcgan_absmax(x.data_ptr(), x.numel(), 0, amax.data_ptr(), st), 'absmax'), 0.0)
-timeit('fwd fp16x3', lambda: L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), x.data_ptr(), amax.data_ptr(), 1, pkf.data_ptr(), None, y.data_ptr(), 0, 0.0, st), 'f'))
-L.check(lib.pcgan_absmax(dy.data_ptr(), dy.numel(), 0, amax.data_ptr(), st), 'absmax')
-timeit('dgrad fp16x3', lambda: L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), dy.data_ptr(), amax.data_ptr(), 1, pkb.data_ptr(), y.data_ptr(), st), 'b'))
+timeit('absmax (33.5 MB)', lambda: L.check(lib.pcgan_absmax(x.data_ptr(), x.numel(), 0, amax.data_ptr(), SL, st), 'absmax'), 0.0)
+timeit('fwd fp16x3', lambda: L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), x.data_ptr(), amax.data_ptr(), SL, pkf.data_ptr(), None, y.data_ptr(), 0, 0.0, st), 'f'))
+L.check(lib.pcgan_absmax(dy.data_ptr(), dy.numel(), 0, amax.data_ptr(), SL, st), 'absmax')
+timeit('dgrad fp16x3', lambda: L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), dy.data_ptr(), amax.data_ptr(), SL, pkb.data_ptr(), y.data_ptr(), st), 'b'))
 for hs, name in ((False, 'bf16x6'), (True, 'fp16x3 via ops (with absmax)')):
     ops.HSPLIT = hs
     cf, cb = {}, {}

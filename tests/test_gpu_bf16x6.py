@@ -73,6 +73,7 @@ def test_host_switch_routes_large_convs_and_follows_the_weights(dev, monkeypatch
     kernel; the packed pieces are re-made when the weights change; small layers keep the fp32 kernel"""
     from pcgan_amd.hip import ops
     monkeypatch.setattr(ops, 'BF16X6', True)
+    monkeypatch.setattr(ops, 'HSPLIT', False)        # (the three-piece bf16 split; the fp16 route has its own tests below)
     g = torch.Generator().manual_seed(3)
     x = torch.randn(4, 128, 64, 64, generator=g).relu_().to(dev)
     w = (torch.randn(128, 128, 3, 3, generator=g) * 0.05).to(dev)
@@ -169,19 +170,20 @@ def _hsplit(dev, N, C, H, W, K, x, w, dgrad):
     st = torch.cuda.current_stream().cuda_stream
     pk = torch.empty(lib.pcgan_conv2d_hsplit_packed_bytes(ctypes.byref(d), pass_), dtype=torch.uint8, device=dev)
     L.check(lib.pcgan_conv2d_hsplit_pack(ctypes.byref(d), pass_, wd.data_ptr(), pk.data_ptr(), st), 'pack')
-    amax = torch.full((1,), float('nan'), device=dev)
-    L.check(lib.pcgan_absmax(xd.data_ptr(), xd.numel(), 0, amax.data_ptr(), st), 'absmax')
-    assert float(amax) == float(x.abs().max())
+    slots = lib.pcgan_absmax_slots(xd.numel())
+    amax = torch.full((slots,), float('nan'), device=dev)
+    L.check(lib.pcgan_absmax(xd.data_ptr(), xd.numel(), 0, amax.data_ptr(), slots, st), 'absmax')
+    assert float(amax.max()) == float(x.abs().max())
     out = torch.full((N, C if dgrad else K, H, W), float('nan'), device=dev)
     if dgrad:
-        L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), xd.data_ptr(), amax.data_ptr(), 1, pk.data_ptr(), out.data_ptr(), st), 'dgrad')
+        L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), xd.data_ptr(), amax.data_ptr(), slots, pk.data_ptr(), out.data_ptr(), st), 'dgrad')
         ops_hs, ops.HSPLIT = ops.HSPLIT, False
         try:
             o32 = ops.conv2d_bwd_data(xd, wd, (H, W), 1, 1, 1)
         finally:
             ops.HSPLIT = ops_hs
     else:
-        L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), xd.data_ptr(), amax.data_ptr(), 1, pk.data_ptr(), None, out.data_ptr(), 0, 0.0, st), 'fwd')
+        L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), xd.data_ptr(), amax.data_ptr(), slots, pk.data_ptr(), None, out.data_ptr(), 0, 0.0, st), 'fwd')
         o32 = ops.conv2d_fwd(xd, wd, None, 1, 1, 1)
     torch.cuda.synchronize()
     return out.cpu(), o32.cpu()
@@ -236,13 +238,14 @@ def test_absmax_unaligned_and_ragged(dev):
     from pcgan_amd.hip import lib as L
     lib = L.load()
     g = torch.Generator().manual_seed(5)
-    base = torch.randn(10007, generator=g).to(dev)
-    out = torch.zeros(1, device=dev)
+    base = torch.randn(3000007, generator=g).to(dev)
     st = torch.cuda.current_stream().cuda_stream
-    for off, n in ((0, 10007), (1, 10006), (3, 5), (2, 4099), (5, 1)):
+    for off, n, slots in ((0, 10007, 1), (1, 10006, 3), (3, 5, 1), (2, 4099, 64), (5, 1, 2), (0, 3000007, None), (3, 2999999, 64)):
         v = base[off:off + n]
-        L.check(lib.pcgan_absmax(v.data_ptr(), n, 0, out.data_ptr(), st), 'absmax')
-        assert float(out) == float(v.abs().max()), (off, n)
+        k = slots or lib.pcgan_absmax_slots(n)
+        out = torch.full((k,), float('nan'), device=dev)
+        L.check(lib.pcgan_absmax(v.data_ptr(), n, 0, out.data_ptr(), k, st), 'absmax')
+        assert float(out.max()) == float(v.abs().max()) and bool((out >= 0).all()), (off, n, k)
 
 
 @pytest.mark.parametrize('N,C,H,W,acc', [

@@ -123,5 +123,8 @@ def test_fullsize_step_vs_oracle(tmp_path, dev, route, monkeypatch):
     assert_close(model.fake_B, oracle.fake_B.detach(), 2e-4, 'fake_B (full-size generator)')
     assert_close(model.rec_A, oracle.rec_A.detach(), 2e-4, 'rec_A (full-size generator)')
     if route == 'split_kernels' and ops.HSPLIT:
-        # 18 convolutions x (2 forward passes + their data gradients)
-        assert ops.AMAX_STATS['attached'] - amax0['attached'] >= 60 and ops.AMAX_STATS['computed'] == amax0['computed'], ops.AMAX_STATS
+        # the norm kernels hand the operand maxima over (18 residual convolutions x 2 generator passes x (forward, data gradient,
+        # 2 operands of the weight gradient) alone are 216); only tensors written by a convolution epilogue or a max-pooling
+        # (the PatchGAN's second layer, AlexNet, the encoder's first block) still cost an absmax pass
+        attached, computed = ops.AMAX_STATS['attached'] - amax0['attached'], ops.AMAX_STATS['computed'] - amax0['computed']
+        assert attached >= 216 and computed <= 24, ops.AMAX_STATS

@@ -281,9 +281,9 @@ def test_step_is_deterministic_with_streams(tmp_path, dev):
     # the generator's conv -> InstanceNorm pairs take their bias gradients from the plane sums the norm backward leaves on
     # its dx (no separate pass over dx): 23 norm sites x 2 generator passes x 3 steps x 2 runs
     assert ops.PLANE_SUM_STATS['fused'] - fused0 >= 2 * 3 * 2 * 20, ops.PLANE_SUM_STATS
-    # (this fixture's planes are smaller than the residual blocks' of the full-size nets: the fp16 route's operand maxima are
-    # covered at size by test_gpu_fullsize.py)
-    assert ops.AMAX_STATS['computed'] == amax0['computed'], ops.AMAX_STATS
+    # operand maxima of the fp16 route: handed over by the norm kernels; an absmax pass only for the few tensors a convolution
+    # epilogue or a max-pooling wrote (at most 20 per step here; counts at full size: test_gpu_fullsize.py)
+    assert ops.AMAX_STATS['computed'] - amax0['computed'] <= 2 * 3 * 20, ops.AMAX_STATS
 
 
 def test_get_current_visuals_matches_reference(tmp_path, dev):
