@@ -66,7 +66,12 @@ enum { BS_FWD_ZERO = 0, BS_FWD_REFLECT = 1, BS_DGRAD_REFLECT = 2, BS_WGRAD = 3 }
 // np = 2: two fp16 pieces of w * pow2_scale(*amax) (the fp16 route)
 __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int M, int C, int T, int nMt, int nst,
                                    int bm_shift, int np, const float* __restrict__ amax = nullptr) {
-    const float wscale = np == 2 ? pow2_scale(max_of_partials(amax, WEIGHT_AMAX_SLOTS)) : 1.f;
+    __shared__ float wscale_s;      // the scale of the fp16 route: one thread reduces the partial maxima for its workgroup
+    if (np == 2) {
+        if (threadIdx.x == 0) wscale_s = pow2_scale(max_of_partials(amax, WEIGHT_AMAX_SLOTS));
+        __syncthreads();
+    }
+    const float wscale = np == 2 ? wscale_s : 1.f;
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nMt * nst * 16 * BM;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_piece; i += (size_t)gridDim.x * blockDim.x) {
@@ -181,7 +186,12 @@ __global__ void bsplit_wgrad_reduce_kernel(const float* __restrict__ part, float
 // row class 2 (row H-2): wf'[2] = wf[2] + wf[0].
 __global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int K, int C, int nMt, int nst, int bm_shift,
                                          int np, const float* __restrict__ amax = nullptr) {
-    const float wscale = np == 2 ? pow2_scale(max_of_partials(amax, WEIGHT_AMAX_SLOTS)) : 1.f;
+    __shared__ float wscale_s;      // the scale of the fp16 route: one thread reduces the partial maxima for its workgroup
+    if (np == 2) {
+        if (threadIdx.x == 0) wscale_s = pow2_scale(max_of_partials(amax, WEIGHT_AMAX_SLOTS));
+        __syncthreads();
+    }
+    const float wscale = np == 2 ? wscale_s : 1.f;
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nMt * nst * 16 * BM, per_phase = (size_t)np * per_piece;
     // (3 row classes x per_piece entries; each entry writes its np pieces)

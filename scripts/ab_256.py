@@ -1,5 +1,5 @@
-"""A/B of the bf16-split residual-convolution kernels (ops.BF16X6) on BASELINE configs 4 and 5 at 256x256: the switch is
-flipped inside ONE process, rounds interleaved (rule 24 of the HIP guide), wall time and host-side issue time per step."""
+"""A/B of the three routes of the fp32 convolutions (fp16 two-piece split = default, three-piece bf16 split, fp32 MFMA) on BASELINE
+configs 4 and 5 at 256x256: the switches are flipped inside ONE process, rounds interleaved (rule 24 of the HIP guide), wall time and host-side issue time per step."""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -37,26 +37,31 @@ common = ['--dataroot', 'synthetic', '--checkpoints_dir', tmp, '--gpu_ids', '0',
 def ab(name, m, batch, nimg):
     dev = torch.device('cuda:0')
     batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-    res = {True: [], False: []}
-    host = {True: [], False: []}
-    for flag in (True, False):          # warm both routes (packed weights, allocator)
-        ops.BF16X6 = flag
+    routes = [('fp16x3 (default)', True, True), ('bf16x6', True, False), ('fp32 MFMA', False, False)]
+    res = {r[0]: [] for r in routes}
+    host = {r[0]: [] for r in routes}
+
+    def select(r):
+        ops.BF16X6, ops.HSPLIT = r[1], r[2]
+    for r in routes:          # warm every route (packed weights, allocator)
+        select(r)
         for _ in range(2):
             m.set_input(batch); m.optimize_parameters()
     torch.cuda.synchronize()
-    for r in range(ROUNDS):
-        for flag in (True, False):
-            ops.BF16X6 = flag
+    for _ in range(ROUNDS):
+        for r in routes:
+            select(r)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(STEPS):
                 m.set_input(batch); m.optimize_parameters()
             t1 = time.perf_counter()
             torch.cuda.synchronize(); t2 = time.perf_counter()
-            res[flag].append((t2 - t0) / STEPS * 1e3); host[flag].append((t1 - t0) / STEPS * 1e3)
-    for flag in (True, False):
-        w = sorted(res[flag]); h = sorted(host[flag])
-        print('%s  BF16X6=%d  wall ms/step min %.1f median %.1f  (%.1f img/s)   host issue ms/step min %.1f median %.1f' % (
-            name, flag, w[0], w[len(w) // 2], nimg / w[len(w) // 2] * 1e3, h[0], h[len(h) // 2]), flush=True)
+            res[r[0]].append((t2 - t0) / STEPS * 1e3); host[r[0]].append((t1 - t0) / STEPS * 1e3)
+    select(routes[0])
+    for r in routes:
+        w = sorted(res[r[0]]); h = sorted(host[r[0]])
+        print('%s  %-17s wall ms/step min %.1f median %.1f  (%.1f img/s)   host issue ms/step min %.1f median %.1f' % (
+            name, r[0], w[0], w[len(w) // 2], nimg / w[len(w) // 2] * 1e3, h[0], h[len(h) // 2]), flush=True)
 
 
 m, opt = parse(['x', '--model', 'wsgan_emb', '--name', 'c4', '--batchSize', '8', '--noisy', 'true', '--bayesian', 'true',
