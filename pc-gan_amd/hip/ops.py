@@ -319,6 +319,62 @@ def _packed_weights(lib, d, pass_, w, cache):
     return buf
 
 
+# Per-shape launch plans: descriptor, workspace size and route of a convolution call are functions of the shape and of the
+# routing switches only -- worked out once (4-5 ctypes queries, ~10 us) and looked up afterwards (the step makes ~330 such calls).
+_PLANS = {}
+
+
+class _Plan(object):
+    __slots__ = ('d', 'dref', 'P', 'Q', 'ws_bytes', 'route', 'pack_pass')
+
+
+def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
+    key = (pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias, BF16X6, HSPLIT, HGEMM, BSPLIT_MIN_PIXELS)
+    p = _PLANS.get(key)
+    if p is not None:
+        return p
+    lib = _L.load()
+    p = _Plan()
+    p.d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
+    p.dref = ctypes.byref(p.d)
+    p.P, p.Q = p.d.P, p.d.Q
+    split = BF16X6 or dt == BF16
+    f16 = HSPLIT and dt == F32
+    if pass_ == _L.PASS_FWD:
+        p.ws_bytes = int(lib.pcgan_conv2d_workspace_bytes(p.dref, _L.PASS_FWD))
+        # (one tile shape, no split-K: only where whole tiles fill the chip, i.e. the residual-block convolutions)
+        bsplit = split and K % 128 == 0 and N * p.P * p.Q >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_supported(p.dref)
+        if bsplit and f16 and lib.pcgan_conv2d_hsplit_supported(p.dref, _L.PASS_FWD):
+            p.route, p.pack_pass = 'hsplit', PASS_FWD_HSPLIT
+        elif bsplit:
+            p.route, p.pack_pass = 'bsplit', PASS_FWD_BSPLIT
+        elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_FWD):
+            p.route, p.pack_pass = 'hgemm', _L.PASS_FWD
+        else:
+            p.route, p.pack_pass = 'packed', _L.PASS_FWD
+    elif pass_ == _L.PASS_BWD_DATA:
+        p.ws_bytes = int(lib.pcgan_conv2d_workspace_bytes(p.dref, _L.PASS_BWD_DATA))
+        bsplit = split and no_bias and C % 128 == 0 and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_dgrad_supported(p.dref)
+        if bsplit and f16 and lib.pcgan_conv2d_hsplit_supported(p.dref, _L.PASS_BWD_DATA):
+            p.route, p.pack_pass = 'hsplit', PASS_BWD_HSPLIT
+        elif bsplit:
+            p.route, p.pack_pass = 'bsplit', PASS_BWD_BSPLIT
+        elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_BWD_DATA):
+            p.route, p.pack_pass = 'hgemm', _L.PASS_BWD_DATA
+        else:
+            p.route, p.pack_pass = 'packed', _L.PASS_BWD_DATA
+    else:
+        p.pack_pass = None
+        if f16 and BF16X6 and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_hsplit_wgrad_supported(p.dref):
+            p.route, p.ws_bytes = 'hsplit', int(lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(p.dref))
+        elif split and K in (128, 256) and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_wgrad_supported(p.dref):
+            p.route, p.ws_bytes = 'bsplit', int(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(p.dref))
+        else:
+            p.route, p.ws_bytes = 'generic', int(lib.pcgan_conv2d_workspace_bytes(p.dref, _L.PASS_BWD_WEIGHT))
+    _PLANS[key] = p
+    return p
+
+
 def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pack_cache=None):
     """pack_cache: a dict owned by the caller (one per weight tensor) that keeps the packed weights between
     calls; None packs inside the call."""
@@ -328,40 +384,34 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
     N, C, H, W = x.shape
     K, C2, R, S = w.shape
     assert C == C2, 'conv2d_fwd: channel mismatch %d vs %d' % (C, C2)
-    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
-    y = torch.empty((N, K, d.P, d.Q), dtype=x.dtype, device=x.device)
-    nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_FWD)
-    ws = _ws(nb, x.device)
+    pl = _plan(_L.PASS_FWD, N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
+    d = pl.dref
+    y = torch.empty((N, K, pl.P, pl.Q), dtype=x.dtype, device=x.device)
+    ws = _ws(pl.ws_bytes, x.device)
     if pack_cache is not None:
-        # (one tile shape, no split-K yet: only where whole 128 x 128 tiles fill the chip, i.e. the residual-block convolutions)
-        bsplit = (BF16X6 or dt == BF16) and K % 128 == 0 and N * d.P * d.Q >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_supported(ctypes.byref(d))
-        hsplit = bsplit and HSPLIT and dt == F32 and lib.pcgan_conv2d_hsplit_supported(ctypes.byref(d), _L.PASS_FWD)
-        pk = _packed_weights(lib, d, PASS_FWD_HSPLIT if hsplit else (PASS_FWD_BSPLIT if bsplit else _L.PASS_FWD), w, pack_cache)
-        xmax = amax_of(x) if hsplit else None
+        pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache)
         ev = None
         if KERNEL_TIMER is not None and KERNEL_TIMER['key'] == (N, C, H, W, K, R, S, stride, pad, pad_mode):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        hgemm = (not bsplit) and HSPLIT and HGEMM and dt == F32 and lib.pcgan_conv2d_hgemm_supported(ctypes.byref(d), _L.PASS_FWD)
-        if hgemm:
+        if pl.route == 'hgemm':
             xmax, wmax = amax_of(x), _weight_amax(lib, w, pack_cache)
-            _L.check(lib.pcgan_conv2d_fwd_packed_hsplit(ctypes.byref(d), _p(x), _p(xmax), xmax.numel(), _p(pk), _p(wmax), _p(bias), _p(y), act,
+            _L.check(lib.pcgan_conv2d_fwd_packed_hsplit(d, _p(x), _p(xmax), xmax.numel(), _p(pk), _p(wmax), _p(bias), _p(y), act,
                                                         float(slope), _p(ws), ws.numel(), _stream()), 'conv2d_fwd_packed_hsplit')
-        elif hsplit:
-            _L.check(lib.pcgan_conv2d_fwd_hsplit(ctypes.byref(d), _p(x), _p(xmax), xmax.numel(), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
+        elif pl.route == 'hsplit':
+            xmax = amax_of(x)
+            _L.check(lib.pcgan_conv2d_fwd_hsplit(d, _p(x), _p(xmax), xmax.numel(), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
                      'conv2d_fwd_hsplit')
-        elif bsplit:
-            _L.check(lib.pcgan_conv2d_fwd_bsplit(ctypes.byref(d), _p(x), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
-                     'conv2d_fwd_bsplit')
+        elif pl.route == 'bsplit':
+            _L.check(lib.pcgan_conv2d_fwd_bsplit(d, _p(x), _p(pk), _p(bias), _p(y), act, float(slope), _stream()), 'conv2d_fwd_bsplit')
         else:
-            _L.check(lib.pcgan_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(pk), _p(bias), _p(y), act, float(slope),
-                                                 _p(ws), ws.numel(), _stream()), 'conv2d_fwd_packed')
+            _L.check(lib.pcgan_conv2d_fwd_packed(d, _p(x), _p(pk), _p(bias), _p(y), act, float(slope), _p(ws), ws.numel(), _stream()),
+                     'conv2d_fwd_packed')
         if ev is not None:
             ev[1].record()
             KERNEL_TIMER['events'].append(ev)
         return y
-    _L.check(lib.pcgan_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), act, float(slope),
-                                  _p(ws), ws.numel(), _stream()), 'conv2d_fwd')
+    _L.check(lib.pcgan_conv2d_fwd(d, _p(x), _p(w), _p(bias), _p(y), act, float(slope), _p(ws), ws.numel(), _stream()), 'conv2d_fwd')
     return y
 
 
@@ -374,33 +424,27 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
     K2, C, R, S = w.shape
     assert K == K2, 'conv2d_bwd_data: channel mismatch'
     H, W = in_hw
-    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
-    assert (d.P, d.Q) == (P, Q), 'conv2d_bwd_data: geometry mismatch %s vs %s' % ((d.P, d.Q), (P, Q))
+    pl = _plan(_L.PASS_BWD_DATA, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, bias is None)
+    d = pl.dref
+    assert (pl.P, pl.Q) == (P, Q), 'conv2d_bwd_data: geometry mismatch %s vs %s' % ((pl.P, pl.Q), (P, Q))
     dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device)
-    nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_BWD_DATA)
-    ws = _ws(nb, dy.device)
+    ws = _ws(pl.ws_bytes, dy.device)
     if pack_cache is not None:
-        if (BF16X6 or dt == BF16) and bias is None and C % 128 == 0 and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_dgrad_supported(ctypes.byref(d)):
-            if HSPLIT and dt == F32 and lib.pcgan_conv2d_hsplit_supported(ctypes.byref(d), _L.PASS_BWD_DATA):
-                pk = _packed_weights(lib, d, PASS_BWD_HSPLIT, w, pack_cache)
-                dmax = amax_of(dy)
-                _L.check(lib.pcgan_conv2d_bwd_data_hsplit(ctypes.byref(d), _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(dx), _stream()),
-                         'conv2d_bwd_data_hsplit')
-                return dx
-            pk = _packed_weights(lib, d, PASS_BWD_BSPLIT, w, pack_cache)
-            _L.check(lib.pcgan_conv2d_bwd_data_bsplit(ctypes.byref(d), _p(dy), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_bsplit')
-            return dx
-        pk = _packed_weights(lib, d, _L.PASS_BWD_DATA, w, pack_cache)
-        if HSPLIT and HGEMM and dt == F32 and lib.pcgan_conv2d_hgemm_supported(ctypes.byref(d), _L.PASS_BWD_DATA):
+        pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache)
+        if pl.route == 'hsplit':
+            dmax = amax_of(dy)
+            _L.check(lib.pcgan_conv2d_bwd_data_hsplit(d, _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_hsplit')
+        elif pl.route == 'bsplit':
+            _L.check(lib.pcgan_conv2d_bwd_data_bsplit(d, _p(dy), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_bsplit')
+        elif pl.route == 'hgemm':
             dmax, wmax = amax_of(dy), _weight_amax(lib, w, pack_cache)
-            _L.check(lib.pcgan_conv2d_bwd_data_packed_hsplit(ctypes.byref(d), _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(wmax), _p(bias), _p(dx),
+            _L.check(lib.pcgan_conv2d_bwd_data_packed_hsplit(d, _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(wmax), _p(bias), _p(dx),
                                                              _p(ws), ws.numel(), _stream()), 'conv2d_bwd_data_packed_hsplit')
-            return dx
-        _L.check(lib.pcgan_conv2d_bwd_data_packed(ctypes.byref(d), _p(dy), _p(pk), _p(bias), _p(dx), _p(ws),
-                                                  ws.numel(), _stream()), 'conv2d_bwd_data_packed')
+        else:
+            _L.check(lib.pcgan_conv2d_bwd_data_packed(d, _p(dy), _p(pk), _p(bias), _p(dx), _p(ws), ws.numel(), _stream()),
+                     'conv2d_bwd_data_packed')
         return dx
-    _L.check(lib.pcgan_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(w), _p(bias), _p(dx), _p(ws), ws.numel(),
-                                       _stream()), 'conv2d_bwd_data')
+    _L.check(lib.pcgan_conv2d_bwd_data(d, _p(dy), _p(w), _p(bias), _p(dx), _p(ws), ws.numel(), _stream()), 'conv2d_bwd_data')
     return dx
 
 
@@ -412,28 +456,24 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=N
     N, C, H, W = x.shape
     K, C2, R, S = w_shape
     assert C == C2 and dy.shape[1] == K
-    d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
-    assert (d.P, d.Q) == tuple(dy.shape[2:]), 'conv2d_bwd_weight: geometry mismatch'
+    pl = _plan(_L.PASS_BWD_WEIGHT, N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
+    d = pl.dref
+    assert (pl.P, pl.Q) == tuple(dy.shape[2:]), 'conv2d_bwd_weight: geometry mismatch'
     if accumulate_into is not None:
         assert tuple(accumulate_into.shape) == (K, C, R, S)
         dw = accumulate_into
     else:
         dw = torch.empty((K, C, R, S), dtype=torch.float32, device=x.device)
-    if (HSPLIT and BF16X6 and dt == F32 and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_hsplit_wgrad_supported(ctypes.byref(d))):
-        ws = _ws(lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
+    acc = int(accumulate_into is not None)
+    ws = _ws(pl.ws_bytes, x.device)
+    if pl.route == 'hsplit':
         xmax, dmax = amax_of(x), amax_of(dy)
-        _L.check(lib.pcgan_conv2d_bwd_weight_hsplit(ctypes.byref(d), _p(x), _p(xmax), xmax.numel(), _p(dy), _p(dmax), dmax.numel(), _p(dw),
-                                                    int(accumulate_into is not None), _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight_hsplit')
-        return dw
-    if (BF16X6 or dt == BF16) and K in (128, 256) and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_wgrad_supported(ctypes.byref(d)):
-        ws = _ws(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
-        _L.check(lib.pcgan_conv2d_bwd_weight_bsplit(ctypes.byref(d), _p(x), _p(dy), _p(dw), int(accumulate_into is not None),
-                                                    _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight_bsplit')
-        return dw
-    nb = lib.pcgan_conv2d_workspace_bytes(ctypes.byref(d), _L.PASS_BWD_WEIGHT)
-    ws = _ws(nb, x.device)
-    _L.check(lib.pcgan_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), int(accumulate_into is not None),
-                                         _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight')
+        _L.check(lib.pcgan_conv2d_bwd_weight_hsplit(d, _p(x), _p(xmax), xmax.numel(), _p(dy), _p(dmax), dmax.numel(), _p(dw), acc,
+                                                    _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight_hsplit')
+    elif pl.route == 'bsplit':
+        _L.check(lib.pcgan_conv2d_bwd_weight_bsplit(d, _p(x), _p(dy), _p(dw), acc, _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight_bsplit')
+    else:
+        _L.check(lib.pcgan_conv2d_bwd_weight(d, _p(x), _p(dy), _p(dw), acc, _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight')
     return dw
 
 
