@@ -825,9 +825,18 @@ __global__ void __launch_bounds__(256) igemm2_kernel(IgemmArgs a) {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int BM, int BP>
+// TA = bf16 (the bf16 path, desc.dtype = PCGAN_BF16): the stored bf16 activations go to LDS as they are, the fp32 weights are rounded
+// to bf16 on their way there, ONE v_mfma_f32_32x32x16_bf16 per block and stage, no scaling -- plain mixed precision as in the
+// one-product form of the residual-convolution kernels (bf16x6_conv.hip).
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
+template <int MODE, int BM, int BP, typename TA>
 __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
     static_assert(MODE == MODE_FWD_ZERO || MODE == MODE_FWD_REFLECT || MODE == MODE_BWD, "forward and plain data gradient");
+    constexpr bool HALF = sizeof(TA) == 2;      // bf16 tensors: one piece, one product
+    constexpr int NP = HALF ? 1 : 2;
+    constexpr unsigned ES = sizeof(TA);
     constexpr int WM = (BM == 128 || (BM == 64 && BP == 64)) ? 2 : 1;
     constexpr int WP = 4 / WM;
     constexpr int WMT = BM / WM, WPT = BP / WP;
@@ -835,8 +844,8 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
     constexpr int KPT = BP / 16;        // channels of its pixel a thread gathers per stage (8 or 4)
     constexpr int ACH = BM * 4 / 256;   // float4 of the weight tile per thread (2 or 1)
     constexpr int TROWS = NTAP_FWD + 1; // + one all-out-of-range row for dead stages
-    __shared__ __attribute__((aligned(16))) f16x8 As[2][2][2 * BM];     // [buffer][piece][k half * BM + row]
-    __shared__ __attribute__((aligned(16))) f16x8 Bs[2][2][2 * BP];     // [buffer][piece][k half * BP + pixel]
+    __shared__ __attribute__((aligned(16))) f16x8 As[2][NP][2 * BM];     // [buffer][piece][k half * BM + row]
+    __shared__ __attribute__((aligned(16))) f16x8 Bs[2][NP][2 * BP];     // [buffer][piece][k half * BP + pixel]
     __shared__ unsigned offT[TROWS][BP];
     __shared__ __attribute__((aligned(16))) float biasS[BM];
 
@@ -855,13 +864,13 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
     const int m0 = mt * BM, p0 = pt * BP;
     const int ph_nS = P.nS;
     const int T = P.nR * ph_nS;
-    const int HgWg4 = a.Hg * a.Wg * 4;
+    const int HgWg4 = a.Hg * a.Wg * (int)ES;     // bytes of one channel plane
     const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(P.A, (unsigned)a.M * (unsigned)Kp * 4u);
 
     // operand scales (largest of the partial maxima the producer left)
-    float sx, sw;
-    {
+    float sx = 1.f, sw = 1.f;
+    if constexpr (!HALF) {
         float m = 0.f;
         for (int i = tid; i < a.x_namax; i += 256) m = fmaxf(m, a.x_amax[i]);
         sx = pow2_scale(block_max(m, biasS));
@@ -882,7 +891,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
             const bool live = pvalid && t < T;
             const unsigned y = axis_entry<MODE>(py, py + a.pad, true, r, a.Hg, a.sl, a.pad);
             const unsigned x = axis_entry<MODE>(px, px + a.pad, true, sxx, a.Wg, a.sl, a.pad);
-            offT[t][pl] = (live && y != 0xffffffffu && x != 0xffffffffu) ? (vbase + y * (unsigned)a.Wg + x) * 4u : OOB;
+            offT[t][pl] = (live && y != 0xffffffffu && x != 0xffffffffu) ? (vbase + y * (unsigned)a.Wg + x) * ES : OOB;
         }
         if (tid < BM) biasS[tid] = (a.bias != nullptr && m0 + tid < a.M) ? a.bias[m0 + tid] : 0.f;
     }
@@ -921,7 +930,10 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j) r.av[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, live ? a_base[j] : OOB, (unsigned)it_k0 * 4u, 0);
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) r.bv[i] = __builtin_amdgcn_raw_buffer_load_b32(rX, vo, so + (unsigned)(i * HgWg4), 0);
+        for (int i = 0; i < KPT; ++i) {
+            if constexpr (HALF) r.bv[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rX, vo, so + (unsigned)(i * HgWg4), 0);
+            else r.bv[i] = __builtin_amdgcn_raw_buffer_load_b32(rX, vo, so + (unsigned)(i * HgWg4), 0);
+        }
         --it_left;
         const int t1 = it_tap + 1;
         const bool wr = t1 == T;
@@ -930,6 +942,24 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
         it_k0 += 16;
     };
     auto stash = [&](const Stage& r, int buf) {
+        if constexpr (HALF) {
+#pragma unroll
+            for (int j = 0; j < ACH; ++j) {
+                const int q = tid + 256 * j;
+                const int row = q >> 2, kc = (q & 3) * 4;
+                bf16x4v h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (__bf16)__uint_as_float(r.av[j][e]);      // weights: round to nearest even
+                *reinterpret_cast<bf16x4v*>(reinterpret_cast<__bf16*>(&As[buf][0][(kc >> 3) * BM + row]) + (kc & 4)) = h;
+            }
+            typedef unsigned short usK __attribute__((ext_vector_type(KPT)));
+            usK v;
+#pragma unroll
+            for (int e = 0; e < KPT; ++e) v[e] = (unsigned short)r.bv[e];                     // stored bf16 patterns as they are
+            if constexpr (KPT == 8) *reinterpret_cast<usK*>(&Bs[buf][0][ksub * BP + pl]) = v;
+            else *reinterpret_cast<usK*>(reinterpret_cast<unsigned short*>(&Bs[buf][0][(ksub >> 1) * BP + pl]) + (ksub & 1) * 4) = v;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int q = tid + 256 * j;
@@ -943,7 +973,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
                 l[e] = y;
             }
             _Float16* d0 = reinterpret_cast<_Float16*>(&As[buf][0][(kc >> 3) * BM + row]) + (kc & 4);
-            _Float16* d1 = reinterpret_cast<_Float16*>(&As[buf][1][(kc >> 3) * BM + row]) + (kc & 4);
+            _Float16* d1 = reinterpret_cast<_Float16*>(&As[buf][NP - 1][(kc >> 3) * BM + row]) + (kc & 4);
             *reinterpret_cast<f16x4*>(d0) = h;
             *reinterpret_cast<f16x4*>(d1) = l;
         }
@@ -957,7 +987,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
                 l[e] = y;
             }
             Bs[buf][0][ksub * BP + pl] = h;
-            Bs[buf][1][ksub * BP + pl] = l;
+            Bs[buf][NP - 1][ksub * BP + pl] = l;
         } else {
             f16x4 h, l;
 #pragma unroll
@@ -968,7 +998,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
                 l[e] = y;
             }
             *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(&Bs[buf][0][(ksub >> 1) * BP + pl]) + (ksub & 1) * 4) = h;
-            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(&Bs[buf][1][(ksub >> 1) * BP + pl]) + (ksub & 1) * 4) = l;
+            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(&Bs[buf][NP - 1][(ksub >> 1) * BP + pl]) + (ksub & 1) * 4) = l;
         }
     };
 
@@ -980,11 +1010,11 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     struct Operands {
-        f16x8 A[2][MI], B[2][PJ];
+        f16x8 A[NP][MI], B[NP][PJ];
     };
     auto fetch = [&](Operands& o, int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) o.A[p][i] = As[buf][p][hi * BM + wm * WMT + i * 32 + lo];
 #pragma unroll
@@ -992,7 +1022,16 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
         }
     };
     auto mma = [&](const Operands& o) {      // (l,h) (h,l) (h,h): smallest terms first
-        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+        if constexpr (HALF) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < PJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, o.A[0][i]), __builtin_bit_cast(bf16x8v, o.B[0][j]),
+                                                                         acc[i][j], 0, 0, 0);
+            return;
+        }
+        constexpr int PA[3] = {NP - 1, 0, 0}, PB[3] = {0, NP - 1, 0};
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -1002,7 +1041,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.A[PA[q]][i], o.B[PB[q]][j], acc[i][j], 0, 0, 0);
     };
     auto interleave = [&]() {
-        constexpr int NM = 3 * MI * PJ, NRD = 2 * (MI + PJ);
+        constexpr int NM = (HALF ? 1 : 3) * MI * PJ, NRD = NP * (MI + PJ);
 #pragma unroll
         for (int q = 0; q < NM; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            // one MFMA
@@ -1061,13 +1100,13 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
                 }
             continue;
         }
-        float* Yp = (float*)a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
+        TA* Yp = (TA*)a.Y + (size_t)n * a.M * YhYw + oy * a.Yw + ox;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m0 + ml < a.M) Yp[(size_t)(m0 + ml) * YhYw] = act_apply((acc[i][j][r] * isx) * isw + biasS[ml], a.act, a.slope);
+                if (m0 + ml < a.M) st1(Yp + (size_t)(m0 + ml) * YhYw, act_apply((acc[i][j][r] * isx) * isw + biasS[ml], a.act, a.slope));
             }
     }
 }
@@ -2460,13 +2499,19 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
             PCGAN_CHECK(a.ph[i].nR * a.ph[i].nS <= (MODE == MODE_BWD_REFLECT ? NTAP_MIR : NTAP_FWD) && (a.ph[i].Kp % 16) == 0,
                         "igemm: chunked K order: bad phase");
     }
-    if (a.hsplit && cg16 && MODE != MODE_BWD_REFLECT && a.dtype == PCGAN_F32 && bm >= 64) {
-        // fp16 two-piece form of the same launch (same tiles, phases, K splits)
+    // bf16 tensors take the one-product bf16 MFMA form of the kernel whenever the shape allows (PCGAN_HGEMM=0: the fp32 MFMA kernels)
+    static const bool hgemm_bf16 = [] { const char* e = getenv("PCGAN_HGEMM"); return !(e && e[0] == '0'); }();
+    const bool half = a.dtype == PCGAN_BF16 && hgemm_bf16;
+    if ((half || (a.hsplit && a.dtype == PCGAN_F32)) && cg16 && MODE != MODE_BWD_REFLECT && bm >= 64) {
+        // fp16 two-piece form (fp32 tensors) / bf16 form (bf16 tensors) of the same launch: same tiles, phases, K splits
         constexpr int HMODE = MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE;
-        if (bm == 128 && bp == 128) hipLaunchKernelGGL((hgemm_kernel<HMODE, 128, 128>), grid2, dim3(256), 0, st, a);
-        else if (bm == 128) hipLaunchKernelGGL((hgemm_kernel<HMODE, 128, 64>), grid2, dim3(256), 0, st, a);
-        else if (bp == 128) hipLaunchKernelGGL((hgemm_kernel<HMODE, 64, 128>), grid2, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((hgemm_kernel<HMODE, 64, 64>), grid2, dim3(256), 0, st, a);
+#define LH(BMV, BPV) do { if (half) hipLaunchKernelGGL((hgemm_kernel<HMODE, BMV, BPV, bf16>), grid2, dim3(256), 0, st, a); \
+                          else hipLaunchKernelGGL((hgemm_kernel<HMODE, BMV, BPV, float>), grid2, dim3(256), 0, st, a); } while (0)
+        if (bm == 128 && bp == 128) LH(128, 128);
+        else if (bm == 128) LH(128, 64);
+        else if (bp == 128) LH(64, 128);
+        else LH(64, 64);
+#undef LH
         PCGAN_LAUNCH_CHECK();
         if (ks > 1 && launch_splitk_reduce(a.dtype, st, part_ws, a.Y, a.bias, ks, out_elems, a.M, a.Yh * a.Yw, a.act, a.slope)) return 2;
         return 0;
