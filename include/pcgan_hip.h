@@ -314,9 +314,11 @@ int pcgan_conv2d_fwd_packed_hsplit(const pcgan_conv_desc* d, const void* x, cons
 int pcgan_conv2d_bwd_data_packed_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax,
                                         const float* packed, const float* w_amax, const float* bias, void* dx, void* ws,
                                         size_t ws_bytes, pcgan_stream_t s);
-/* weight gradient on the same route (256 output channels, width a multiple of 16): both operands are split on their way to LDS, so
- * there is no packed copy of dy; ws (pcgan_conv2d_hsplit_wgrad_workspace_bytes) holds the reflection-padded x and the partial sums of
- * the splits of the pixel reduction, which are combined in a fixed order.  accumulate != 0 adds into dw like pcgan_conv2d_bwd_weight. */
+/* weight gradient on the same route: stride 1 or 2, reflection (stride 1) or zero padding, <= 25 taps, 32..256 output channels,
+ * output width a multiple of 16 -- the residual blocks, the generator's down / up-sampling layers, the PatchGAN's strided layers.  Both
+ * operands are split on their way to LDS, so there is no packed copy of dy; ws (pcgan_conv2d_hsplit_wgrad_workspace_bytes) holds the
+ * padded copy of x and the partial sums of the splits of the pixel reduction, which are combined in a fixed order.  accumulate != 0 adds
+ * into dw like pcgan_conv2d_bwd_weight.  desc.dtype = PCGAN_BF16: the one-product bf16 form (the maxima pointers may be NULL). */
 int pcgan_conv2d_hsplit_wgrad_supported(const pcgan_conv_desc* d);
 size_t pcgan_conv2d_hsplit_wgrad_workspace_bytes(const pcgan_conv_desc* d);
 int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_xamax, const void* dy,

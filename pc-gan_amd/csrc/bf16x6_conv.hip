@@ -129,12 +129,19 @@ __global__ void __launch_bounds__(256) absmax_kernel(const TA* __restrict__ x, s
 // = (c, r, s), reduction = (n, y, x) in stages of 16 consecutive x.  The reflection padding is materialised once (xpad), so that
 // the gather address is separable: column part (c, r, s) in the lane's offset, reduction part (n, y, x) in the scalar offset.
 template <typename TA>
-__global__ void bsplit_pad_reflect_kernel(const TA* __restrict__ x, TA* __restrict__ xp, int H, int W, int pad) {
+__global__ void bsplit_pad_reflect_kernel(const TA* __restrict__ x, TA* __restrict__ xp, int H, int W, int pad, int reflect = 1) {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const TA* src = x + (size_t)blockIdx.y * H * W;
     TA* dst = xp + (size_t)blockIdx.y * Hp * Wp;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hp * Wp; i += gridDim.x * blockDim.x) {
         int y = i / Wp - pad, xx = i % Wp - pad;
+        if (!reflect) {      // zero padding
+            const bool in = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+            TA v;
+            st1(&v, 0.f);
+            dst[i] = in ? src[y * W + xx] : v;
+            continue;
+        }
         y = y < 0 ? -y : (y >= H ? 2 * (H - 1) - y : y);
         xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
         dst[i] = src[y * W + xx];
@@ -910,36 +917,45 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     }
 }
 
-// ---- fp16 two-piece route, weight gradient of the reflection-padded 3x3 convolution ---------------------------------------------
-// dW[k][(c, r, s)] = sum over (n, y, x) of dy[n][k][y][x] * xpad[n][c][y + r][x + s]: rows = output channels (256), columns = (c, tap),
-// reduction over pixels in stages of 16 consecutive x.  Both operands are split on their way to LDS (no packed copy of dy):
-//   A  dy[n][row][y][x0 + 8 half .. + 8): two 16-byte loads per thread, two 16-byte LDS writes (one per piece);
-//   B  xpad[n][c][y + r][x0 + s + 4 q .. + 4): four 4-byte loads (the tap column shifts the alignment), two 8-byte LDS writes;
-// 12 MFMAs and 8 ds_read_b128 per wave and stage; blockIdx.y takes a range of stages and writes a raw partial sum, combined in
-// a fixed order by bsplit_wgrad_reduce_kernel.
+// ---- fp16 two-piece route (fp32 tensors) / bf16 one-product route (bf16 tensors): weight gradient of a padded convolution -----------
+// dW[k][(c, r, s)] = sum over (n, y, x) of dy[n][k][y][x] * xpad[n][c][y * STRIDE + r][x * STRIDE + s]: rows = output channels (one tile of
+// BM = 128 or 256), columns = (c, tap) in tiles of 128, reduction over output pixels in stages of 16 consecutive x (output width a
+// multiple of 16).  xpad = the input with its padding materialised once (reflection or zeros), so that the gather address separates into
+// a column part (lane offset) and a pixel part (scalar offset).  Both operands are split on their way to LDS (no packed copy of dy):
+//   A  dy[n][row][y][x0 + 8 half .. + 8): two 16-byte loads per thread, one 16-byte LDS write per piece;
+//   B  xpad[n][c][y STRIDE + r][(x0 + KB q + j) STRIDE + s], j < KB = 2048 / threads: KB element loads (the tap shifts the alignment), one
+//      8- or 16-byte LDS write per piece;
+// 12 MFMAs (fp16 route; bf16: 4) and 8 (4) ds_read_b128 per wave and stage; blockIdx.y takes a range of stages and writes a raw partial
+// sum, combined in a fixed order by bsplit_wgrad_reduce_kernel.  Replaces autograd's weight gradient of nn.Conv2d /
+// nn.ConvTranspose2d of the generator's down / up-sampling layers, the residual blocks and the PatchGAN (models/networks.py:584-648, 734-763).
 struct HWgradArgs {
-    const float* XP;       // reflection-padded input [N][C][H + 2][W + 2]
-    const float* DY;       // [N][256][H][W]
-    float* part;           // [splits][256][C * 9]
-    int N, C, H, W, nst, nst_split;
+    const void* XP;        // padded input [N][C][Hp][Wp], storage type TA
+    const void* DY;        // [N][K][P][Q]
+    float* part;           // [splits][K][C * T]
+    int N, C, K, P, Q, Hp, Wp, R, S, nst, nst_split;
     unsigned xp_bytes, dy_bytes;
-    const float* x_amax;
+    const float* x_amax;   // fp16 route: partial maxima of |x| and |dy| (device)
     const float* dy_amax;
     int x_namax, dy_namax;
 };
 
-__global__ void __launch_bounds__(512) hsplit_wgrad_kernel(HWgradArgs a) {
-    constexpr int BM = 256, NT = 512;
-    __shared__ __attribute__((aligned(16))) bf16x8 As[2][2][2 * BM];     // [buffer][piece][half * 256 + row]
-    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][2][256];        // [buffer][piece][half * 128 + column]
+template <int BM, int STRIDE, typename TA>
+__global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
+    constexpr int NT = BM * 2;
+    constexpr bool HALF = sizeof(TA) == 2;      // bf16 tensors: one piece, one product, no scaling
+    constexpr int NP = HALF ? 1 : 2;
+    constexpr unsigned ES = sizeof(TA);
+    constexpr int KB = 2048 / NT;               // consecutive output pixels of its column a thread gathers per stage (4 or 8)
+    __shared__ __attribute__((aligned(16))) bf16x8 As[2][NP][2 * BM];     // [buffer][piece][half * BM + row]
+    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][NP][256];        // [buffer][piece][half * 128 + column]
     const int tid = threadIdx.x;
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wp = wave & 1;
-    const int C9 = a.C * 9, Hp = a.H + 2, Wp = a.W + 2, HW = a.H * a.W;
+    const int T = a.R * a.S, CT = a.C * T, PQ = a.P * a.Q;
 
-    float sx, sdy;
-    {
+    float sx = 1.f, sdy = 1.f;
+    if constexpr (!HALF) {
         float m = 0.f, g = 0.f;
         for (int i = tid; i < a.x_namax; i += NT) m = fmaxf(m, a.x_amax[i]);
         for (int i = tid; i < a.dy_namax; i += NT) g = fmaxf(g, a.dy_amax[i]);
@@ -949,77 +965,97 @@ __global__ void __launch_bounds__(512) hsplit_wgrad_kernel(HWgradArgs a) {
         __syncthreads();
     }
 
-    // A loader: row = tid / 2, half = tid % 2;  B loader: column = tid % 128, pixel quad q = tid / 128
+    // A loader: row = tid / 2, half = tid % 2;  B loader: column = tid % 128, pixel group q = tid / 128
     const int arow = tid >> 1, ahalf = tid & 1;
-    const unsigned avo = (unsigned)(arow * HW + ahalf * 8) * 4u;
+    const unsigned avo = arow < a.K ? (unsigned)(arow * PQ + ahalf * 8) * ES : BS_OOB;
     const int bcol = tid & 127, bq = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int col = blockIdx.x * 128 + bcol;
     unsigned bvo = BS_OOB;
-    if (col < C9) {
-        const int c = col / 9, tap = col - c * 9, r = tap / 3, s = tap - r * 3;
-        bvo = (unsigned)((c * Hp + r) * Wp + s) * 4u;
+    if (col < CT) {
+        const int c = col / T, tap = col - c * T, r = tap / a.S, s = tap - r * a.S;
+        bvo = (unsigned)((c * a.Hp + r) * a.Wp + s) * ES;
     }
-    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.DY), 0, (int)a.dy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.XP), 0, (int)a.xp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.DY), 0, (int)a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.XP), 0, (int)a.xp_bytes, 0x00020000);
 
     const int st0 = (int)blockIdx.y * a.nst_split;
     const int nst_here = min(a.nst_split, a.nst - st0);
-    // position of the next stage to LOAD (scalar): image, row, first column
+    // position of the next stage to LOAD (scalar): image, output row, first output column
     int ln, ly, lx;
     {
         const int e0 = st0 * 16;
-        ln = e0 / HW;
-        const int rem = e0 - ln * HW;
-        ly = rem / a.W;
-        lx = rem - ly * a.W;
+        ln = e0 / PQ;
+        const int rem = e0 - ln * PQ;
+        ly = rem / a.Q;
+        lx = rem - ly * a.Q;
     }
     struct Stage {
-        u32x4 a0, a1;      // 8 consecutive dy values of this thread's row
-        unsigned b[4];     // 4 consecutive x values of this thread's column
+        unsigned a[HALF ? 4 : 8];     // 8 consecutive dy values of this thread's row (bf16: packed pairs)
+        unsigned b[KB];               // KB consecutive output pixels of this thread's column
     };
     int lcount = 0;
     auto load = [&](Stage& r) {
         const bool live = lcount < nst_here;
-        const unsigned aso = (unsigned)(ln * BM * HW + ly * a.W + lx) * 4u;
-        const unsigned bso = (unsigned)(((ln * a.C) * Hp + ly) * Wp + lx + bq * 4) * 4u;
+        const unsigned aso = (unsigned)(ln * a.K * PQ + ly * a.Q + lx) * ES;
+        const unsigned bso = (unsigned)(((ln * a.C) * a.Hp + ly * STRIDE) * a.Wp + (lx + bq * KB) * STRIDE) * ES;
         const unsigned av = live ? avo : BS_OOB, bv = live ? bvo : BS_OOB;
-        r.a0 = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso, 0);
-        r.a1 = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso + 16, 0);
+        if constexpr (HALF) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso, 0);
+            r.a[0] = v.x; r.a[1] = v.y; r.a[2] = v.z; r.a[3] = v.w;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r.b[j] = __builtin_amdgcn_raw_buffer_load_b32(rX, bv, bso + j * 4, 0);
+            for (int j = 0; j < KB; ++j) r.b[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rX, bv, bso + (unsigned)(j * STRIDE) * ES, 0);
+        } else {
+            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso, 0), v1 = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso + 16, 0);
+            r.a[0] = v0.x; r.a[1] = v0.y; r.a[2] = v0.z; r.a[3] = v0.w;
+            r.a[4 % (HALF ? 4 : 8)] = v1.x; r.a[5 % (HALF ? 4 : 8)] = v1.y; r.a[6 % (HALF ? 4 : 8)] = v1.z; r.a[7 % (HALF ? 4 : 8)] = v1.w;
+#pragma unroll
+            for (int j = 0; j < KB; ++j) r.b[j] = __builtin_amdgcn_raw_buffer_load_b32(rX, bv, bso + (unsigned)(j * STRIDE) * ES, 0);
+        }
         ++lcount;
         lx += 16;
-        if (lx == a.W) {
+        if (lx == a.Q) {
             lx = 0;
-            if (++ly == a.H) {
+            if (++ly == a.P) {
                 ly = 0;
                 ++ln;
             }
         }
     };
-    typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+    // the thread's KB consecutive k (pixels) of column bcol: k half (bq * KB) / 8, offset (bq * KB) % 8 inside it
+    const int bhalf = (bq * KB) >> 3, bsub = (bq * KB) & 7;
     auto stash = [&](const Stage& r, int buf) {
-        f16x8 h, l;
+        if constexpr (HALF) {      // stored bf16 patterns as they are
+            u32x4 v;
+            v.x = r.a[0]; v.y = r.a[1]; v.z = r.a[2]; v.w = r.a[3];
+            *reinterpret_cast<u32x4*>(&As[buf][0][ahalf * BM + arow]) = v;
+            typedef unsigned short usK __attribute__((ext_vector_type(KB)));
+            usK w;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            _Float16 x, y;
-            split2h(__uint_as_float(j < 4 ? r.a0[j] : r.a1[j - 4]) * sdy, x, y);
-            h[j] = x;
-            l[j] = y;
-        }
-        As[buf][0][ahalf * BM + arow] = __builtin_bit_cast(bf16x8, h);
-        As[buf][1][ahalf * BM + arow] = __builtin_bit_cast(bf16x8, l);
-        hf4 bh, bl;
+            for (int j = 0; j < KB; ++j) w[j] = (unsigned short)r.b[j];
+            *reinterpret_cast<usK*>(reinterpret_cast<unsigned short*>(&Bs[buf][0][bhalf * 128 + bcol]) + bsub) = w;
+        } else {
+            f16x8 h, l;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            _Float16 x, y;
-            split2h(__uint_as_float(r.b[j]) * sx, x, y);
-            bh[j] = x;
-            bl[j] = y;
+            for (int j = 0; j < 8; ++j) {
+                _Float16 x, y;
+                split2h(__uint_as_float(r.a[j % (HALF ? 4 : 8)]) * sdy, x, y);
+                h[j] = x;
+                l[j] = y;
+            }
+            As[buf][0][ahalf * BM + arow] = __builtin_bit_cast(bf16x8, h);
+            As[buf][NP - 1][ahalf * BM + arow] = __builtin_bit_cast(bf16x8, l);
+            typedef _Float16 hfK __attribute__((ext_vector_type(KB)));
+            hfK bh, bl;
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                _Float16 x, y;
+                split2h(__uint_as_float(r.b[j]) * sx, x, y);
+                bh[j] = x;
+                bl[j] = y;
+            }
+            *reinterpret_cast<hfK*>(reinterpret_cast<_Float16*>(&Bs[buf][0][bhalf * 128 + bcol]) + bsub) = bh;
+            *reinterpret_cast<hfK*>(reinterpret_cast<_Float16*>(&Bs[buf][NP - 1][bhalf * 128 + bcol]) + bsub) = bl;
         }
-        // pixels 4 q .. 4 q + 3 of the stage: k half q / 2, offset (q % 2) * 4 inside the column's 8-wide half
-        *reinterpret_cast<hf4*>(reinterpret_cast<_Float16*>(&Bs[buf][0][(bq >> 1) * 128 + bcol]) + (bq & 1) * 4) = bh;
-        *reinterpret_cast<hf4*>(reinterpret_cast<_Float16*>(&Bs[buf][1][(bq >> 1) * 128 + bcol]) + (bq & 1) * 4) = bl;
     };
 
     f32x16 acc[2][2];
@@ -1030,36 +1066,54 @@ __global__ void __launch_bounds__(512) hsplit_wgrad_kernel(HWgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     struct Operands {
-        bf16x8 A[2][2], B[2][2];
+        bf16x8 A[NP][2], B[NP][2];
     };
     auto fetch = [&](Operands& o, int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 o.A[p][i] = As[buf][p][hi * BM + wm * 64 + i * 32 + lo];
                 o.B[p][i] = Bs[buf][p][hi * 128 + wp * 64 + i * 32 + lo];
             }
     };
-    auto mma = [&](const Operands& o) {      // (l,h) (h,l) (h,h)
-        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
+    auto mma = [&](const Operands& o) {
+        if constexpr (HALF) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, o.A[PA[q]][i]),
-                                                                        __builtin_bit_cast(f16x8, o.B[PB[q]][j]), acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.A[0][i], o.B[0][j], acc[i][j], 0, 0, 0);
+        } else {      // (l,h) (h,l) (h,h)
+            constexpr int PA[3] = {NP - 1, 0, 0}, PB[3] = {0, NP - 1, 0};
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, o.A[PA[q]][i]),
+                                                                            __builtin_bit_cast(f16x8, o.B[PB[q]][j]), acc[i][j], 0, 0, 0);
+        }
     };
     auto interleave = [&]() {
+        if constexpr (HALF) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
-            if (q < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // LDS reads of the next stage first
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                   // split arithmetic
-            if (q >= 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // LDS writes
-            if (q >= 4 && q < 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // global loads
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+                if (q < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // LDS reads of the next stage first
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                   // split arithmetic
+                if (q >= 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // LDS writes
+                if (q >= 4 && q < 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // global loads
+            }
         }
     };
 
@@ -1095,18 +1149,17 @@ __global__ void __launch_bounds__(512) hsplit_wgrad_kernel(HWgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int cg = blockIdx.x * 128 + wp * 64 + j * 32 + lo;
-        if (cg >= C9) continue;
-        float* out = a.part + (size_t)blockIdx.y * BM * C9 + cg;
+        if (cg >= CT) continue;
+        float* out = a.part + (size_t)blockIdx.y * a.K * CT + cg;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
-                out[(size_t)m * C9] = (acc[i][j][r] * isx) * isd;
+                if (m < a.K) out[(size_t)m * CT] = (acc[i][j][r] * isx) * isd;
             }
     }
 }
-
 
 static int bsplit_check(const pcgan_conv_desc* d) {
     PCGAN_CHECK(d, "conv2d_bsplit: null descriptor");
@@ -1477,17 +1530,25 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void
     return 0;
 }
 
-// weight gradient on the fp16 route: reflection pad of x (workspace), the kernel above over splits of the pixel reduction, reduce
+// weight gradient on the fp16 route (fp32 tensors) / bf16 route (bf16 tensors): padded copy of x (workspace), the kernel above over
+// splits of the pixel reduction, reduce
 extern "C" int pcgan_conv2d_hsplit_wgrad_supported(const pcgan_conv_desc* d) {
-    return d && d->dtype == PCGAN_F32 && d->stride == 1 && d->pad_mode == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && d->K == 256 &&
-           d->W % 16 == 0 && d->H >= 2 && d->P == d->H && d->Q == d->W && (size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4 < 0x80000000ull &&
-           (size_t)d->N * d->K * d->H * d->W * 4 < 0x80000000ull;
+    if (!d || (d->dtype != PCGAN_F32 && d->dtype != PCGAN_BF16)) return 0;
+    if (d->stride != 1 && d->stride != 2) return 0;
+    if (d->pad_mode == 1 && (d->stride != 1 || d->pad >= d->H || d->pad >= d->W)) return 0;
+    if (d->K > 256 || d->K < 32 || d->R * d->S > 25 || d->Q % 16 != 0 || d->P < 1) return 0;
+    if (d->P != (d->H + 2 * d->pad - d->R) / d->stride + 1 || d->Q != (d->W + 2 * d->pad - d->S) / d->stride + 1) return 0;
+    // the gather reads xpad rows up to (P-1) stride + R - 1 and columns up to (Q-1) stride + S - 1: inside the padded plane by the two lines above
+    return (size_t)d->N * d->C * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * 4 < 0x80000000ull && (size_t)d->N * d->K * d->P * d->Q * 4 < 0x80000000ull &&
+           d->N * d->C <= 65535;
 }
 
+static inline int hsplit_wgrad_bm(const pcgan_conv_desc* d) { return d->K > 128 ? 256 : 128; }
+
 static inline int hsplit_wgrad_splits(const pcgan_conv_desc* d, int* nst_split) {
-    const int nst = d->N * d->H * d->W / 16;
-    const long tiles = (d->C * 9 + 127) / 128;
-    long want = 256 / tiles;          // one round of resident workgroups
+    const int nst = d->N * d->P * d->Q / 16;
+    const long tiles = (d->C * d->R * d->S + 127) / 128;
+    long want = (hsplit_wgrad_bm(d) == 256 ? 256 : 512) / tiles;          // one round of resident workgroups
     if (want < 1) want = 1;
     if (want > nst / 8) want = nst / 8 > 0 ? nst / 8 : 1;
     *nst_split = (int)((nst + want - 1) / want);
@@ -1498,37 +1559,51 @@ extern "C" size_t pcgan_conv2d_hsplit_wgrad_workspace_bytes(const pcgan_conv_des
     if (!pcgan_conv2d_hsplit_wgrad_supported(d)) return 0;
     int per;
     const int splits = hsplit_wgrad_splits(d, &per);
-    return pcgan::align_up((size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4, 256) + (size_t)splits * 256 * d->C * 9 * 4;
+    return pcgan::align_up((size_t)d->N * d->C * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * 4, 256) + (size_t)splits * d->K * d->C * d->R * d->S * 4;
 }
 
 extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_xamax, const void* dy,
                                               const float* dy_amax, int n_dyamax, float* dw, int accumulate, void* ws, size_t ws_bytes,
                                               pcgan_stream_t s) {
     PCGAN_CHECK(pcgan_conv2d_hsplit_wgrad_supported(d), "conv2d_bwd_weight_hsplit: unsupported shape");
-    PCGAN_CHECK(x && dy && dw && x_amax && dy_amax && n_xamax > 0 && n_dyamax > 0 && ws &&
-                    ws_bytes >= pcgan_conv2d_hsplit_wgrad_workspace_bytes(d), "conv2d_bwd_weight_hsplit: null pointer or small workspace");
+    const bool half = d->dtype == PCGAN_BF16;
+    PCGAN_CHECK(x && dy && dw && ws && ws_bytes >= pcgan_conv2d_hsplit_wgrad_workspace_bytes(d), "conv2d_bwd_weight_hsplit: null pointer or small workspace");
+    PCGAN_CHECK(half || (x_amax && dy_amax && n_xamax > 0 && n_dyamax > 0), "conv2d_bwd_weight_hsplit: fp32 tensors need their operand maxima");
     hipStream_t st = (hipStream_t)s;
     int per;
     const int splits = hsplit_wgrad_splits(d, &per);
-    const size_t xpad_bytes = pcgan::align_up((size_t)d->N * d->C * (d->H + 2) * (d->W + 2) * 4, 256);
-    float* xpad = (float*)ws;
+    const int Hp = d->H + 2 * d->pad, Wp = d->W + 2 * d->pad;
+    const size_t es = half ? 2 : 4;
+    const size_t xpad_bytes = pcgan::align_up((size_t)d->N * d->C * Hp * Wp * 4, 256);
+    void* xpad = ws;
     float* part = (float*)((char*)ws + xpad_bytes);
-    PCGAN_CHECK(d->N * d->C <= 65535, "conv2d_bwd_weight_hsplit: more than 65535 planes");
-    const int per_plane = (d->H + 2) * (d->W + 2);
-    hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel<float>, dim3((per_plane + 255) / 256, d->N * d->C), dim3(256), 0, st, (const float*)x, xpad,
-                       d->H, d->W, 1);
-    PCGAN_LAUNCH_CHECK();
+    const void* xin = x;
+    if (d->pad > 0) {
+        const dim3 pgrid((Hp * Wp + 255) / 256, d->N * d->C);
+        if (half) hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel<pcgan::bf16>, pgrid, dim3(256), 0, st, (const pcgan::bf16*)x, (pcgan::bf16*)xpad, d->H, d->W, d->pad, d->pad_mode);
+        else hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel<float>, pgrid, dim3(256), 0, st, (const float*)x, (float*)xpad, d->H, d->W, d->pad, d->pad_mode);
+        PCGAN_LAUNCH_CHECK();
+        xin = xpad;
+    }
     pcgan::HWgradArgs a;
-    a.XP = xpad; a.DY = (const float*)dy; a.part = part;
-    a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W;
-    a.nst = d->N * d->H * d->W / 16;
+    a.XP = xin; a.DY = dy; a.part = part;
+    a.N = d->N; a.C = d->C; a.K = d->K; a.P = d->P; a.Q = d->Q; a.Hp = Hp; a.Wp = Wp; a.R = d->R; a.S = d->S;
+    a.nst = d->N * d->P * d->Q / 16;
     a.nst_split = per;
-    a.xp_bytes = (unsigned)((size_t)d->N * d->C * per_plane * 4);
-    a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->H * d->W * 4);
+    a.xp_bytes = (unsigned)((size_t)d->N * d->C * Hp * Wp * es);
+    a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * es);
     a.x_amax = x_amax; a.x_namax = n_xamax; a.dy_amax = dy_amax; a.dy_namax = n_dyamax;
-    hipLaunchKernelGGL(pcgan::hsplit_wgrad_kernel, dim3((unsigned)((d->C * 9 + 127) / 128), (unsigned)splits), dim3(512), 0, st, a);
+    const dim3 grid((unsigned)((d->C * d->R * d->S + 127) / 128), (unsigned)splits);
+    const int bm = hsplit_wgrad_bm(d);
+#define LWH(BMV, SV) do { if (half) hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, pcgan::bf16>), grid, dim3(BMV * 2), 0, st, a); \
+                          else hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, float>), grid, dim3(BMV * 2), 0, st, a); } while (0)
+    if (bm == 256 && d->stride == 1) LWH(256, 1);
+    else if (bm == 256) LWH(256, 2);
+    else if (d->stride == 1) LWH(128, 1);
+    else LWH(128, 2);
+#undef LWH
     PCGAN_LAUNCH_CHECK();
-    const size_t total = (size_t)d->K * d->C * 9;
+    const size_t total = (size_t)d->K * d->C * d->R * d->S;
     hipLaunchKernelGGL(pcgan::bsplit_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, dw, splits, total, accumulate);
     PCGAN_LAUNCH_CHECK();
     return 0;

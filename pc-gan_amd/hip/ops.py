@@ -365,7 +365,13 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
             p.route, p.pack_pass = 'packed', _L.PASS_BWD_DATA
     else:
         p.pack_pass = None
-        if f16 and BF16X6 and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_hsplit_wgrad_supported(p.dref):
+        # fp16 / bf16 matrix-pipe weight gradient: the residual convolutions from the host's routing threshold on, every other
+        # eligible layer (stride 1 / 2, <= 256 output channels, output width a multiple of 16) from 4096 output pixels on
+        px = N * p.P * p.Q
+        res_like = K == 256 and R == 3 and S == 3 and stride == 1 and pad_mode == 1
+        if (HSPLIT and BF16X6 and lib.pcgan_conv2d_hsplit_wgrad_supported(p.dref)
+                and (px >= BSPLIT_MIN_PIXELS if (res_like or not HGEMM) else px >= min(BSPLIT_MIN_PIXELS, 4096))
+                and (res_like or HGEMM)):
             p.route, p.ws_bytes = 'hsplit', int(lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(p.dref))
         elif split and K in (128, 256) and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_wgrad_supported(p.dref):
             p.route, p.ws_bytes = 'bsplit', int(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(p.dref))
@@ -467,8 +473,13 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=N
     acc = int(accumulate_into is not None)
     ws = _ws(pl.ws_bytes, x.device)
     if pl.route == 'hsplit':
-        xmax, dmax = amax_of(x), amax_of(dy)
-        _L.check(lib.pcgan_conv2d_bwd_weight_hsplit(d, _p(x), _p(xmax), xmax.numel(), _p(dy), _p(dmax), dmax.numel(), _p(dw), acc,
+        if dt == F32:
+            xmax, dmax = amax_of(x), amax_of(dy)
+            nx, nd = xmax.numel(), dmax.numel()
+        else:            # bf16 tensors: one product, no scaling
+            xmax = dmax = None
+            nx = nd = 0
+        _L.check(lib.pcgan_conv2d_bwd_weight_hsplit(d, _p(x), _p(xmax), nx, _p(dy), _p(dmax), nd, _p(dw), acc,
                                                     _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight_hsplit')
     elif pl.route == 'bsplit':
         _L.check(lib.pcgan_conv2d_bwd_weight_bsplit(d, _p(x), _p(dy), _p(dw), acc, _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight_bsplit')

@@ -290,3 +290,54 @@ def test_hsplit_weight_gradient(dev, N, C, H, W, acc, data):
     got = dw.double().cpu() - (base.double() if acc else 0.0)
     e = lambda t: float((t - ref).norm() / ref.norm())
     assert e(got) < (3e-6 if not acc else 1e-5) and (acc or e(got) < 4 * e(dw32.double().cpu()) + 5e-7), (e(got), e(dw32.double().cpu()))
+
+
+@pytest.mark.parametrize('N,C,H,W,K,k,stride,pad,mode', [
+    (2, 64, 32, 32, 128, 3, 2, 1, 0),     # generator down-sampling: 3x3 stride 2, 128-row tile
+    (2, 128, 32, 64, 256, 3, 2, 1, 0),    # 256-row tile, stride 2, non-square
+    (2, 64, 32, 32, 128, 4, 2, 1, 0),     # PatchGAN 4x4 stride 2 (16 taps: 1024 columns)
+    (3, 24, 16, 16, 96, 3, 1, 1, 0),      # ragged rows (96 of 128) and columns (216), zero padding stride 1
+    (1, 16, 18, 34, 32, 5, 1, 1, 0),      # 25 taps, padding smaller than the filter radius (output 16 x 32)
+    (2, 32, 16, 16, 64, 1, 1, 0, 0),      # 1x1, no padding (no padded copy)
+])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_hsplit_weight_gradient_general(dev, N, C, H, W, K, k, stride, pad, mode, dtype):
+    """the matrix-pipe weight gradient on the other layer shapes it takes (fp16 two-piece route / bf16 one-product route) against
+    autograd in float64"""
+    from pcgan_amd.hip import lib as L, ops
+    g = torch.Generator().manual_seed(N * 100 + C + K + k)
+    x = torch.randn(N, C, H, W, generator=g)
+    P, Q = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = torch.randn(N, K, P, Q, generator=g) * 0.01
+    if dtype == 'bf16':
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()       # bf16-valued operands: the products are exact in fp32
+    w = torch.zeros(K, C, k, k, dtype=torch.float64, requires_grad=True)
+    R.conv2d(x.double(), w, None, stride, pad, mode).backward(dy.double())
+    ref = w.grad
+    dt = L.BF16 if dtype == 'bf16' else L.F32
+    d = ops.make_desc(N, C, H, W, K, k, k, stride, pad, mode, dt)
+    lib = L.load()
+    assert lib.pcgan_conv2d_hsplit_wgrad_supported(ctypes.byref(d))
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    xd, dyd = x.to(dev).to(tdt), dy.to(dev).to(tdt)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    dw = torch.full((K, C, k, k), float('nan'), device=dev)
+    if dtype == 'fp32':
+        xmax, dmax = ops.amax_of(xd), ops.amax_of(dyd)
+        args = (xmax.data_ptr(), xmax.numel(), dyd.data_ptr(), dmax.data_ptr(), dmax.numel())
+    else:
+        args = (None, 0, dyd.data_ptr(), None, 0)
+    L.check(lib.pcgan_conv2d_bwd_weight_hsplit(ctypes.byref(d), xd.data_ptr(), args[0], args[1], args[2], args[3], args[4], dw.data_ptr(), 0,
+                                               ws.data_ptr(), ws.numel(), st), 'wgrad')
+    torch.cuda.synchronize()
+    e = float((dw.double().cpu() - ref).norm() / ref.norm())
+    assert e < 3e-6, e
+    # the host routes these shapes there (packed or not: the weight gradient has no packed operand)
+    old = ops.BSPLIT_MIN_PIXELS
+    ops.BSPLIT_MIN_PIXELS = 0
+    try:
+        dw2 = ops.conv2d_bwd_weight(xd, dyd, (K, C, k, k), stride, pad, mode)
+    finally:
+        ops.BSPLIT_MIN_PIXELS = old
+    assert torch.equal(dw2, dw) or float((dw2.double().cpu() - ref).norm() / ref.norm()) < 3e-6
