@@ -369,9 +369,12 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
         # eligible layer (stride 1 / 2, <= 256 output channels, output width a multiple of 16) from 4096 output pixels on
         px = N * p.P * p.Q
         res_like = K == 256 and R == 3 and S == 3 and stride == 1 and pad_mode == 1
+        # (not where the padded copy of x costs more than the matrix pipe saves: measured slower for the 134 MB inputs of the
+        # generator's outermost 64-channel layers, 0.235 vs 0.17 ms, and for 3- / 4-channel images)
+        cheap_pad = C % 16 == 0 and N * C * H * W * 4 <= 80 * 1000 * 1000
         if (HSPLIT and BF16X6 and lib.pcgan_conv2d_hsplit_wgrad_supported(p.dref)
                 and (px >= BSPLIT_MIN_PIXELS if (res_like or not HGEMM) else px >= min(BSPLIT_MIN_PIXELS, 4096))
-                and (res_like or HGEMM)):
+                and (res_like or (HGEMM and cheap_pad))):
             p.route, p.ws_bytes = 'hsplit', int(lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(p.dref))
         elif split and K in (128, 256) and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_wgrad_supported(p.dref):
             p.route, p.ws_bytes = 'bsplit', int(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(p.dref))
