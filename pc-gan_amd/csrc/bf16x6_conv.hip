@@ -946,7 +946,9 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     constexpr int NP = HALF ? 1 : 2;
     constexpr unsigned ES = sizeof(TA);
     constexpr int KB = 2048 / NT;               // consecutive output pixels of its column a thread gathers per stage (4 or 8)
-    __shared__ __attribute__((aligned(16))) bf16x8 As[2][NP][2 * BM];     // [buffer][piece][half * BM + row]
+    // the two k halves of a row are written by neighbouring lanes: 128 bytes of padding between the halves put them on disjoint banks
+    constexpr int AH = BM + 8;
+    __shared__ __attribute__((aligned(16))) bf16x8 As[2][NP][2 * AH];     // [buffer][piece][half * AH + row]
     __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][NP][256];        // [buffer][piece][half * 128 + column]
     const int tid = threadIdx.x;
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
@@ -1027,7 +1029,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
         if constexpr (HALF) {      // stored bf16 patterns as they are
             u32x4 v;
             v.x = r.a[0]; v.y = r.a[1]; v.z = r.a[2]; v.w = r.a[3];
-            *reinterpret_cast<u32x4*>(&As[buf][0][ahalf * BM + arow]) = v;
+            *reinterpret_cast<u32x4*>(&As[buf][0][ahalf * AH + arow]) = v;
             typedef unsigned short usK __attribute__((ext_vector_type(KB)));
             usK w;
 #pragma unroll
@@ -1042,8 +1044,8 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
                 h[j] = x;
                 l[j] = y;
             }
-            As[buf][0][ahalf * BM + arow] = __builtin_bit_cast(bf16x8, h);
-            As[buf][NP - 1][ahalf * BM + arow] = __builtin_bit_cast(bf16x8, l);
+            As[buf][0][ahalf * AH + arow] = __builtin_bit_cast(bf16x8, h);
+            As[buf][NP - 1][ahalf * AH + arow] = __builtin_bit_cast(bf16x8, l);
             typedef _Float16 hfK __attribute__((ext_vector_type(KB)));
             hfK bh, bl;
 #pragma unroll
@@ -1073,7 +1075,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
         for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                o.A[p][i] = As[buf][p][hi * BM + wm * 64 + i * 32 + lo];
+                o.A[p][i] = As[buf][p][hi * AH + wm * 64 + i * 32 + lo];
                 o.B[p][i] = Bs[buf][p][hi * 128 + wp * 64 + i * 32 + lo];
             }
     };
