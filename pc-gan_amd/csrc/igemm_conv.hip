@@ -844,7 +844,9 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
     constexpr int KPT = BP / 16;        // channels of its pixel a thread gathers per stage (8 or 4)
     constexpr int ACH = BM * 4 / 256;   // float4 of the weight tile per thread (2 or 1)
     constexpr int TROWS = NTAP_FWD + 1; // + one all-out-of-range row for dead stages
-    __shared__ __attribute__((aligned(16))) f16x8 As[2][NP][2 * BM];     // [buffer][piece][k half * BM + row]
+    // four neighbouring lanes write the two k halves of one weight row: 128 bytes of padding between the halves put them on disjoint banks
+    constexpr int AH = BM + 8;
+    __shared__ __attribute__((aligned(16))) f16x8 As[2][NP][2 * AH];     // [buffer][piece][k half * AH + row]
     __shared__ __attribute__((aligned(16))) f16x8 Bs[2][NP][2 * BP];     // [buffer][piece][k half * BP + pixel]
     __shared__ unsigned offT[TROWS][BP];
     __shared__ __attribute__((aligned(16))) float biasS[BM];
@@ -950,7 +952,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
                 bf16x4v h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h[e] = (__bf16)__uint_as_float(r.av[j][e]);      // weights: round to nearest even
-                *reinterpret_cast<bf16x4v*>(reinterpret_cast<__bf16*>(&As[buf][0][(kc >> 3) * BM + row]) + (kc & 4)) = h;
+                *reinterpret_cast<bf16x4v*>(reinterpret_cast<__bf16*>(&As[buf][0][(kc >> 3) * AH + row]) + (kc & 4)) = h;
             }
             typedef unsigned short usK __attribute__((ext_vector_type(KPT)));
             usK v;
@@ -972,8 +974,8 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
                 h[e] = x;
                 l[e] = y;
             }
-            _Float16* d0 = reinterpret_cast<_Float16*>(&As[buf][0][(kc >> 3) * BM + row]) + (kc & 4);
-            _Float16* d1 = reinterpret_cast<_Float16*>(&As[buf][NP - 1][(kc >> 3) * BM + row]) + (kc & 4);
+            _Float16* d0 = reinterpret_cast<_Float16*>(&As[buf][0][(kc >> 3) * AH + row]) + (kc & 4);
+            _Float16* d1 = reinterpret_cast<_Float16*>(&As[buf][NP - 1][(kc >> 3) * AH + row]) + (kc & 4);
             *reinterpret_cast<f16x4*>(d0) = h;
             *reinterpret_cast<f16x4*>(d1) = l;
         }
@@ -1016,7 +1018,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) o.A[p][i] = As[buf][p][hi * BM + wm * WMT + i * 32 + lo];
+            for (int i = 0; i < MI; ++i) o.A[p][i] = As[buf][p][hi * AH + wm * WMT + i * 32 + lo];
 #pragma unroll
             for (int j = 0; j < PJ; ++j) o.B[p][j] = Bs[buf][p][hi * BP + wp * WPT + j * 32 + lo];
         }
