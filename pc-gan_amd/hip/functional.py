@@ -107,6 +107,7 @@ class _ConvTranspose2dFn(torch.autograd.Function):
         ctx.cfg = (stride, pad)
         ctx.has_bias = b is not None
         ctx.params = (w, b)
+        ctx.x_amax = x.__dict__.get('_pcgan_amax')     # (see _Conv2dFn)
         ctx.save_for_backward(x, w)
         return y
 
@@ -115,18 +116,33 @@ class _ConvTranspose2dFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, pad = ctx.cfg
         dy = _c(dy)
+        if ctx.x_amax is not None and ctx.x_amax[0] == x._version and '_pcgan_amax' not in x.__dict__:
+            x._pcgan_amax = ctx.x_amax
         dx = dw = db = None
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        wt = _fused_grad_target(ctx.params[0]) if want_w else None
+        bt = _fused_grad_target(ctx.params[1]) if want_b else None
+        if ops.SIDE_STREAM and (not want_w or wt is not None) and (not want_b or bt is not None) and (want_w or want_b):
+            # as in _Conv2dFn: both go straight into the optimizer's gradient buffer, on the parameter-gradient stream (all
+            # accumulations into that buffer are issued in order on the one stream)
+            with ops.fork_side(x, dy):
+                if want_w:
+                    ops.conv2d_bwd_weight(dy, x, tuple(w.shape), stride, pad, 0, accumulate_into=wt)
+                if want_b:
+                    ops.channel_sum(dy, accumulate_into=bt)
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv2d_fwd(dy, w, None, stride, pad, 0, pack_cache=ctx.pack)
+            return dx, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_fwd(dy, w, None, stride, pad, 0, pack_cache=ctx.pack)
-        if ctx.needs_input_grad[1]:
-            tgt = _fused_grad_target(ctx.params[0])
-            dw = ops.conv2d_bwd_weight(dy, x, tuple(w.shape), stride, pad, 0, accumulate_into=tgt)
-            if tgt is not None:
+        if want_w:
+            dw = ops.conv2d_bwd_weight(dy, x, tuple(w.shape), stride, pad, 0, accumulate_into=wt)
+            if wt is not None:
                 dw = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            tgt = _fused_grad_target(ctx.params[1])
-            db = ops.channel_sum(dy, accumulate_into=tgt)
-            if tgt is not None:
+        if want_b:
+            db = ops.channel_sum(dy, accumulate_into=bt)
+            if bt is not None:
                 db = None
         return dx, dw, db, None, None, None
 
