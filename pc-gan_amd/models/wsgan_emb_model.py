@@ -388,8 +388,24 @@ class WSGANEmbModel(BaseModel):
 
     def optimize_parameters(self):
         self.forward()
-        self.update_G()
-        self.update_D()
+        if not parallel.is_distributed():
+            self.update_G()
+            self.update_D()
+            return
+        # data parallel: the generator's gradient all-reduce is launched after backward_G and runs under backward_D, which neither
+        # reads the generator's weights (fake_B is detached and was computed in forward()) nor touches its gradients; both optimizer
+        # steps follow -- same arithmetic as update_G(); update_D() (reference models/wsgan_emb_model.py:451-461, 478-484)
+        self.set_requires_grad(self.netD, False)
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        finish_G = parallel.sync_gradients(self.optimizer_G, async_op=True)
+        self.set_requires_grad(self.netD, True)
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        finish_G()
+        self.optimizer_G.step()
+        parallel.sync_gradients(self.optimizer_D)
+        self.optimizer_D.step()
 
     def get_current_visuals(self):
         self._join_rec()
