@@ -367,6 +367,88 @@ def golden_siamese(rn, outdir):
     print('siamese_step.npz: %d arrays, losses %s' % (len(out), [float(out['it%d/loss' % i]) for i in range(3)]))
 
 
+# Elo-trainer variants (reference siamese.py:577-669): name -> (noisy, rsample, lb_or_mc, bnn_dropout, T_train, M)
+SIAMESE_VARIANTS = {
+    'bayesian': (False, True, 'lb', 0.2, 2, 1),
+    'noisy_std': (True, False, 'lb', 0.0, 1, 1),
+    'noisy_mc': (True, True, 'mc', 0.0, 1, 3),
+    'noisy_lb': (True, True, 'lb', 0.0, 1, 2),
+    'bayesian_noisy_lb': (True, True, 'lb', 0.2, 2, 2),
+    'bayesian_noisy_std': (True, False, 'lb', 0.2, 2, 1),
+}
+SIAMESE_LR_SIGMA = 1e-4        # (the reference's default 2e-7 would leave cnn_logvar unmoved in two steps)
+
+
+def golden_siamese_variants(rn, outdir):
+    """The reparameterised / MC-dropout variants of the Elo trainer's iteration (reference siamese.py:577-669: --noisy with
+    --rsample mc / lb or the score / score_std form, --bayesian with T_train passes): two iterations each of the reference's
+    SiameseNetwork with its own `reparameterize` (util/util.py:130-133), the branch bodies applied as in golden_siamese (siamese.py
+    cannot be imported); a second Adam on `cnn_logvar` (siamese.py:552-553, 667-668).  torch.manual_seed(1000 + it) before every
+    iteration: the oracle draws the same dropout masks and eps under the same seed."""
+    import util.util as ref_util
+    lut = torch.tensor([0.0, 0.5, 1.0])
+
+    def criterion(prob, label):
+        target = lut[label].reshape(prob.size(0), 1, 1, 1).expand(prob.size(0), 1, prob.size(2), prob.size(3))
+        return -(target * torch.log(prob + 1e-20) + (1 - target) * torch.log(1 - prob + 1e-20)).mean()
+
+    out = {}
+    for name, (noisy, rsample, lb_or_mc, p_drop, T, M) in SIAMESE_VARIANTS.items():
+        base = rn.ResNetFeature(3, 'resnet18', dropout=p_drop)
+        net = rn.SiameseNetwork(base, pooling='avg', cnn_dim=[32, 1], cnn_pad=1, cnn_relu_slope=0.7, fc_dim=[], noisy=noisy,
+                                drop_layer=rn.get_dropout_layer(p_drop), rsample=rsample)
+        net.load_state_dict(W.fill_state_dict(net.state_dict(), 61))
+        params = list(net.base.parameters()) + list(net.cnn.parameters())
+        optimizer = torch.optim.Adam(params, lr=2e-4)
+        optimizer_sigma = torch.optim.Adam(net.cnn_logvar.parameters(), lr=SIAMESE_LR_SIGMA) if noisy else None
+        bayesian = p_drop > 0
+        for it in range(2):
+            img0 = W.seeded_tensor((4, 3, 64, 64), 900 + it)
+            img1 = W.seeded_tensor((4, 3, 64, 64), 950 + it)
+            label = torch.tensor([[0, 2, 1, 2], [2, 2, 0, 1]][it])
+            torch.manual_seed(1000 + it)
+            optimizer.zero_grad()
+            if noisy:
+                optimizer_sigma.zero_grad()
+            TT = T if bayesian else 1
+            loss = 0.0
+            for t in range(TT):
+                if noisy and rsample:
+                    y1, y2, logvar1, logvar2 = net(img0, img1)
+                    if lb_or_mc == 'mc':
+                        prob_ = 0.0
+                        for m in range(M):
+                            score = ref_util.reparameterize(y1, logvar1) - ref_util.reparameterize(y2, logvar2)
+                            prob_ = prob_ + 1. / M * torch.sigmoid(score)
+                        loss = loss + 1. / TT * criterion(prob_, label)
+                    else:
+                        for m in range(M):
+                            score = ref_util.reparameterize(y1, logvar1) - ref_util.reparameterize(y2, logvar2)
+                            prob_ = torch.sigmoid(score)
+                            loss = loss + 1. / (TT * M) * criterion(prob_, label)
+                elif noisy:
+                    y1, y2, score, score_std = net(img0, img1)
+                    prob_ = torch.sigmoid(score / (score_std + 1e-20))
+                    loss = loss + 1. / TT * criterion(prob_, label)
+                else:
+                    y1, y2, score = net(img0, img1)
+                    prob_ = torch.sigmoid(score)
+                    loss = loss + 1. / TT * criterion(prob_, label)
+            loss.backward()
+            q = '%s/it%d' % (name, it)
+            out[q + '/loss'] = np.array(float(loss))
+            out[q + '/f1'], out[q + '/prob'] = t2n(y1), t2n(prob_)        # of the last pass
+            grads_summary([(k, v.grad) for k, v in net.named_parameters()], q + '/grad', out, False)
+            optimizer.step()
+            if noisy:
+                optimizer_sigma.step()
+            for k, v in net.state_dict().items():
+                a = t2n(v).astype(np.float64)
+                out['%s/after/%s' % (q, k)] = np.array([a.sum(), np.abs(a).sum()])
+        print('siamese variant %-20s losses %s' % (name, [float(out['%s/it%d/loss' % (name, i)]) for i in range(2)]))
+    np.savez_compressed(os.path.join(outdir, 'siamese_variants.npz'), **out)
+
+
 def golden_ints(outdir):
     """Integer-exact helpers."""
     from util import util as ref_util
@@ -434,5 +516,7 @@ if __name__ == '__main__':
         golden_cycle_step(rn, a.out)
     if a.only in ('', 'siamese'):
         golden_siamese(rn, a.out)
+    if a.only in ('', 'siamese_variants'):
+        golden_siamese_variants(rn, a.out)
     if a.only in ('', 'fid'):
         golden_fid(a.out)

@@ -76,6 +76,12 @@ def _randn_like(t):
     return torch.randn_like(t)
 
 
+def reparameterize(mu, logvar):
+    """reference util/util.py:130-133: mu + eps * exp(logvar / 2), one randn_like per call"""
+    std = torch.exp(0.5 * logvar)
+    return mu + _randn_like(std) * std
+
+
 def resample(mu=0., var=0.):
     """reference util/util.py:136-139 (tiny (B,1,1,1) tensors: host-side scalar plumbing)."""
     std = torch.sqrt(var)

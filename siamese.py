@@ -6,8 +6,10 @@ label (0: first < second, 1: draw, 2: first > second) with the draw-aware binary
 Adam; writes `init_net.pth`, `latest_net.pth`, `<epoch>_net.pth` and `loss.txt` under <checkpoint_dir>/<name>/ -- the
 `<epoch>_net.pth` file is what `train.py --model wsgan_emb --pretrained_model_path_E` loads.
 
-Same flag names and defaults as the reference for everything implemented; the deterministic recipe only (`--noisy false
---bayesian false`, no `fc_dim`, no `use_cxn`); image augmentation is resize + random crop + flip (torchvision's affine /
+Same flag names and defaults as the reference for everything implemented: the deterministic recipe, MC dropout (`--bayesian true
+--bnn_dropout p --T_train T`) and the noisy-rating variants (`--noisy true` with `--rsample`, `--lb_or_mc`, `--M`, a second Adam on
+the log-variance head with `--lr_sigma` and its epoch schedule); no `fc_dim`, no `use_cxn`, no `--finetune_fc_only`; image
+augmentation is resize + random crop + flip (torchvision's affine /
 colour jitter are not available here); `--dataroot synthetic` trains on seeded synthetic pairs whose label is decided
 by a hidden per-image score, so the loss must fall.
 
@@ -25,7 +27,7 @@ from pcgan_amd.data.base_dataset import get_transform
 from pcgan_amd.hip import parallel
 from pcgan_amd.hip.optim import FusedAdam
 from pcgan_amd.models import networks
-from pcgan_amd.util.util import str2bool
+from pcgan_amd.util.util import reparameterize, str2bool
 
 
 def build_parser():
@@ -69,6 +71,12 @@ def build_parser():
     add('--noisy', type=str2bool, default=False)
     add('--bayesian', type=str2bool, default=False)
     add('--bnn_dropout', type=float, default=0.)
+    add('--M', type=int, default=1, help='number of reparameterization samples')
+    add('--T_train', type=int, default=1, help='MC-dropout passes per iteration (--bayesian)')
+    add('--lr_sigma', type=float, default=0.0000002, help='learning rate of the log-variance head (--noisy)')
+    add('--noisy_sigma_updating_epochs', nargs='*', type=int, default=[0, 1], help='starts ends (-1: --num_epochs)')
+    add('--rsample', type=str2bool, default=True)
+    add('--lb_or_mc', type=str, default='lb', choices=['lb', 'mc'])
     add('--seed', type=int, default=0)
     add('--max_dataset_size', type=int, default=1 << 30)
     return ap
@@ -123,12 +131,12 @@ def init_like_reference(net):
 def build_net(opt, device):
     if 'resnet' not in opt.which_model:
         raise NotImplementedError('pcgan_amd: rating trunk [%s] is outside the MI355X hot path' % opt.which_model)
-    if opt.noisy or opt.bayesian or opt.finetune_fc_only:
-        raise NotImplementedError('pcgan_amd: siamese.py implements the deterministic Elo recipe (no --noisy / --bayesian / '
-                                  '--finetune_fc_only)')
+    if opt.finetune_fc_only:
+        raise NotImplementedError('pcgan_amd: siamese.py --finetune_fc_only is outside the MI355X hot path')
     base = networks.ResNetFeature(input_nc=3, which_model=opt.which_model, dropout=opt.bnn_dropout)
     net = networks.SiameseNetwork(base, pooling=opt.pooling, cnn_dim=[] if opt.no_cnn else opt.cnn_dim, cnn_pad=opt.cnn_pad,
-                                  cnn_relu_slope=opt.cnn_relu_slope, fc_dim=opt.fc_dim, use_cxn=opt.use_cxn)
+                                  cnn_relu_slope=opt.cnn_relu_slope, fc_dim=opt.fc_dim, use_cxn=opt.use_cxn, noisy=opt.noisy,
+                                  drop_layer=networks.get_dropout_layer(dropout=opt.bnn_dropout), rsample=opt.rsample)
     save_dir = os.path.join(opt.checkpoint_dir, opt.name)
     if opt.continue_train:
         net.load_state_dict(torch.load(os.path.join(save_dir, '%s_net.pth' % opt.which_epoch), map_location='cpu'), strict=False)
@@ -137,6 +145,54 @@ def build_net(opt, device):
         if opt.pretrained_model_path:
             net.load_pretrained(opt.pretrained_model_path)
     return net.to(device)
+
+
+MAGIC_EPS = 1e-20
+
+
+def iteration_loss(opt, net, criterion, img0, img1, label):
+    """loss and probabilities of one training iteration (reference siamese.py:596-665): the deterministic recipe, T_train
+    MC-dropout passes (--bayesian), and with --noisy either the score / score_std form or M reparameterised ratings per pass,
+    combined as a Monte-Carlo estimate of the probability (`mc`) or of the loss (`lb`)."""
+    T = opt.T_train if opt.bayesian else 1
+    loss, prob = 0.0, None
+    for _ in range(T):
+        if opt.noisy and opt.rsample:
+            y1, y2, logvar1, logvar2 = net(img0, img1)
+            if opt.lb_or_mc == 'mc':
+                prob = 0.0
+                for _m in range(opt.M):
+                    score = reparameterize(y1, logvar1) - reparameterize(y2, logvar2)
+                    prob = prob + 1. / opt.M * torch.sigmoid(score)
+                loss = loss + 1. / T * criterion(prob, label)
+            else:
+                for _m in range(opt.M):
+                    score = reparameterize(y1, logvar1) - reparameterize(y2, logvar2)
+                    prob = torch.sigmoid(score)
+                    loss = loss + 1. / (T * opt.M) * criterion(prob, label)
+        elif opt.noisy:
+            _, _, score, score_std = net(img0, img1)
+            prob = torch.sigmoid(score / (score_std + MAGIC_EPS))
+            loss = loss + 1. / T * criterion(prob, label)
+        else:
+            _, _, score = net(img0, img1)
+            prob = torch.sigmoid(score)
+            loss = loss + 1. / T * criterion(prob, label)
+    return loss, prob
+
+
+def sigma_lr_rule(opt):
+    """LambdaLR factor of the log-variance head's optimizer (reference siamese.py:555-565): lr_sigma until the first epoch of
+    --noisy_sigma_updating_epochs, ramped linearly to --lr at the second"""
+    e0, e1 = [opt.num_epochs if e == -1 else e for e in opt.noisy_sigma_updating_epochs]
+
+    def rule(epoch):
+        if epoch + opt.epoch_count <= e0:
+            return 1.0
+        if epoch + opt.epoch_count >= e1:
+            return 1.0 * opt.lr / opt.lr_sigma
+        return 1.0 * opt.lr / opt.lr_sigma * (float(epoch + opt.epoch_count) - e0) / float(e1 - e0)
+    return rule
 
 
 def predictions(prob, draw_thresh):
@@ -164,6 +220,10 @@ def train(opt):
     criterion = networks.BinaryNLLLoss()
     params = list(net.base.parameters()) + (list(net.cnn.parameters()) if net.cnn is not None else [])
     optimizer = FusedAdam(params, lr=opt.lr)                                   # optim.Adam(param, lr) of the reference
+    optimizer_sigma = scheduler_sigma = None
+    if opt.noisy:                                                              # siamese.py:552-566
+        optimizer_sigma = FusedAdam(net.cnn_logvar.parameters(), lr=opt.lr_sigma)
+        scheduler_sigma = torch.optim.lr_scheduler.LambdaLR(optimizer_sigma, lr_lambda=sigma_lr_rule(opt))
     data = PairDataset(opt, opt.dataroot, opt.datafile)
     loader = torch.utils.data.DataLoader(data, batch_size=opt.batch_size, shuffle=not opt.serial_batches,
                                          num_workers=0 if data.synthetic else opt.num_workers)
@@ -177,12 +237,15 @@ def train(opt):
             img0, img1, label = (parallel.shard_batch(t, rank, world).to(device) for t in (img0, img1, label))
             total += 1
             optimizer.zero_grad()
-            _, _, score = net(img0, img1)
-            prob = torch.sigmoid(score)
-            loss = criterion(prob, label)
+            if optimizer_sigma is not None:
+                optimizer_sigma.zero_grad()
+            loss, prob = iteration_loss(opt, net, criterion, img0, img1, label)
             loss.backward()
             parallel.sync_gradients(optimizer)
             optimizer.step()
+            if optimizer_sigma is not None:
+                parallel.sync_gradients(optimizer_sigma)
+                optimizer_sigma.step()
             wrong += int((predictions(prob, opt.draw_prob_thresh) != label).sum())
             seen += int(label.numel())
             if total % opt.print_freq == 0:
@@ -194,6 +257,11 @@ def train(opt):
                 save(net, os.path.join(save_dir, 'latest_net.pth'))
         if rank == 0:
             print('epoch %02d: train accuracy %.4f' % (epoch, 1.0 - wrong / max(seen, 1)))
+        if scheduler_sigma is not None:
+            scheduler_sigma.step()
+            if rank == 0:
+                print('--->> lr      : %g' % optimizer.param_groups[0]['lr'])
+                print('--->> lr_sigma: %g' % optimizer_sigma.param_groups[0]['lr'])
         save(net, os.path.join(save_dir, 'latest_net.pth'))
         if epoch % opt.save_epoch_freq == 0:
             save(net, os.path.join(save_dir, '%d_net.pth' % epoch))

@@ -69,3 +69,85 @@ def test_siamese_script_trains_on_synthetic_pairs(tmp_path, dev):
     from pcgan_amd.models import networks
     e = networks.define_E('resnet18', 3, 'normal', 'avg', [32, 1], 1, 0.7)
     e.load_pretrained(os.path.join(str(tmp_path), 'elo', '2_net.pth'))
+
+
+@pytest.mark.parametrize('name', ['bayesian', 'noisy_std', 'noisy_mc', 'noisy_lb', 'bayesian_noisy_lb', 'bayesian_noisy_std'])
+def test_siamese_variant_iteration_matches_reference_and_oracle(dev, name):
+    """the trainer's reparameterised / MC-dropout iterations (siamese.iteration_loss, second Adam on cnn_logvar) against the
+    reference's golden vectors and the oracle; the oracle's dropout masks and eps draws are replayed on the GPU"""
+    sys.path.insert(0, ROOT)
+    import siamese
+    from oracle import networks_ref as N
+    from pcgan_amd.hip import nn as hnn
+    from pcgan_amd.hip.optim import FusedAdam
+    from pcgan_amd.models import networks
+    from pcgan_amd.util import util as hutil
+    from test_siamese_oracle_golden import VARIANTS, LR_SIGMA, build_variant_oracle
+    noisy, rsample, lb_or_mc, p_drop, T, M = VARIANTS[name]
+    gold = np.load(os.path.join(GOLD, 'siamese_variants.npz'))
+    opt = siamese.build_parser().parse_args(['--dataroot', 'synthetic', '--noisy', str(noisy), '--bayesian', str(p_drop > 0), '--bnn_dropout', str(p_drop),
+                                             '--T_train', str(T), '--M', str(M), '--rsample', str(rsample), '--lb_or_mc', lb_or_mc,
+                                             '--lr_sigma', str(LR_SIGMA)])
+    net = networks.SiameseNetwork(networks.ResNetFeature(3, 'resnet18', dropout=p_drop), pooling='avg', cnn_dim=[32, 1], cnn_pad=1, cnn_relu_slope=0.7,
+                                  noisy=noisy, drop_layer=networks.get_dropout_layer(p_drop), rsample=rsample)
+    net.load_state_dict(W.fill_state_dict({k: v.cpu() for k, v in net.state_dict().items()}, 61))
+    net.to(dev)
+    crit = networks.BinaryNLLLoss()
+    optimizer = FusedAdam(list(net.base.parameters()) + list(net.cnn.parameters()), lr=2e-4)
+    optimizer_sigma = FusedAdam(net.cnn_logvar.parameters(), lr=LR_SIGMA) if noisy else None
+    oracle = build_variant_oracle(name)
+    for it in range(2):
+        img0, img1, label = siamese_inputs(it)
+        # align the weights of the two sides (Adam turns rounding noise of near-zero gradients into +-lr moves)
+        if it > 0:
+            net.load_state_dict({k: v.to(dev) for k, v in oracle.net.state_dict().items()})
+        N.Dropout2dRec.record = []
+        oracle.draws = []
+        torch.manual_seed(1000 + it)
+        oracle.step(img0, img1, label)
+        masks, N.Dropout2dRec.record = N.Dropout2dRec.record, None
+        hnn.Dropout2d.mask_source = iter(masks)
+        hutil.inject_noise(iter(oracle.draws))
+        try:
+            optimizer.zero_grad()
+            if noisy:
+                optimizer_sigma.zero_grad()
+            loss, prob = siamese.iteration_loss(opt, net, crit, img0.to(dev), img1.to(dev), label.to(dev))
+            loss.backward()
+            assert next(hnn.Dropout2d.mask_source, None) is None, 'the HIP iteration consumed fewer dropout masks than the oracle drew'
+            assert next(iter(hutil._inject['eps']), None) is None, 'the HIP iteration drew fewer eps than the oracle'
+        finally:
+            hnn.Dropout2d.mask_source = None
+            hutil.inject_noise(None)
+        q = '%s/it%d' % (name, it)
+        assert abs(float(loss) - oracle.loss.item()) <= 2e-4 * max(1.0, abs(oracle.loss.item())), (q, float(loss), oracle.loss.item())
+        assert_close(prob, oracle.prob.detach(), 5e-4, q + ' probability vs oracle')
+        if it == 0:
+            assert abs(float(loss) - float(gold[q + '/loss'])) <= 2e-4, (q, float(loss), float(gold[q + '/loss']))
+            assert_close(prob, torch.from_numpy(gold[q + '/prob']), 5e-4, q + ' probability vs reference')
+        for k, g in oracle.grads.items():
+            hg = dict(net.named_parameters())[k].grad
+            scale = float(g.norm())
+            if scale < 1e-7:
+                continue
+            e = float((hg.double().cpu() - g.double()).norm()) / scale
+            assert e <= 5e-2, '%s grad %s: relative L2 against the oracle %.3e' % (q, k, e)
+        optimizer.step()
+        if noisy:
+            optimizer_sigma.step()
+
+
+def test_siamese_script_trains_noisy_bayesian(tmp_path, dev):
+    sys.path.insert(0, ROOT)
+    import siamese
+    opt = siamese.build_parser().parse_args(
+        ['--dataroot', 'synthetic', '--name', 'elo_nb', '--checkpoint_dir', str(tmp_path), '--batch_size', '16',
+         '--num_epochs', '2', '--fineSize', '64', '--max_dataset_size', '128', '--print_freq', '1', '--save_epoch_freq', '1',
+         '--pretrained_model_path', '', '--lr', '0.001', '--noisy', 'true', '--bayesian', 'true', '--bnn_dropout', '0.1',
+         '--T_train', '2', '--M', '2', '--lb_or_mc', 'mc', '--lr_sigma', '1e-5', '--noisy_sigma_updating_epochs', '0', '2'])
+    history = siamese.train(opt)
+    assert len(history) == 16 and all(np.isfinite(history))
+    # the checkpoint carries the log-variance head: it is what wsgan_emb --noisy true loads
+    from pcgan_amd.models import networks
+    e = networks.define_E('resnet18', 3, 'normal', 'avg', [32, 1], 1, 0.7, noisy=True, bnn_dropout=0.1)
+    e.load_pretrained(os.path.join(str(tmp_path), 'elo_nb', '2_net.pth'))
