@@ -1,0 +1,94 @@
+"""hipGraph replay of a frozen network's forward under no_grad.
+
+The step calls the frozen Elo encoder on the two real image sets without building an autograd graph -- twice per step by default, 20
+times per step with MC dropout (config 4: T = 10 passes per image set at batch 8).  Alone, such a pass is bound by the host's launch
+rate, not by the GPU: 1.40 ms eager against 0.76 ms as a graph at batch 8, 3.49 against 1.42 ms at batch 32
+(`scripts/graph_e_probe.py`).  `GraphedNoGrad(fn)` runs fn eagerly for its first calls of an input shape (allocator, packed weights,
+launch plans settle), captures the next call with torch.cuda.graph -- the captured launch sequence is the eager one, kernel for
+kernel, including the in-place BatchNorm running-statistics updates of a train-mode net -- and replays it afterwards.  The C-ABI
+makes that possible: no hidden allocation, no host synchronisation, device-side scalars.
+
+Dropout2d inside a captured net: the keep flags of every site are slices of ONE static buffer that is refilled by a single
+`bernoulli_` launch in front of each replay (independent draws per pass, as in eager mode).
+
+Not used while autograd is recording, while a parity test injects masks (`Dropout2d.mask_source`), or with PCGAN_GRAPH_NOGRAD=0.
+A capture is tied to the packed-weight epoch: anything that re-packs every weight (load_networks, broadcast) starts over with
+eager calls."""
+import os
+
+import torch
+
+from . import nn as hnn
+from . import ops
+
+ENABLED = os.environ.get('PCGAN_GRAPH_NOGRAD', '1') != '0'
+STATS = {'eager': 0, 'captured': 0, 'replayed': 0}
+
+
+def _map(out, f):
+    if isinstance(out, torch.Tensor):
+        return f(out)
+    if isinstance(out, (tuple, list)):
+        return type(out)(_map(o, f) for o in out)
+    return out
+
+
+class FlagArena(object):
+    """static keep-flag storage of the Dropout2d sites of one captured forward"""
+
+    def __init__(self, device, size=1 << 17):
+        self.buf = torch.ones(size, dtype=torch.float32, device=device)
+        self.used = 0
+        self.p = None
+
+    def take(self, n, p):
+        assert self.p is None or self.p == p, 'one dropout rate per captured net'
+        self.p = p
+        o = self.used
+        self.used = o + n
+        assert self.used <= self.buf.numel(), 'flag arena too small'
+        return self.buf[o:o + n]
+
+    def refill(self):
+        if self.used:
+            self.buf[:self.used].bernoulli_(1.0 - self.p)
+
+
+class GraphedNoGrad(object):
+    def __init__(self, fn, warm=2):
+        self.fn = fn
+        self.warm = warm
+        self.state = {}
+
+    def __call__(self, x):
+        if (not ENABLED or torch.is_grad_enabled() or not (isinstance(x, torch.Tensor) and x.is_cuda)
+                or hnn.Dropout2d.mask_source is not None or torch.cuda.is_current_stream_capturing()):
+            return self.fn(x)
+        key = (tuple(x.shape), x.dtype, ops._PACK_EPOCH[0], ops.BF16X6, ops.HSPLIT, ops.HGEMM, ops.BSPLIT_MIN_PIXELS)
+        ent = self.state.get(key)
+        if ent is None:
+            if len(self.state) > 8:      # shapes keep changing (a last partial batch, ...): do not hoard graph pools
+                self.state.clear()
+            ent = self.state[key] = {'calls': 0}
+        if 'graph' not in ent:
+            if ent['calls'] < self.warm:
+                ent['calls'] += 1
+                STATS['eager'] += 1
+                return self.fn(x)
+            inp = x.clone()
+            arena = FlagArena(x.device)
+            g = torch.cuda.CUDAGraph()
+            hnn.Dropout2d.flag_arena = arena
+            try:
+                with torch.cuda.graph(g):
+                    out = self.fn(inp)
+            finally:
+                hnn.Dropout2d.flag_arena = None
+            ent.update(graph=g, inp=inp, out=out, arena=arena)
+            STATS['captured'] += 1
+        else:
+            ent['inp'].copy_(x)
+        ent['arena'].refill()
+        ent['graph'].replay()
+        STATS['replayed'] += 1
+        return _map(ent['out'], lambda t: t.clone())      # the graph's output buffers are overwritten by the next replay

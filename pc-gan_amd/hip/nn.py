@@ -64,11 +64,15 @@ class Dropout2d(tnn.Dropout2d):
     """nn.Dropout2d; `Dropout2d.mask_source` (an iterator of N*C keep-flag tensors, consumed in call
     order) lets a parity test replay the masks the oracle drew."""
     mask_source = None
+    flag_arena = None      # hip/graphs.py: static flag storage while a forward is captured into a hipGraph
 
     def forward(self, x):
         mask = None
-        if Dropout2d.mask_source is not None and self.training and self.p > 0:
-            mask = next(Dropout2d.mask_source).to(device=x.device, dtype=torch.float32)
+        if self.training and self.p > 0:
+            if Dropout2d.mask_source is not None:
+                mask = next(Dropout2d.mask_source).to(device=x.device, dtype=torch.float32)
+            elif Dropout2d.flag_arena is not None:
+                mask = Dropout2d.flag_arena.take(x.shape[0] * x.shape[1], float(self.p))
         return F.dropout2d(x, self.p, self.training, mask)
 
 

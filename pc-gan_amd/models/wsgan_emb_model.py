@@ -216,16 +216,27 @@ class WSGANEmbModel(BaseModel):
         is what `resample` needs for the configured noisy_var_type."""
         o = self.opt
         x = self.transform_E(x_E)
+        # the frozen encoder on a real image set (no autograd graph): hipGraph replay of the same launches (hip/graphs.py)
+        E = self._graphed('E', self.netE) if not torch.is_grad_enabled() else self.netE
         if not o.bayesian and not o.noisy:
-            return self.netE(x), None
+            return E(x), None
         if not o.bayesian and o.noisy:
-            y, logvar = self.netE(x)
+            y, logvar = E(x)
             return y, (torch.exp(logvar) if 'a' in o.noisy_var_type else None)
         if o.bayesian and not o.noisy:
-            y, y_var = compute_mu_and_var(self.netE, x, o.bnn_T, False)
+            y, y_var = compute_mu_and_var(E, x, o.bnn_T, False)
             return y, (y_var if 'e' in o.noisy_var_type else None)
-        y, y_var, y_s2 = compute_mu_and_var(self.netE, x, o.bnn_T, True)
+        y, y_var, y_s2 = compute_mu_and_var(E, x, o.bnn_T, True)
         return y, (y_s2 + y_var if 'a' in o.noisy_var_type else None)
+
+    def _graphed(self, name, net):
+        """GraphedNoGrad wrapper of a frozen net (made on first use)"""
+        cache = self.__dict__.setdefault('_graphed_nets', {})
+        g = cache.get(name)
+        if g is None:
+            from ..hip.graphs import GraphedNoGrad
+            g = cache[name] = GraphedNoGrad(net)
+        return g
 
     def forward(self):
         o = self.opt

@@ -55,6 +55,11 @@ class record_decisions(object):
         self.tape, self.saved, self.hooks = [], [], []
         self.tapes = {name: [] for name in self.nets}
         rec = self
+        # the recorder copies every decision to the host inside the forward pass: not capturable, so the frozen encoder's
+        # no-grad passes run eagerly (same kernels) instead of as a hipGraph replay while it is active
+        from pcgan_amd.hip import graphs
+        self.saved.append((graphs, 'ENABLED', graphs.ENABLED))
+        graphs.ENABLED = False
 
         class _Sink(object):
             """appends to the tape of the network whose forward() is running"""
