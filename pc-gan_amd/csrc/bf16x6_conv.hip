@@ -939,17 +939,19 @@ struct HWgradArgs {
     int x_namax, dy_namax;
 };
 
-template <int BM, int STRIDE, typename TA>
+// NC = column tiles of 128 per workgroup (2 with the 256-row tile: the dy tile is loaded and split once for 256 columns)
+template <int BM, int STRIDE, typename TA, int NC>
 __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     constexpr int NT = BM * 2;
+    constexpr int CW = 128 * NC;                // columns per workgroup
     constexpr bool HALF = sizeof(TA) == 2;      // bf16 tensors: one piece, one product, no scaling
     constexpr int NP = HALF ? 1 : 2;
     constexpr unsigned ES = sizeof(TA);
-    constexpr int KB = 2048 / NT;               // consecutive output pixels of its column a thread gathers per stage (4 or 8)
+    constexpr int KB = 16 * CW / NT;            // consecutive output pixels of its column a thread gathers per stage (4 or 8)
     // the two k halves of a row are written by neighbouring lanes: 128 bytes of padding between the halves put them on disjoint banks
     constexpr int AH = BM + 8;
     __shared__ __attribute__((aligned(16))) bf16x8 As[2][NP][2 * AH];     // [buffer][piece][half * AH + row]
-    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][NP][256];        // [buffer][piece][half * 128 + column]
+    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][NP][2 * CW];     // [buffer][piece][half * CW + column]
     const int tid = threadIdx.x;
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -970,8 +972,8 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     // A loader: row = tid / 2, half = tid % 2;  B loader: column = tid % 128, pixel group q = tid / 128
     const int arow = tid >> 1, ahalf = tid & 1;
     const unsigned avo = arow < a.K ? (unsigned)(arow * PQ + ahalf * 8) * ES : BS_OOB;
-    const int bcol = tid & 127, bq = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int col = blockIdx.x * 128 + bcol;
+    const int bcol = tid & (CW - 1), bq = __builtin_amdgcn_readfirstlane(tid / CW);
+    const int col = blockIdx.x * CW + bcol;
     unsigned bvo = BS_OOB;
     if (col < CT) {
         const int c = col / T, tap = col - c * T, r = tap / a.S, s = tap - r * a.S;
@@ -1034,7 +1036,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
             usK w;
 #pragma unroll
             for (int j = 0; j < KB; ++j) w[j] = (unsigned short)r.b[j];
-            *reinterpret_cast<usK*>(reinterpret_cast<unsigned short*>(&Bs[buf][0][bhalf * 128 + bcol]) + bsub) = w;
+            *reinterpret_cast<usK*>(reinterpret_cast<unsigned short*>(&Bs[buf][0][bhalf * CW + bcol]) + bsub) = w;
         } else {
             f16x8 h, l;
 #pragma unroll
@@ -1055,36 +1057,37 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
                 bh[j] = x;
                 bl[j] = y;
             }
-            *reinterpret_cast<hfK*>(reinterpret_cast<_Float16*>(&Bs[buf][0][bhalf * 128 + bcol]) + bsub) = bh;
-            *reinterpret_cast<hfK*>(reinterpret_cast<_Float16*>(&Bs[buf][NP - 1][bhalf * 128 + bcol]) + bsub) = bl;
+            *reinterpret_cast<hfK*>(reinterpret_cast<_Float16*>(&Bs[buf][0][bhalf * CW + bcol]) + bsub) = bh;
+            *reinterpret_cast<hfK*>(reinterpret_cast<_Float16*>(&Bs[buf][NP - 1][bhalf * CW + bcol]) + bsub) = bl;
         }
     };
 
-    f32x16 acc[2][2];
+    constexpr int NJ = 2 * NC;                  // 32-column blocks of a wave (its half of the workgroup's columns)
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     struct Operands {
-        bf16x8 A[NP][2], B[NP][2];
+        bf16x8 A[NP][2], B[NP][NJ];
     };
     auto fetch = [&](Operands& o, int buf) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                o.A[p][i] = As[buf][p][hi * AH + wm * 64 + i * 32 + lo];
-                o.B[p][i] = Bs[buf][p][hi * 128 + wp * 64 + i * 32 + lo];
-            }
+            for (int i = 0; i < 2; ++i) o.A[p][i] = As[buf][p][hi * AH + wm * 64 + i * 32 + lo];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) o.B[p][j] = Bs[buf][p][hi * CW + wp * (CW / 2) + j * 32 + lo];
+        }
     };
     auto mma = [&](const Operands& o) {
         if constexpr (HALF) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.A[0][i], o.B[0][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.A[0][i], o.B[0][j], acc[i][j], 0, 0, 0);
         } else {      // (l,h) (h,l) (h,h)
             constexpr int PA[3] = {NP - 1, 0, 0}, PB[3] = {0, NP - 1, 0};
 #pragma unroll
@@ -1092,7 +1095,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, o.A[PA[q]][i]),
                                                                             __builtin_bit_cast(f16x8, o.B[PB[q]][j]), acc[i][j], 0, 0, 0);
         }
@@ -1100,7 +1103,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     auto interleave = [&]() {
         if constexpr (HALF) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4 * NC; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
@@ -1109,12 +1112,12 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
+            for (int q = 0; q < 12 * NC; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
-                if (q < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // LDS reads of the next stage first
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                   // split arithmetic
+                if (q < 4 + 4 * NC) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // LDS reads of the next stage first
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   // split arithmetic
                 if (q >= 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // LDS writes
-                if (q >= 4 && q < 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // global loads
+                if (q >= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // global loads
             }
         }
     };
@@ -1149,8 +1152,8 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     // epilogue: acc[i][j][r] = part[split][row wm*64 + i*32 + (r/4)*8 + hi*4 + r%4][column wp*64 + j*32 + lo]
     const float isx = 1.f / sx, isd = 1.f / sdy;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int cg = blockIdx.x * 128 + wp * 64 + j * 32 + lo;
+    for (int j = 0; j < NJ; ++j) {
+        const int cg = blockIdx.x * CW + wp * (CW / 2) + j * 32 + lo;
         if (cg >= CT) continue;
         float* out = a.part + (size_t)blockIdx.y * a.K * CT + cg;
 #pragma unroll
@@ -1547,9 +1550,16 @@ extern "C" int pcgan_conv2d_hsplit_wgrad_supported(const pcgan_conv_desc* d) {
 
 static inline int hsplit_wgrad_bm(const pcgan_conv_desc* d) { return d->K > 128 ? 256 : 128; }
 
+// 256 columns per workgroup: bf16 tensors with the 256-row tile when that still leaves at least 8 column tiles (26.5 -> 26.0 ms per
+// bf16 step).  The fp16 two-piece form needs 256 VGPRs there and spills: 0.166 -> 0.177 ms per launch, so it keeps 128 columns.
+static inline int hsplit_wgrad_cw(const pcgan_conv_desc* d) {
+    return d->dtype == PCGAN_BF16 && hsplit_wgrad_bm(d) == 256 && d->C * d->R * d->S >= 8 * 256 ? 256 : 128;
+}
+
 static inline int hsplit_wgrad_splits(const pcgan_conv_desc* d, int* nst_split) {
     const int nst = d->N * d->P * d->Q / 16;
-    const long tiles = (d->C * d->R * d->S + 127) / 128;
+    const int cw = hsplit_wgrad_cw(d);
+    const long tiles = (d->C * d->R * d->S + cw - 1) / cw;
     long want = (hsplit_wgrad_bm(d) == 256 ? 256 : 512) / tiles;          // one round of resident workgroups
     if (want < 1) want = 1;
     if (want > nst / 8) want = nst / 8 > 0 ? nst / 8 : 1;
@@ -1595,14 +1605,17 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     a.xp_bytes = (unsigned)((size_t)d->N * d->C * Hp * Wp * es);
     a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * es);
     a.x_amax = x_amax; a.x_namax = n_xamax; a.dy_amax = dy_amax; a.dy_namax = n_dyamax;
-    const dim3 grid((unsigned)((d->C * d->R * d->S + 127) / 128), (unsigned)splits);
+    const int cw = hsplit_wgrad_cw(d);
+    const dim3 grid((unsigned)((d->C * d->R * d->S + cw - 1) / cw), (unsigned)splits);
     const int bm = hsplit_wgrad_bm(d);
-#define LWH(BMV, SV) do { if (half) hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, pcgan::bf16>), grid, dim3(BMV * 2), 0, st, a); \
-                          else hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, float>), grid, dim3(BMV * 2), 0, st, a); } while (0)
-    if (bm == 256 && d->stride == 1) LWH(256, 1);
-    else if (bm == 256) LWH(256, 2);
-    else if (d->stride == 1) LWH(128, 1);
-    else LWH(128, 2);
+#define LWH(BMV, SV, NCV) do { if (half) hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, pcgan::bf16, NCV>), grid, dim3(BMV * 2), 0, st, a); \
+                               else hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, float, NCV>), grid, dim3(BMV * 2), 0, st, a); } while (0)
+    if (bm == 256 && cw == 256 && d->stride == 1) LWH(256, 1, 2);
+    else if (bm == 256 && cw == 256) LWH(256, 2, 2);
+    else if (bm == 256 && d->stride == 1) LWH(256, 1, 1);
+    else if (bm == 256) LWH(256, 2, 1);
+    else if (d->stride == 1) LWH(128, 1, 1);
+    else LWH(128, 2, 1);
 #undef LWH
     PCGAN_LAUNCH_CHECK();
     const size_t total = (size_t)d->K * d->C * d->R * d->S;
