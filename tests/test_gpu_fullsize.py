@@ -89,10 +89,11 @@ def test_fullsize_conv_properties(case, dev):
     assert_close(dw8, w8.grad, 1e-4, name + ' weight gradient (%d images) vs oracle' % lo)
 
 
-@pytest.mark.parametrize('route', ['as_routed', 'split_kernels'])
+@pytest.mark.parametrize('route', ['as_routed', 'split_kernels', 'split_kernels_bf16x6', 'fp32_mfma'])
 def test_fullsize_step_vs_oracle(tmp_path, dev, route, monkeypatch):
     """One optimize_parameters() with the FULL networks of config 2 (9-block G ngf 64, 3-layer D ndf 64, ResNet-18 E
     and AlexNet IP at 224) on a batch of 2: losses and fake_B against the oracle's CPU step from the same weights.
+    The three routes of the fp32 convolutions (fp16 two-piece = default, three-piece bf16, fp32 MFMA) are held to the SAME oracle numbers.
     'split_kernels': the residual convolutions on the matrix-pipe split kernels they take at the benchmark's batch size (the host
     routes them there from 16384 output pixels; a batch of 2 has 2048) -- with the default fp16 route the operand maxima must come
     from the instance-norm kernels, not from extra passes."""
@@ -100,8 +101,13 @@ def test_fullsize_step_vs_oracle(tmp_path, dev, route, monkeypatch):
     from oracle import networks_ref as N
     from oracle import step_ref as S
     from pcgan_amd.hip import ops
-    if route == 'split_kernels':
+    if route.startswith('split_kernels'):
         monkeypatch.setattr(ops, 'BSPLIT_MIN_PIXELS', 0)
+    if route == 'split_kernels_bf16x6':      # PCGAN_SPLIT=bf16: the exact three-piece split on the residual convolutions, fp32 MFMA elsewhere
+        monkeypatch.setattr(ops, 'HSPLIT', False)
+    if route == 'fp32_mfma':                 # PCGAN_BF16X6=0: every convolution on the fp32 MFMA kernels (round 1's route)
+        monkeypatch.setattr(ops, 'HSPLIT', False)
+        monkeypatch.setattr(ops, 'BF16X6', False)
     amax0 = dict(ops.AMAX_STATS)
     torch.manual_seed(0)
     model, opt = bench.build_model(0, 2, 128, str(tmp_path), seed=3)
