@@ -11,7 +11,8 @@ makes that possible: no hidden allocation, no host synchronisation, device-side 
 Dropout2d inside a captured net: the keep flags of every site are slices of ONE static buffer that is refilled by a single
 `bernoulli_` launch in front of each replay (independent draws per pass, as in eager mode).
 
-Not used while autograd is recording, while a parity test injects masks (`Dropout2d.mask_source`), or with PCGAN_GRAPH_NOGRAD=0.
+Not used while autograd is recording, while a parity test injects masks (`Dropout2d.mask_source`), under torch.distributed, or with
+PCGAN_GRAPH_NOGRAD=0.
 A capture is tied to the packed-weight epoch: anything that re-packs every weight (load_networks, broadcast) starts over with
 eager calls."""
 import os
@@ -20,6 +21,7 @@ import torch
 
 from . import nn as hnn
 from . import ops
+from . import parallel
 
 ENABLED = os.environ.get('PCGAN_GRAPH_NOGRAD', '1') != '0'
 STATS = {'eager': 0, 'captured': 0, 'replayed': 0}
@@ -62,8 +64,8 @@ class GraphedNoGrad(object):
 
     def __call__(self, x):
         if (not ENABLED or torch.is_grad_enabled() or not (isinstance(x, torch.Tensor) and x.is_cuda)
-                or hnn.Dropout2d.mask_source is not None or torch.cuda.is_current_stream_capturing()):
-            return self.fn(x)
+                or hnn.Dropout2d.mask_source is not None or torch.cuda.is_current_stream_capturing() or parallel.is_distributed()):
+            return self.fn(x)      # (under torch.distributed: RCCL's watchdog thread and stream capture do not mix; eager there)
         key = (tuple(x.shape), x.dtype, ops._PACK_EPOCH[0], ops.BF16X6, ops.HSPLIT, ops.HGEMM, ops.BSPLIT_MIN_PIXELS)
         ent = self.state.get(key)
         if ent is None:
@@ -80,7 +82,7 @@ class GraphedNoGrad(object):
             g = torch.cuda.CUDAGraph()
             hnn.Dropout2d.flag_arena = arena
             try:
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     out = self.fn(inp)
             finally:
                 hnn.Dropout2d.flag_arena = None
