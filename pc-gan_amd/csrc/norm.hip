@@ -512,6 +512,129 @@ __global__ void __launch_bounds__(1024) instnorm_bwd_fused_kernel(const T* __res
     }
 }
 
+// Planes of up to 1024 elements (the residual blocks' 32x32 maps: 8192 planes per launch): ONE WAVE per plane, four planes per workgroup.
+// Every reduction is a wave reduction (no barrier, no LDS): the workgroup-per-plane form above spends its time in three barrier
+// pairs per 4 KB plane.  Same arithmetic (exact two-pass mean / M2), other summation order.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) instnorm_fwd_wave_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                                 float* __restrict__ mean_nc, float* __restrict__ m2_nc, int planes, int HW,
+                                                                 float eps, int act, float slope, float* __restrict__ y_pmax) {
+    const int lane = threadIdx.x & 63;
+    const size_t plane = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= (size_t)planes) return;
+    const int n4 = HW >> 2;
+    const T* xp = x + plane * (size_t)HW;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + k * 64;
+        v[k] = i < n4 ? ld4(xp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mean = wave_sum(s) / (float)HW;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (lane + k * 64 < n4) {
+            const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float m2 = wave_sum(q);
+    const float rstd = rsqrtf(m2 / (float)HW + eps);
+    const float sh = -mean * rstd;
+    const T* rp = res ? res + plane * (size_t)HW : nullptr;
+    T* yp = y + plane * (size_t)HW;
+    float am = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + k * 64;
+        if (i < n4) {
+            float4 o = make_float4(v[k].x * rstd + sh, v[k].y * rstd + sh, v[k].z * rstd + sh, v[k].w * rstd + sh);
+            if (rp) {
+                const float4 r = ld4(rp + 4 * i);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            o.x = act_apply(o.x, act, slope); o.y = act_apply(o.y, act, slope);
+            o.z = act_apply(o.z, act, slope); o.w = act_apply(o.w, act, slope);
+            st4(yp + 4 * i, o);
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+    }
+    if (y_pmax) am = wave_max(am);
+    if (lane == 0) {
+        mean_nc[plane] = mean;
+        m2_nc[plane] = m2;
+        if (y_pmax) y_pmax[plane] = am;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) instnorm_bwd_wave_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                                 const float* __restrict__ mean_nc, const float* __restrict__ m2_nc,
+                                                                 T* __restrict__ dx, float* __restrict__ dx_psum, int planes, int HW, float eps,
+                                                                 int act, float slope, float* __restrict__ dx_pmax) {
+    const int lane = threadIdx.x & 63;
+    const size_t plane = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= (size_t)planes) return;
+    const int n4 = HW >> 2;
+    const float mean = mean_nc[plane];
+    const float rstd = rsqrtf(m2_nc[plane] / (float)HW + eps);
+    const T* dp = dy + plane * (size_t)HW;
+    const T* xp = x + plane * (size_t)HW;
+    const T* yp = (act != PCGAN_ACT_NONE) ? y + plane * (size_t)HW : nullptr;
+    float4 g[4], xh[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + k * 64;
+        if (i < n4) {
+            g[k] = ld4(dp + 4 * i);
+            const float4 xv = ld4(xp + 4 * i);
+            if (yp) {
+                const float4 yv = ld4(yp + 4 * i);
+                g[k].x *= act_grad_from_out(yv.x, act, slope); g[k].y *= act_grad_from_out(yv.y, act, slope);
+                g[k].z *= act_grad_from_out(yv.z, act, slope); g[k].w *= act_grad_from_out(yv.w, act, slope);
+            }
+            xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            s1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+            s2 += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+        } else {
+            g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[k] = g[k];
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float m1 = s1 / (float)HW, mm2 = s2 / (float)HW;
+    T* op = dx + plane * (size_t)HW;
+    float ps = 0.f, am = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + k * 64;
+        if (i < n4) {
+            const float4 o = make_float4(rstd * (g[k].x - m1 - xh[k].x * mm2), rstd * (g[k].y - m1 - xh[k].y * mm2),
+                                         rstd * (g[k].z - m1 - xh[k].z * mm2), rstd * (g[k].w - m1 - xh[k].w * mm2));
+            st4(op + 4 * i, o);
+            ps += (o.x + o.y) + (o.z + o.w);
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+    }
+    if (dx_psum) ps = wave_sum(ps);
+    if (dx_pmax) am = wave_max(am);
+    if (lane == 0) {
+        if (dx_psum) dx_psum[plane] = ps;
+        if (dx_pmax) dx_pmax[plane] = am;
+    }
+}
+
 // (threads, float4-per-thread) for a plane of HW elements; E == 0: plane too large / not a multiple of 4
 static inline void fused_plan(int HW, int* T, int* E) {  // T: threads
     *T = 0;
@@ -618,7 +741,9 @@ static void launch_instnorm_fwd(int E, int NT, int planes, hipStream_t st, const
     const T* xp = (const T*)x;
     const T* rp = (const T*)residual;
     T* yp = (T*)y;
-    if (E == 1) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<1, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope, amax);
+    if (E == 1 && planes >= 1024)      // small planes, many of them: one wave per plane
+        hipLaunchKernelGGL((instnorm_fwd_wave_kernel<T>), dim3((planes + 3) / 4), dim3(256), 0, st, xp, rp, yp, mean_nc, m2_nc, planes, HW, eps, act, slope, amax);
+    else if (E == 1) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<1, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope, amax);
     else if (E == 4) hipLaunchKernelGGL((instnorm_fwd_fused_kernel<4, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope, amax);
     else hipLaunchKernelGGL((instnorm_fwd_fused_kernel<16, T>), dim3(planes), dim3(NT), 0, st, xp, rp, yp, mean_nc, m2_nc, HW, eps, act, slope, amax);
 }
@@ -652,7 +777,9 @@ static void launch_instnorm_bwd(int E, int NT, int planes, hipStream_t st, const
     const T* xp = (const T*)x;
     const T* yp = (const T*)y;
     T* op = (T*)dx;
-    if (E == 1) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope, amax);
+    if (E == 1 && planes >= 1024)
+        hipLaunchKernelGGL((instnorm_bwd_wave_kernel<T>), dim3((planes + 3) / 4), dim3(256), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, planes, HW, eps, act, slope, amax);
+    else if (E == 1) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope, amax);
     else if (E == 4) hipLaunchKernelGGL((instnorm_bwd_fused_kernel<4, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope, amax);
     else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<16, T>), dim3(planes), dim3(NT), 0, st, dp, xp, yp, mean_nc, m2_nc, op, dx_psum, HW, eps, act, slope, amax);
 }

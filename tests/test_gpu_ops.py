@@ -231,7 +231,9 @@ def test_instance_norm(shape, act, slope, res, dev):
 
 
 @pytest.mark.parametrize('shape', [(2, 8, 32, 32), (3, 5, 7, 7), (2, 4, 128, 128), (1, 2, 256, 256), (2, 6, 15, 15),
-                                   (2, 3, 64, 64), (2, 3, 8, 8), (2, 16, 32, 32), (1, 32, 12, 20)])
+                                   (2, 3, 64, 64), (2, 3, 8, 8), (2, 16, 32, 32), (1, 32, 12, 20),
+                                   # >= 1024 small planes: the wave-per-plane kernels (a plane count that is no multiple of 4, a ragged last float4 row)
+                                   (8, 128, 32, 32), (13, 79, 8, 8), (4, 256, 12, 20), (4, 272, 16, 16)])
 @pytest.mark.parametrize('act,res', [(0, False), (1, False), (0, True)])
 def test_instance_norm_fused(shape, act, res, dev):
     """register-resident single-pass kernels (and their two-pass fallback for planes that are not a multiple of 4)"""
