@@ -937,6 +937,7 @@ struct HWgradArgs {
     const float* x_amax;   // fp16 route: partial maxima of |x| and |dy| (device)
     const float* dy_amax;
     int x_namax, dy_namax;
+    int ntile, nwg;        // column tiles, workgroups that have work (the grid is padded to a multiple of 8)
 };
 
 // NC = column tiles of 128 per workgroup (2 with the 256-row tile: the dy tile is loaded and split once for 256 columns)
@@ -951,12 +952,18 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     // the two k halves of a row are written by neighbouring lanes: 128 bytes of padding between the halves put them on disjoint banks
     constexpr int AH = BM + 8;
     __shared__ __attribute__((aligned(16))) bf16x8 As[2][NP][2 * AH];     // [buffer][piece][half * AH + row]
-    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][NP][2 * CW];     // [buffer][piece][half * CW + column]
+    constexpr int BH = CW + 8;
+    __shared__ __attribute__((aligned(16))) bf16x8 Bs[2][NP][2 * BH];     // [buffer][piece][half * BH + column]
     const int tid = threadIdx.x;
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wp = wave & 1;
     const int T = a.R * a.S, CT = a.C * T, PQ = a.P * a.Q;
+    // workgroups go to the 8 XCDs round-robin: give each XCD a CONTIGUOUS run of (split, column tile) pairs, so that the column tiles
+    // of one split -- which all read the same dy rows -- share one L2 (dispatch order put them on all eight: dy crossed the fabric 8x)
+    const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if (wg >= a.nwg) return;
+    const int bx = wg % a.ntile, by = wg / a.ntile;
 
     float sx = 1.f, sdy = 1.f;
     if constexpr (!HALF) {
@@ -969,20 +976,27 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
         __syncthreads();
     }
 
-    // A loader: row = tid / 2, half = tid % 2;  B loader: column = tid % 128, pixel group q = tid / 128
-    const int arow = tid >> 1, ahalf = tid & 1;
-    const unsigned avo = arow < a.K ? (unsigned)(arow * PQ + ahalf * 8) * ES : BS_OOB;
-    const int bcol = tid & (CW - 1), bq = __builtin_amdgcn_readfirstlane(tid / CW);
-    const int col = blockIdx.x * CW + bcol;
+    // loaders: neighbouring lanes read neighbouring bytes of one row / one column's pixel run (64 contiguous bytes per 4 lanes of fp32
+    // data: a wave's load touches 16 lines, not 32-64 -- the vector memory path, not the matrix pipe, was the limit of this kernel).
+    // fp32 A: rows tid / 4 and NT / 4 + tid / 4, floats 4 * (tid % 4) ..+3 of the stage's 16;  bf16 A: row tid / 2, 8 values
+    // B: column tid / BT, pixels KB * (tid % BT) ..+KB-1
+    constexpr int AR = NT / 4;
+    constexpr int BT = 16 / KB;
+    const int arow = HALF ? tid >> 1 : tid >> 2, aq = HALF ? (tid & 1) * 2 : tid & 3;
+    const int ahalf = aq >> 1, asub = (aq & 1) * 4;
+    const unsigned avo = arow < a.K ? (unsigned)(arow * PQ + aq * 4) * ES : BS_OOB;
+    const unsigned avo1 = (!HALF && arow + AR < a.K) ? (unsigned)((arow + AR) * PQ + aq * 4) * ES : BS_OOB;
+    const int bcol = tid / BT, bq = tid % BT;
+    const int col = bx * CW + bcol;
     unsigned bvo = BS_OOB;
     if (col < CT) {
         const int c = col / T, tap = col - c * T, r = tap / a.S, s = tap - r * a.S;
-        bvo = (unsigned)((c * a.Hp + r) * a.Wp + s) * ES;
+        bvo = (unsigned)((c * a.Hp + r) * a.Wp + s + bq * KB * STRIDE) * ES;
     }
     const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.DY), 0, (int)a.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.XP), 0, (int)a.xp_bytes, 0x00020000);
 
-    const int st0 = (int)blockIdx.y * a.nst_split;
+    const int st0 = by * a.nst_split;
     const int nst_here = min(a.nst_split, a.nst - st0);
     // position of the next stage to LOAD (scalar): image, output row, first output column
     int ln, ly, lx;
@@ -998,10 +1012,13 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
         unsigned b[KB];               // KB consecutive output pixels of this thread's column
     };
     int lcount = 0;
+#ifndef WG_ABL
+#define WG_ABL 0      // timing-only ablations (results wrong by construction): 1 no global loads, 2 no split / LDS writes, 3 no LDS reads, 4 no MFMAs, 5 no barriers
+#endif
     auto load = [&](Stage& r) {
-        const bool live = lcount < nst_here;
+        const bool live = WG_ABL == 1 ? false : lcount < nst_here;
         const unsigned aso = (unsigned)(ln * a.K * PQ + ly * a.Q + lx) * ES;
-        const unsigned bso = (unsigned)(((ln * a.C) * a.Hp + ly * STRIDE) * a.Wp + (lx + bq * KB) * STRIDE) * ES;
+        const unsigned bso = (unsigned)(((ln * a.C) * a.Hp + ly * STRIDE) * a.Wp + lx * STRIDE) * ES;
         const unsigned av = live ? avo : BS_OOB, bv = live ? bvo : BS_OOB;
         if constexpr (HALF) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso, 0);
@@ -1009,11 +1026,19 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
 #pragma unroll
             for (int j = 0; j < KB; ++j) r.b[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rX, bv, bso + (unsigned)(j * STRIDE) * ES, 0);
         } else {
-            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso, 0), v1 = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso + 16, 0);
+            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso, 0), v1 = __builtin_amdgcn_raw_buffer_load_b128(rD, live ? avo1 : BS_OOB, aso, 0);
             r.a[0] = v0.x; r.a[1] = v0.y; r.a[2] = v0.z; r.a[3] = v0.w;
             r.a[4 % (HALF ? 4 : 8)] = v1.x; r.a[5 % (HALF ? 4 : 8)] = v1.y; r.a[6 % (HALF ? 4 : 8)] = v1.z; r.a[7 % (HALF ? 4 : 8)] = v1.w;
+            if constexpr (STRIDE == 1) {      // KB consecutive floats (any 4-byte alignment): 16 bytes per load
 #pragma unroll
-            for (int j = 0; j < KB; ++j) r.b[j] = __builtin_amdgcn_raw_buffer_load_b32(rX, bv, bso + (unsigned)(j * STRIDE) * ES, 0);
+                for (int j = 0; j < KB; j += 4) {
+                    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rX, bv, bso + (unsigned)j * ES, 0);
+                    r.b[j] = w.x; r.b[j + 1] = w.y; r.b[j + 2] = w.z; r.b[j + 3] = w.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < KB; ++j) r.b[j] = __builtin_amdgcn_raw_buffer_load_b32(rX, bv, bso + (unsigned)(j * STRIDE) * ES, 0);
+            }
         }
         ++lcount;
         lx += 16;
@@ -1027,8 +1052,55 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     };
     // the thread's KB consecutive k (pixels) of column bcol: k half (bq * KB) / 8, offset (bq * KB) % 8 inside it
     const int bhalf = (bq * KB) >> 3, bsub = (bq * KB) & 7;
+    // fp16 route: the pieces of a stage in registers (split), then to LDS (write) -- two steps, a barrier apart in the loop below
+    typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 hfK __attribute__((ext_vector_type(KB)));
+    struct Pieces {
+        hf4 ah[2], al[2];      // rows arow and arow + AR: 4 values each
+        hfK bh, bl;
+    };
+    auto split = [&](const Stage& r, Pieces& q) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 x, y;
+                split2h(__uint_as_float(r.a[(i * 4 + j) % (HALF ? 4 : 8)]) * sdy, x, y);
+                q.ah[i][j] = x;
+                q.al[i][j] = y;
+            }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            _Float16 x, y;
+            split2h(__uint_as_float(r.b[j]) * sx, x, y);
+            q.bh[j] = x;
+            q.bl[j] = y;
+        }
+    };
+    auto write = [&](const Pieces& q, int buf) {
+        if (WG_ABL == 2) {
+            asm volatile("" :: "v"(q.ah[0]), "v"(q.bh));
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<hf4*>(reinterpret_cast<_Float16*>(&As[buf][0][ahalf * AH + arow + i * AR]) + asub) = q.ah[i];
+            *reinterpret_cast<hf4*>(reinterpret_cast<_Float16*>(&As[buf][NP - 1][ahalf * AH + arow + i * AR]) + asub) = q.al[i];
+        }
+        *reinterpret_cast<hfK*>(reinterpret_cast<_Float16*>(&Bs[buf][0][bhalf * BH + bcol]) + bsub) = q.bh;
+        *reinterpret_cast<hfK*>(reinterpret_cast<_Float16*>(&Bs[buf][NP - 1][bhalf * BH + bcol]) + bsub) = q.bl;
+    };
+
     auto stash = [&](const Stage& r, int buf) {
-        if constexpr (HALF) {      // stored bf16 patterns as they are
+        if (WG_ABL == 2) {
+            asm volatile("" :: "v"(r.a[0]), "v"(r.b[0]));
+            return;
+        }
+        if constexpr (!HALF) {
+            Pieces q;
+            split(r, q);
+            write(q, buf);
+        } else {                   // stored bf16 patterns as they are
             u32x4 v;
             v.x = r.a[0]; v.y = r.a[1]; v.z = r.a[2]; v.w = r.a[3];
             *reinterpret_cast<u32x4*>(&As[buf][0][ahalf * AH + arow]) = v;
@@ -1036,32 +1108,9 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
             usK w;
 #pragma unroll
             for (int j = 0; j < KB; ++j) w[j] = (unsigned short)r.b[j];
-            *reinterpret_cast<usK*>(reinterpret_cast<unsigned short*>(&Bs[buf][0][bhalf * CW + bcol]) + bsub) = w;
-        } else {
-            f16x8 h, l;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 x, y;
-                split2h(__uint_as_float(r.a[j % (HALF ? 4 : 8)]) * sdy, x, y);
-                h[j] = x;
-                l[j] = y;
-            }
-            As[buf][0][ahalf * AH + arow] = __builtin_bit_cast(bf16x8, h);
-            As[buf][NP - 1][ahalf * AH + arow] = __builtin_bit_cast(bf16x8, l);
-            typedef _Float16 hfK __attribute__((ext_vector_type(KB)));
-            hfK bh, bl;
-#pragma unroll
-            for (int j = 0; j < KB; ++j) {
-                _Float16 x, y;
-                split2h(__uint_as_float(r.b[j]) * sx, x, y);
-                bh[j] = x;
-                bl[j] = y;
-            }
-            *reinterpret_cast<hfK*>(reinterpret_cast<_Float16*>(&Bs[buf][0][bhalf * CW + bcol]) + bsub) = bh;
-            *reinterpret_cast<hfK*>(reinterpret_cast<_Float16*>(&Bs[buf][NP - 1][bhalf * CW + bcol]) + bsub) = bl;
+            *reinterpret_cast<usK*>(reinterpret_cast<unsigned short*>(&Bs[buf][0][bhalf * BH + bcol]) + bsub) = w;
         }
     };
-
     constexpr int NJ = 2 * NC;                  // 32-column blocks of a wave (its half of the workgroup's columns)
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -1074,15 +1123,26 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
         bf16x8 A[NP][2], B[NP][NJ];
     };
     auto fetch = [&](Operands& o, int buf) {
+        if (WG_ABL == 3) return;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) o.A[p][i] = As[buf][p][hi * AH + wm * 64 + i * 32 + lo];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) o.B[p][j] = Bs[buf][p][hi * CW + wp * (CW / 2) + j * 32 + lo];
+            for (int j = 0; j < NJ; ++j) o.B[p][j] = Bs[buf][p][hi * BH + wp * (CW / 2) + j * 32 + lo];
         }
     };
     auto mma = [&](const Operands& o) {
+        if (WG_ABL == 4) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(o.A[p][i]));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(o.B[p][j]));
+            }
+            return;
+        }
         if constexpr (HALF) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1135,16 +1195,60 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     __syncthreads();
     load(rg[1]);
     const int nst2 = (nst_here + 1) & ~1;
-    for (int s = 0; s < nst2; s += 2) {
+    if constexpr (HALF) {
+        for (int s = 0; s < nst2; s += 2) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            fetch(op[(t + 1) & 1], (t + 1) & 1);     // operands of stage s+t+1
-            mma(op[t]);                              // stage s+t
-            stash(rg[t], t);                         // stage s+t+2
-            load(rg[t]);                             // stage s+t+4
-            interleave();
+            for (int t = 0; t < 2; ++t) {
+                fetch(op[(t + 1) & 1], (t + 1) & 1);     // operands of stage s+t+1
+                mma(op[t]);                              // stage s+t
+                stash(rg[t], t);                         // stage s+t+2
+                load(rg[t]);                             // stage s+t+4
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        // fp16 route: TWO SLOTS per stage, and the two waves of a SIMD (w and w + 4) run them in opposite order --
+        //   slot X   the 12 MFMAs of stage k (operands in registers) with the split arithmetic of stage k+2 between them
+        //   slot Y   pieces of stage k+2 to LDS, global loads of stage k+4, LDS reads of the operands of stage k+1
+        // waves 4-7 start one slot late, so that in every slot one wave of each SIMD feeds the matrix pipe while the other works
+        // the LDS / memory side (with all eight waves in the same phase the two kinds of work ran one after the other: the kernel
+        // took the SUM of its MFMA time and its load / split / LDS time).  Buffer k & 1 holds stage k: written in the Y slots
+        // 2k-3 (waves 0-3) and 2k-2 (waves 4-7), read in the Y slots 2k-1 and 2k, rewritten from slot 2k+1 on; a barrier ends
+        // every slot.
+        const bool late = wave >= NT / 128;
+        if (late) {
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
+            if (WG_ABL != 5) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int s = 0; s < nst2; s += 2) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                Pieces q;
+                split(rg[t], q);                         // stage s+t+2
+                mma(op[0]);                              // stage s+t
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (WG_ABL != 5) __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                write(q, t);                             // stage s+t+2 over stage s+t
+                load(rg[t]);                             // stage s+t+4
+                fetch(op[0], (t + 1) & 1);               // operands of stage s+t+1
+                __builtin_amdgcn_sched_barrier(0);
+                if (WG_ABL != 5) __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!late) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (WG_ABL != 5) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1153,9 +1257,9 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     const float isx = 1.f / sx, isd = 1.f / sdy;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int cg = blockIdx.x * CW + wp * (CW / 2) + j * 32 + lo;
+        const int cg = bx * CW + wp * (CW / 2) + j * 32 + lo;
         if (cg >= CT) continue;
-        float* out = a.part + (size_t)blockIdx.y * a.K * CT + cg;
+        float* out = a.part + (size_t)by * a.K * CT + cg;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1606,7 +1710,9 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * es);
     a.x_amax = x_amax; a.x_namax = n_xamax; a.dy_amax = dy_amax; a.dy_namax = n_dyamax;
     const int cw = hsplit_wgrad_cw(d);
-    const dim3 grid((unsigned)((d->C * d->R * d->S + cw - 1) / cw), (unsigned)splits);
+    a.ntile = (d->C * d->R * d->S + cw - 1) / cw;
+    a.nwg = a.ntile * splits;
+    const dim3 grid((unsigned)((a.nwg + 7) & ~7));
     const int bm = hsplit_wgrad_bm(d);
 #define LWH(BMV, SV, NCV) do { if (half) hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, pcgan::bf16, NCV>), grid, dim3(BMV * 2), 0, st, a); \
                                else hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, float, NCV>), grid, dim3(BMV * 2), 0, st, a); } while (0)
