@@ -148,6 +148,60 @@ __global__ void bsplit_pad_reflect_kernel(const TA* __restrict__ x, TA* __restri
     }
 }
 
+// the same copy for small planes (the residual blocks: 8192 planes of 34 x 34): one WAVE per plane, a lane writes PAIRS of neighbouring
+// elements (padded width even: a pair never leaves its row, every pair is 8- / 4-byte aligned), row / column advanced without
+// a division.  The element-per-thread form above spent its time in 40960 workgroups of one element per thread (0.030 ms).
+template <typename TA>
+__global__ void __launch_bounds__(256) bsplit_pad_wave_kernel(const TA* __restrict__ x, TA* __restrict__ xp, int planes, int H, int W, int pad, int reflect) {
+    const int lane = threadIdx.x & 63;
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad, half = Wp >> 1;
+    const TA* src = x + (size_t)plane * H * W;
+    TA* dst = xp + (size_t)plane * Hp * Wp;
+    int row = lane / half, cp = lane - row * half;
+    const int drow = 64 / half, dcp = 64 - drow * half;
+    typedef TA pair_t __attribute__((ext_vector_type(2)));
+    while (row < Hp) {
+        int y = row - pad, x0 = 2 * cp - pad, x1 = x0 + 1;
+        bool in0 = (unsigned)y < (unsigned)H, in1 = in0;
+        if (reflect) {
+            y = y < 0 ? -y : (y >= H ? 2 * (H - 1) - y : y);
+            x0 = x0 < 0 ? -x0 : (x0 >= W ? 2 * (W - 1) - x0 : x0);
+            x1 = x1 < 0 ? -x1 : (x1 >= W ? 2 * (W - 1) - x1 : x1);
+            in0 = in1 = true;
+        } else {
+            in0 = in0 && (unsigned)x0 < (unsigned)W;
+            in1 = in1 && (unsigned)x1 < (unsigned)W;
+        }
+        TA zero;
+        st1(&zero, 0.f);
+        pair_t v;
+        v.x = in0 ? src[y * W + x0] : zero;
+        v.y = in1 ? src[y * W + x1] : zero;
+        *reinterpret_cast<pair_t*>(dst + row * Wp + 2 * cp) = v;
+        cp += dcp;
+        row += drow;
+        if (cp >= half) {
+            cp -= half;
+            ++row;
+        }
+    }
+}
+
+static void launch_pad(const void* x, void* xpad, int planes, int H, int W, int pad, int reflect, bool half, hipStream_t st) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    if (Wp % 2 == 0 && Wp <= 128 && Hp * Wp <= 8192 && planes >= 1024) {
+        const dim3 grid((planes + 3) / 4);
+        if (half) hipLaunchKernelGGL(bsplit_pad_wave_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (bf16*)xpad, planes, H, W, pad, reflect);
+        else hipLaunchKernelGGL(bsplit_pad_wave_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)xpad, planes, H, W, pad, reflect);
+        return;
+    }
+    const dim3 pgrid((Hp * Wp + 255) / 256, planes);
+    if (half) hipLaunchKernelGGL(bsplit_pad_reflect_kernel<bf16>, pgrid, dim3(256), 0, st, (const bf16*)x, (bf16*)xpad, H, W, pad, reflect);
+    else hipLaunchKernelGGL(bsplit_pad_reflect_kernel<float>, pgrid, dim3(256), 0, st, (const float*)x, (float*)xpad, H, W, pad, reflect);
+}
+
 // dy[N][K][HW] -> [piece][stage][half][BM][8] bf16 pieces, stage = 16 consecutive elements of the (n, y, x) reduction
 template <typename TA>
 __global__ void bsplit_pack_dy_kernel(const TA* __restrict__ dy, __bf16* __restrict__ A, int K, int HW, int nst, int bm_shift, int np) {
@@ -1507,10 +1561,7 @@ extern "C" int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const vo
     __bf16* packed = (__bf16*)((char*)ws + xpad_bytes);
     float* part = (float*)((char*)ws + xpad_bytes + packed_bytes);
     PCGAN_CHECK(d->N * d->C <= 65535, "conv2d_bwd_weight_bsplit: more than 65535 planes");
-    const int per_plane = (d->H + 2) * (d->W + 2);
-    const dim3 pgrid((per_plane + 255) / 256, d->N * d->C);
-    if (half) hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel<pcgan::bf16>, pgrid, dim3(256), 0, st, (const pcgan::bf16*)x, (pcgan::bf16*)xpad, d->H, d->W, 1);
-    else hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel<float>, pgrid, dim3(256), 0, st, (const float*)x, (float*)xpad, d->H, d->W, 1);
+    pcgan::launch_pad(x, xpad, d->N * d->C, d->H, d->W, 1, 1, half, st);
     PCGAN_LAUNCH_CHECK();
     PCGAN_CHECK(nMt == 1, "conv2d_bwd_weight_bsplit: more than one %d-row tile of output channels is not built", bm);
     const size_t per_piece = (size_t)nst * 16 * bm;
@@ -1695,9 +1746,7 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     float* part = (float*)((char*)ws + xpad_bytes);
     const void* xin = x;
     if (d->pad > 0) {
-        const dim3 pgrid((Hp * Wp + 255) / 256, d->N * d->C);
-        if (half) hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel<pcgan::bf16>, pgrid, dim3(256), 0, st, (const pcgan::bf16*)x, (pcgan::bf16*)xpad, d->H, d->W, d->pad, d->pad_mode);
-        else hipLaunchKernelGGL(pcgan::bsplit_pad_reflect_kernel<float>, pgrid, dim3(256), 0, st, (const float*)x, (float*)xpad, d->H, d->W, d->pad, d->pad_mode);
+        pcgan::launch_pad(x, xpad, d->N * d->C, d->H, d->W, d->pad, d->pad_mode, half, st);
         PCGAN_LAUNCH_CHECK();
         xin = xpad;
     }

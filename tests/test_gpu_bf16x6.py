@@ -299,6 +299,9 @@ def test_hsplit_weight_gradient(dev, N, C, H, W, acc, data):
     (3, 24, 16, 16, 96, 3, 1, 1, 0),      # ragged rows (96 of 128) and columns (216), zero padding stride 1
     (1, 16, 18, 34, 32, 5, 1, 1, 0),      # 25 taps, padding smaller than the filter radius (output 16 x 32)
     (2, 32, 16, 16, 64, 1, 1, 0, 0),      # 1x1, no padding (no padded copy)
+    (8, 128, 16, 16, 64, 3, 1, 1, 0),     # 1024 small planes: the wave-per-plane padded copy, zero padding
+    (9, 128, 16, 32, 64, 3, 1, 1, 1),     # ... reflection, a plane count that is no multiple of 4, non-square
+    (4, 256, 12, 16, 64, 5, 1, 2, 1),     # ... padding 2
 ])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_hsplit_weight_gradient_general(dev, N, C, H, W, K, k, stride, pad, mode, dtype):
