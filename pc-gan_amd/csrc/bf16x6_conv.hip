@@ -553,8 +553,9 @@ __global__ void __launch_bounds__(BM * 2) bsplit_conv_fwd_kernel(BsplitArgs a) {
 // The kernel above gathers every input element once per tap (9 loads, 9 splits, 9 LDS writes per element and workgroup).  Here a
 // pixel tile is RT = 128 / W full image rows, and per 16-channel chunk its (RT + 2) x (W + 2) window is loaded, split and written
 // to LDS ONCE; the nine taps read it at shifted addresses ([piece][k half][window pixel][8 bf16]: a tap is a constant added to the
-// lane's LDS address, 32 consecutive lanes still read 512 contiguous bytes).  Weights, accumulators, MFMA order and the two-stage
-// software pipeline are those of the kernel above (BM = 256: 8 waves of 64 x 64).
+// lane's LDS address, 32 consecutive lanes still read 512 contiguous bytes).  The packed weights and the MFMA order are those of the
+// kernel above; a wave owns 32 output channels x all 128 pixels and loads its weight fragments from memory into registers (no
+// weight stage in LDS, one barrier per 16-channel chunk: see the A operand below).
 //   forward        the window holds the reflection-padded input (the mirror is applied when the window is built);
 //   data gradient  the window holds dy with a ring of zeros; the contributions of the padded rows / columns -1 and H / W, which
 //                  fold onto rows / columns 1 and H-2 / W-2, become two extra window rows and columns of SUMS
@@ -597,13 +598,13 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     constexpr int NPATCH = DG ? 2 * WR + 2 * QH : 0, NRP = DG ? (NPATCH * 4 + NT - 1) / NT : 0;
     constexpr unsigned ASTAGE = BM * 32;            // bytes of one stage of one piece of the weights
     constexpr unsigned XPIECE = 2 * NPX * 16, XBUF = NP * XPIECE;
-    __shared__ __attribute__((aligned(16))) bf16x8 As[2][NP][2 * BM];    // [buffer][piece][half * BM + row]
     __shared__ __attribute__((aligned(16))) bf16x8 Xs[2 * NP * 2 * NPX];  // [buffer][piece][half][window entry]
+    __shared__ float red_scratch[16];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wp = wave & 1;
+    constexpr int NI = 1, NJ = 4;                   // a wave's tile: 32 output channels x all 128 pixels (its weight fragments are its own: no wave loads another's)
     const int mt = blockIdx.x % a.nMt, pt = blockIdx.x / a.nMt;
     const int TPI = a.H / RT;
     const int n = pt / TPI, y0 = (pt - n * TPI) * RT;
@@ -680,10 +681,10 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     }
 
     // ---- LDS addresses of this lane's two pixel columns (j = 0, 1) of the B operand, per tap
-    unsigned boff[2], rowb[DG ? 2 : 1][3], colb[DG ? 2 : 1][3];
+    unsigned boff[NJ], rowb[DG ? NJ : 1][3], colb[DG ? NJ : 1][3];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = wp * 64 + j * 32 + lo, ty = p / QW, tx = p - ty * QW;
+    for (int j = 0; j < NJ; ++j) {
+        const int p = j * 32 + lo, ty = p / QW, tx = p - ty * QW;
         boff[j] = (unsigned)((hi * NPX + ty * QH + tx) * 16);
         if constexpr (DG) {
             const int y = y0 + ty;
@@ -716,8 +717,8 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     if constexpr (PK == PK_F16X2) {      // largest of the partial maxima the producer left (one per plane, or a single value)
         float m = 0.f;
         for (int i = tid; i < a.x_namax; i += NT) m = fmaxf(m, a.x_amax[i]);
-        sx = pow2_scale(block_max(m, reinterpret_cast<float*>(&As[0][0][0])));
-        sw = pow2_scale(block_max(tid < WEIGHT_AMAX_SLOTS ? a.w_amax[tid] : 0.f, reinterpret_cast<float*>(&As[0][0][0])));
+        sx = pow2_scale(block_max(m, red_scratch));
+        sw = pow2_scale(block_max(tid < WEIGHT_AMAX_SLOTS ? a.w_amax[tid] : 0.f, red_scratch));
         __syncthreads();
     }
     auto put_split = [&](unsigned lds, int buf, const float (&v)[4]) {
@@ -808,40 +809,41 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
         }
     };
 
-    struct Stage {
-        u32x4 ap[NP];
+    // the A operand (weights) never touches LDS: the packed image holds, per stage and piece, [k half][256 rows][8 values] -- exactly
+    // the 16 bytes a lane feeds to the MFMA (row wave * 32 + lo, k half hi) -- so every wave loads ITS fragments from memory
+    // (32 rows x 16 bytes contiguous per half-wave; every byte of the image is loaded by exactly one wave of the workgroup) two or three stages ahead.
+    // No weight stage in LDS means no barrier per stage (one per 16-channel chunk, for the window), none of this chip's slow LDS stores
+    // (~80 B/clk), half the LDS reads, and waves that drift apart so that one wave's window work sits under another's MFMAs.
+    struct OpA {
+        bf16x8 A[NP][NI];
     };
-    auto load = [&](Stage& r, int s) {
+    const unsigned a_lane = (unsigned)((hi * BM + wave * 32 + lo) * 16);
+    auto aload = [&](OpA& o, int s) {
         const bool live = s < nst;
-        const unsigned avo = live ? (unsigned)tid * 16u : BS_OOB;
+        const unsigned avo = live ? a_lane : BS_OOB;
         const unsigned aso = a_tile + (unsigned)(live ? s : 0) * ASTAGE;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) r.ap[p] = __builtin_amdgcn_raw_buffer_load_b128(rA, avo, aso + p * piece_bytes, 0);
-    };
-    auto stash = [&](const Stage& r, int buf) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(&As[buf][p][tid]) = r.ap[p];
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    struct Operands {
-        bf16x8 A[NP][2], B[NP][2];
-    };
-    // operands of one stage: weights from As[abuf], pixels of tap (tr, ts) from window buffer xbuf
-    auto fetch = [&](Operands& o, int abuf, int xbuf, int tr, int ts) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) o.A[p][i] = As[abuf][p][hi * BM + wm * 64 + i * 32 + lo];
+            for (int i = 0; i < NI; ++i)
+                o.A[p][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rA, avo, aso + p * piece_bytes + i * 512, 0));
+    };
+
+    f32x16 acc[NI][NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    struct OpB {
+        bf16x8 B[NP][NJ];
+    };
+    // B operand of one stage: pixels of tap (tr, ts) from window buffer xbuf
+    auto fetch = [&](OpB& o, int xbuf, int tr, int ts) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
             unsigned ad;
             if constexpr (DG) ad = rowb[j][tr] + colb[j][ts];
             else ad = boff[j] + (unsigned)((tr * QH + ts) * 16);
@@ -850,26 +852,26 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
                 o.B[p][j] = *reinterpret_cast<const bf16x8*>(xs_bytes + ad + (unsigned)xbuf * XBUF + p * XPIECE);
         }
     };
-    auto mma = [&](const Operands& o) {
+    auto mma = [&](const OpA& oa, const OpB& ob) {
         if constexpr (PK == PK_F16X2) {       // (l,h) (h,l) (h,h)
             constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, o.A[PA[q]][i]),
-                                                                            __builtin_bit_cast(f16x8, o.B[PB[q]][j]), acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, oa.A[PA[q]][i]),
+                                                                            __builtin_bit_cast(f16x8, ob.B[PB[q]][j]), acc[i][j], 0, 0, 0);
         } else {
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
             for (int q = (NP == 3 ? 0 : 5); q < 6; ++q)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.A[PA[q]][i], o.B[PB[q]][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa.A[PA[q]][i], ob.B[PB[q]][j], acc[i][j], 0, 0, 0);
         }
     };
     // issue order inside a stage (a hint): every MFMA is followed by its share of the other work
@@ -879,9 +881,10 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
             for (int q = 0; q < 12; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
                 if (q < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // LDS reads of the next stage first
+                if (q < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // weight fragments two stages ahead
                 __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                   // VALU (split arithmetic of a window)
                 if (q >= 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // LDS writes
-                if (q >= 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);       // global loads
+                if (q >= 4) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);       // window loads
             }
         } else if constexpr (NP == 3) {
 #pragma unroll
@@ -904,28 +907,25 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
         }
     };
 
-    // window of chunk 0, then the weight pipeline of the kernel above, unrolled over a PAIR of chunks (18 stages) so that window
-    // buffer, tap, LDS weight buffer and register sets are all static.  Stage t of the pair: MFMAs of stage t out of registers |
-    // operand fetch of stage t+1 | weights of stage t+2 to LDS, of stage t+4 from memory | window of the next chunk:
+    // window of chunk 0, then the stage loop unrolled over a PAIR of chunks (18 stages) so that window buffer, tap and register sets
+    // are all static.  Stage t of the pair: MFMAs of stage t out of registers | B fetch (LDS) of stage t+1 | weight fragments of
+    // stage t+NA-1 from memory | window of the next chunk:
     //   t = 0 / 9    loads of the window proper                       (registers only)
     //   t = 3 / 12   its split + LDS writes; loads of the sum rows / columns (data gradient)
     //   t = 6 / 15   their split + LDS writes
-    // first reader: the fetch during t = 8 / 17; the buffer overwritten was last read by the fetch during t = 16 / 7.
+    // ONE barrier per chunk, at the end of t = 7 / 16: behind every wave's window writes and its last fetch from the window before
+    // (during t = 7 / 16), in front of the first fetch from the new window (during t = 8 / 17) and of the next writes (t = 3 / 12).
+    constexpr int NA = NP == 3 ? 2 : 3;       // register sets of weight fragments (18 = 0 mod NA)
     base_load(0);
     patch_load(0);
-    Stage rg[2];
-    Operands op[2];
-    load(rg[0], 0);
-    load(rg[1], 1);
+    OpA oa[NA];
+    OpB ob[2];
+#pragma unroll
+    for (int i = 0; i < NA - 1; ++i) aload(oa[i], i);
     base_write(0);
     patch_write(0);
-    stash(rg[0], 0);
     __syncthreads();
-    load(rg[0], 2);
-    fetch(op[0], 0, 0, 0, 0);
-    stash(rg[1], 1);
-    __syncthreads();
-    load(rg[1], 3);
+    fetch(ob[0], 0, 0, 0);
     for (int c = 0; c < a.nch; c += 2) {
         const int s0 = c * 9;
 #pragma unroll
@@ -934,10 +934,9 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
 #ifndef HALO_ABL
 #define HALO_ABL 0
 #endif
-            if (HALO_ABL != 3) fetch(op[(t + 1) & 1], (t + 1) & 1, tn / 9, tapn / 3, tapn % 3);    // operands of stage t+1
-            if (HALO_ABL != 4) mma(op[t & 1]);                                                  // stage t
-            if (HALO_ABL != 2) stash(rg[t & 1], t & 1);                                         // weights of stage t+2 (its buffer was read for stage t before the last barrier)
-            if (HALO_ABL != 2) load(rg[t & 1], s0 + t + 4);
+            if (HALO_ABL != 2) aload(oa[(t + NA - 1) % NA], s0 + t + NA - 1);                   // weight fragments of stage t+NA-1
+            if (HALO_ABL != 3) fetch(ob[(t + 1) & 1], tn / 9, tapn / 3, tapn % 3);              // pixels of stage t+1
+            if (HALO_ABL != 4) mma(oa[t % NA], ob[t & 1]);                                      // stage t
             if (t == 0) base_load(c + 1);
             if (t == 9) base_load(c + 2);
             if (t == 3 || t == 12) {
@@ -947,21 +946,23 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
             if (t == 6 || t == 15) patch_write(t == 6 ? 1 : 0);
             interleave();
             __builtin_amdgcn_sched_barrier(0);      // nothing moves across a stage boundary (MFMAs of the next stage would wait on its own LDS reads)
-            if (HALO_ABL != 1) __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
+            if (t == 7 || t == 16) {
+                if (HALO_ABL != 1) __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
-    // epilogue: acc[i][j][r] = Y[m0 + wm*64 + i*32 + (r/4)*8 + hi*4 + r%4][pixel wp*64 + j*32 + lo]; a tile is RT full rows of image n
+    // epilogue: acc[i][j][r] = Y[m0 + wave*32 + (r/4)*8 + hi*4 + r%4][pixel j*32 + lo]; a tile is RT full rows of image n
     const float isx = 1.f / sx, isw = 1.f / sw;    // powers of two: exact
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const size_t yo = (size_t)n * a.M * HW + (size_t)y0 * QW + wp * 64 + j * 32 + lo;
+    for (int j = 0; j < NJ; ++j) {
+        const size_t yo = (size_t)n * a.M * HW + (size_t)y0 * QW + j * 32 + lo;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mt * BM + wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+                const int m = mt * BM + wave * 32 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
                 if (m < a.M) {
                     const float av = PK == PK_F16X2 ? (acc[i][j][r] * isx) * isw : acc[i][j][r];
                     const float v = act_apply(av + (a.bias ? a.bias[m] : 0.f), a.act, a.slope);
