@@ -715,8 +715,7 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
     float sx = 1.f, sw = 1.f;
     if constexpr (PK == PK_F16X2) {      // largest of the partial maxima the producer left (one per plane, or a single value)
-        float m = 0.f;
-        for (int i = tid; i < a.x_namax; i += NT) m = fmaxf(m, a.x_amax[i]);
+        const float m = thread_max_of_partials(a.x_amax, a.x_namax, tid, NT);
         sx = pow2_scale(block_max(m, red_scratch));
         sw = pow2_scale(block_max(tid < WEIGHT_AMAX_SLOTS ? a.w_amax[tid] : 0.f, red_scratch));
         __syncthreads();
@@ -1022,9 +1021,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
 
     float sx = 1.f, sdy = 1.f;
     if constexpr (!HALF) {
-        float m = 0.f, g = 0.f;
-        for (int i = tid; i < a.x_namax; i += NT) m = fmaxf(m, a.x_amax[i]);
-        for (int i = tid; i < a.dy_namax; i += NT) g = fmaxf(g, a.dy_amax[i]);
+        const float m = thread_max_of_partials(a.x_amax, a.x_namax, tid, NT), g = thread_max_of_partials(a.dy_amax, a.dy_namax, tid, NT);
         float* scratch = reinterpret_cast<float*>(&As[0][0][0]);
         sx = pow2_scale(block_max(m, scratch));
         sdy = pow2_scale(block_max(g, scratch));

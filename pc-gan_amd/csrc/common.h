@@ -143,6 +143,30 @@ __device__ __forceinline__ float max_of_partials(const float* __restrict__ p, in
     return m;
 }
 static constexpr int WEIGHT_AMAX_SLOTS = 64;     // partial maxima kept for a weight tensor
+// a thread's share of n partial maxima, strided over the workgroup's nt threads (block_max finishes it).  16-byte loads, four in
+// flight, when the pointer allows: the element-per-iteration loop took one L2 round trip per element -- 16 in a row for the 8192
+// per-plane maxima of a residual-block tensor and 512 threads, 3-6 % of a 0.09 ms convolution (scripts/namax_probe.py)
+__device__ __forceinline__ float thread_max_of_partials(const float* __restrict__ p, int n, int tid, int nt) {
+    float m = 0.f;
+    if ((reinterpret_cast<size_t>(p) & 15) != 0) {
+        for (int i = tid; i < n; i += nt) m = fmaxf(m, p[i]);
+        return m;
+    }
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const int n4 = n >> 2;
+    int i = tid;
+    for (; i + 3 * nt < n4; i += 4 * nt) {
+        const float4 a = p4[i], b = p4[i + nt], c = p4[i + 2 * nt], d = p4[i + 3 * nt];
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)), fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w))));
+    }
+    for (; i < n4; i += nt) {
+        const float4 a = p4[i];
+        m = fmaxf(m, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+    }
+    for (int j = (n4 << 2) + tid; j < n; j += nt) m = fmaxf(m, p[j]);
+    return m;
+}
 
 __device__ __forceinline__ void split2h(float x, _Float16& h, _Float16& l) {
     h = (_Float16)x;

@@ -873,8 +873,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
     // operand scales (largest of the partial maxima the producer left)
     float sx = 1.f, sw = 1.f;
     if constexpr (!HALF) {
-        float m = 0.f;
-        for (int i = tid; i < a.x_namax; i += 256) m = fmaxf(m, a.x_amax[i]);
+        const float m = thread_max_of_partials(a.x_amax, a.x_namax, tid, 256);
         sx = pow2_scale(block_max(m, biasS));
         sw = pow2_scale(block_max(tid < WEIGHT_AMAX_SLOTS ? a.w_amax[tid] : 0.f, biasS));
         __syncthreads();
