@@ -61,6 +61,37 @@ struct BsplitArgs {
 
 enum { BS_FWD_ZERO = 0, BS_FWD_REFLECT = 1, BS_DGRAD_REFLECT = 2, BS_WGRAD = 3 };
 
+// one 16-byte entry (8 values) of every piece of a packed weight image: entry e of piece p sits at A + p * per_piece + 8 e
+__device__ __forceinline__ void pack_store8(__bf16* __restrict__ A, size_t e, size_t per_piece, int np, float wscale, const float (&v)[8]) {
+    if (np == 2) {       // two fp16 pieces of the scaled value
+        f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 x, y;
+            split2h(v[j] * wscale, x, y);
+            h[j] = x;
+            l[j] = y;
+        }
+        *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(A) + 8 * e) = h;
+        *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(A) + per_piece + 8 * e) = l;
+        return;
+    }
+    bf16x8 h, mm, l;     // np == 1: the weight rounded to nearest-even bf16; np == 3: the exact three-piece split
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 x, y, z;
+        split3(v[j], x, y, z);
+        h[j] = x;
+        mm[j] = y;
+        l[j] = z;
+    }
+    *reinterpret_cast<bf16x8*>(A + 8 * e) = h;
+    if (np == 3) {
+        *reinterpret_cast<bf16x8*>(A + per_piece + 8 * e) = mm;
+        *reinterpret_cast<bf16x8*>(A + 2 * per_piece + 8 * e) = l;
+    }
+}
+
 // weights w[M][C][R][S] -> [piece][mt][stage][half][BM][8] bf16 (BM = 128 << bm_shift), stage = chunk * T + tap, k in stage =
 // channel in chunk
 // np = 2: two fp16 pieces of w * pow2_scale(*amax) (the fp16 route)
@@ -74,26 +105,16 @@ __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restri
     const float wscale = np == 2 ? wscale_s : 1.f;
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nMt * nst * 16 * BM;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_piece; i += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 7), row = (int)((i >> 3) & (BM - 1)), half = (int)((i >> (10 + bm_shift)) & 1);
-        const size_t q = i >> (11 + bm_shift);
+    // a thread builds one 16-byte entry (8 consecutive channels of a row and tap) of every piece: 8 loads in flight, one store per piece
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < per_piece / 8; e += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(e & (BM - 1)), half = (int)((e >> (7 + bm_shift)) & 1);
+        const size_t q = e >> (8 + bm_shift);
         const int st = (int)(q % nst), mt = (int)(q / nst);
-        const int m = mt * BM + row, c = (st / T) * 16 + half * 8 + j, tap = st % T;
-        const float v = m < M ? w[((size_t)m * C + c) * T + tap] : 0.f;
-        if (np == 2) {
-            _Float16 h, l;
-            split2h(v * wscale, h, l);
-            reinterpret_cast<_Float16*>(A)[i] = h;
-            reinterpret_cast<_Float16*>(A)[per_piece + i] = l;
-            continue;
-        }
-        __bf16 h, mm, l;
-        split3(v, h, mm, l);
-        A[i] = h;                      // (np == 1: the weight rounded to nearest-even bf16)
-        if (np == 3) {
-            A[per_piece + i] = mm;
-            A[2 * per_piece + i] = l;
-        }
+        const int m = mt * BM + row, c0 = (st / T) * 16 + half * 8, tap = st % T;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = m < M ? w[((size_t)m * C + c0 + j) * T + tap] : 0.f;
+        pack_store8(A, e, per_piece, np, wscale, v);
     }
 }
 
@@ -245,8 +266,9 @@ __global__ void bsplit_wgrad_reduce_kernel(const float* __restrict__ part, float
 // k = (16-chunk of output channels, tap (r', s'), channel), value = wf[c][k][r'][s'] = w[k][c][2-r'][2-s'] with the row mirror
 // folded in: row class 1 (row 1) reads row 0 through tap r'=0 for itself AND for padded row -1: wf'[0] = wf[0] + wf[2];
 // row class 2 (row H-2): wf'[2] = wf[2] + wf[0].
+// nphase = 1: only row class 0, the plain flipped weights (all the window kernel reads)
 __global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int K, int C, int nMt, int nst, int bm_shift,
-                                         int np, const float* __restrict__ amax = nullptr) {
+                                         int np, const float* __restrict__ amax = nullptr, int nphase = 3) {
     __shared__ float wscale_s;      // the scale of the fp16 route: one thread reduces the partial maxima for its workgroup
     if (np == 2) {
         if (threadIdx.x == 0) wscale_s = pow2_scale(max_of_partials(amax, WEIGHT_AMAX_SLOTS));
@@ -255,36 +277,29 @@ __global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __
     const float wscale = np == 2 ? wscale_s : 1.f;
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nMt * nst * 16 * BM, per_phase = (size_t)np * per_piece;
-    // (3 row classes x per_piece entries; each entry writes its np pieces)
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 3 * per_piece; i += (size_t)gridDim.x * blockDim.x) {
-        const int phase = (int)(i / per_piece);
-        const size_t e = i - (size_t)phase * per_piece;
-        const int j = (int)(e & 7), row = (int)((e >> 3) & (BM - 1)), half = (int)((e >> (10 + bm_shift)) & 1);
-        const size_t q = e >> (11 + bm_shift);
+    // (nphase row classes x per_piece / 8 entries of 8 values; each entry writes its np pieces.  A folded row-class weight is at most
+    // twice the largest weight: still far inside the fp16 range)
+    const size_t per_phase8 = per_piece / 8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)nphase * per_phase8; i += (size_t)gridDim.x * blockDim.x) {
+        const int phase = (int)(i / per_phase8);
+        const size_t e = i - (size_t)phase * per_phase8;
+        const int row = (int)(e & (BM - 1)), half = (int)((e >> (7 + bm_shift)) & 1);
+        const size_t q = e >> (8 + bm_shift);
         const int st = (int)(q % nst), mt = (int)(q / nst);
-        const int c = mt * BM + row, k = (st / 9) * 16 + half * 8 + j, tap = st % 9;
+        const int c = mt * BM + row, k0 = (st / 9) * 16 + half * 8, tap = st % 9;
         const int rp = tap / 3, sp = tap - rp * 3;
-        float v = 0.f;
-        if (c < C) {
-            const float* wk = w + ((size_t)k * C + c) * 9;
-            v = wk[(2 - rp) * 3 + (2 - sp)];
-            if ((phase == 1 && rp == 0) || (phase == 2 && rp == 2)) v += wk[rp * 3 + (2 - sp)];   // + wf[2 - rp][sp]
+        const bool fold = (phase == 1 && rp == 0) || (phase == 2 && rp == 2);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = 0.f;
+            if (c < C) {
+                const float* wk = w + ((size_t)(k0 + j) * C + c) * 9;
+                v[j] = wk[(2 - rp) * 3 + (2 - sp)];
+                if (fold) v[j] += wk[rp * 3 + (2 - sp)];   // + wf[2 - rp][sp]
+            }
         }
-        __bf16* out = A + (size_t)phase * per_phase;
-        if (np == 2) {     // (a folded row-class weight is at most twice the largest weight: still far inside the fp16 range)
-            _Float16 h, l;
-            split2h(v * wscale, h, l);
-            reinterpret_cast<_Float16*>(out)[e] = h;
-            reinterpret_cast<_Float16*>(out)[per_piece + e] = l;
-            continue;
-        }
-        __bf16 h, mm, l;
-        split3(v, h, mm, l);
-        out[e] = h;
-        if (np == 3) {
-            out[per_piece + e] = mm;
-            out[2 * per_piece + e] = l;
-        }
+        pack_store8(A + (size_t)phase * per_phase, e, per_piece, np, wscale, v);
     }
 }
 
@@ -1399,7 +1414,7 @@ extern "C" int pcgan_conv2d_bsplit_pack(const pcgan_conv_desc* d, const float* w
     const int bm = bsplit_bm(d);
     const int T = d->R * d->S, nMt = (d->K + bm - 1) / bm, nst = (d->C / 16) * T;
     const size_t per_piece = (size_t)nMt * nst * 16 * bm;
-    const int blocks = (int)((per_piece + 255) / 256 > 4096 ? 4096 : (per_piece + 255) / 256);
+    const int blocks = (int)((per_piece / 8 + 255) / 256 > 4096 ? 4096 : (per_piece / 8 + 255) / 256);      // 8 values per thread
     hipLaunchKernelGGL(pcgan::bsplit_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (__bf16*)packed, d->K, d->C, T, nMt, nst,
                        bm == 256 ? 1 : 0, pcgan::np_of(d));
     PCGAN_LAUNCH_CHECK();
@@ -1462,7 +1477,7 @@ extern "C" int pcgan_conv2d_bsplit_dgrad_pack(const pcgan_conv_desc* d, const fl
     PCGAN_CHECK(w && packed, "conv2d_bsplit_dgrad_pack: null pointer");
     const int bm = bsplit_dgrad_bm(d);
     const int nMt = (d->C + bm - 1) / bm, nst = (d->K / 16) * 9;
-    const size_t total = 3 * (size_t)nMt * nst * 16 * bm;
+    const size_t total = 3 * (size_t)nMt * nst * 2 * bm;      // 16-byte entries of the three row classes
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(pcgan::bsplit_pack_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (__bf16*)packed, d->K, d->C, nMt, nst,
                        bm == 256 ? 1 : 0, pcgan::np_of(d));
@@ -1591,12 +1606,12 @@ extern "C" int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const vo
 }
 
 // ---- fp16 two-piece route of the reflection-padded 3x3 convolution (forward + data gradient), fp32 tensors -------------------------
-// packed buffer: [2 pieces][M tile][stage][k half][256 rows][8 fp16] (data gradient: three row classes of it, the window kernel reads
-// the first) followed by 256 bytes: 64 partial maxima of |w|
+// packed buffer: [2 pieces][M tile][stage][k half][256 rows][8 fp16] (data gradient: the plain flipped weights -- the window kernel
+// has no row classes) followed by 256 bytes: 64 partial maxima of |w|
 static size_t hsplit_body_bytes(const pcgan_conv_desc* d, int pass) {
     const int rows = pass == PCGAN_PASS_FWD ? d->K : d->C, chan = pass == PCGAN_PASS_FWD ? d->C : d->K;
     const size_t nMt = (rows + 255) / 256, nst = (size_t)(chan / 16) * 9;
-    return (pass == PCGAN_PASS_FWD ? 1 : 3) * 2 * nMt * nst * 32 * 256;
+    return 2 * nMt * nst * 32 * 256;
 }
 
 extern "C" int pcgan_conv2d_hsplit_supported(const pcgan_conv_desc* d, int pass) {
@@ -1638,13 +1653,13 @@ extern "C" int pcgan_conv2d_hsplit_pack(const pcgan_conv_desc* d, int pass, cons
     if (pass == PCGAN_PASS_FWD) {
         const int nMt = (d->K + 255) / 256, nst = (d->C / 16) * 9;
         const size_t per_piece = (size_t)nMt * nst * 16 * 256;
-        const int blocks = (int)((per_piece + 255) / 256 > 4096 ? 4096 : (per_piece + 255) / 256);
+        const int blocks = (int)((per_piece / 8 + 255) / 256 > 4096 ? 4096 : (per_piece / 8 + 255) / 256);
         hipLaunchKernelGGL(pcgan::bsplit_pack_kernel, dim3(blocks), dim3(256), 0, st, w, (__bf16*)packed, d->K, d->C, 9, nMt, nst, 1, 2, amax);
     } else {
         const int nMt = (d->C + 255) / 256, nst = (d->K / 16) * 9;
-        const size_t total = 3 * (size_t)nMt * nst * 16 * 256;
+        const size_t total = (size_t)nMt * nst * 2 * 256;       // 16-byte entries of one row class
         const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-        hipLaunchKernelGGL(pcgan::bsplit_pack_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w, (__bf16*)packed, d->K, d->C, nMt, nst, 1, 2, amax);
+        hipLaunchKernelGGL(pcgan::bsplit_pack_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w, (__bf16*)packed, d->K, d->C, nMt, nst, 1, 2, amax, 1);
     }
     PCGAN_LAUNCH_CHECK();
     return 0;
@@ -1678,7 +1693,7 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void
     h.X = dy; h.A = packed; h.bias = nullptr; h.Y = dx;
     h.N = d->N; h.C = d->K; h.H = d->H; h.M = d->C; h.nMt = (d->C + 255) / 256; h.nch = d->K / 16; h.act = PCGAN_ACT_NONE; h.slope = 0.f;
     h.x_bytes = (unsigned)((size_t)d->N * d->K * d->H * d->W * 4);
-    h.a_bytes = (unsigned)(body / 3);        // plain flipped weights = row class 0
+    h.a_bytes = (unsigned)body;              // plain flipped weights
     h.x_amax = dy_amax;
     h.x_namax = n_amax;
     h.w_amax = (const float*)((const char*)packed + body);
