@@ -17,6 +17,7 @@ forward launches inside the timed region is bracketed by HIP events on the launc
 `cpu_baseline` = the oracle's PyTorch-CPU step on this host's cores, bounded sample.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -145,7 +146,8 @@ def main():
     device = torch.device('cuda', dev_index)
 
     tmpdir = tempfile.mkdtemp(prefix='pcgan_bench_')
-    model, opt = build_model(dev_index, PER_GPU_BATCH, SIZE, tmpdir, dtype=args.dtype)
+    with contextlib.redirect_stdout(sys.stderr):      # the reference's 'initialize network with ...' notices: stdout carries the JSON line only
+        model, opt = build_model(dev_index, PER_GPU_BATCH, SIZE, tmpdir, dtype=args.dtype)
     batches = [synthetic_batch(PER_GPU_BATCH, SIZE, rank, it) for it in range(2)]
     # inputs resident in HBM before the timed region (set_input's .to(device) is then a no-op copy)
     batches = [{k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in b.items()} for b in batches]
