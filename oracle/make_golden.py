@@ -270,6 +270,59 @@ def golden_visuals(rn, outdir):
     print('visuals.npz: %d arrays, visuals %s' % (len(out), list(vis.keys())))
 
 
+SAMPLER_VARIANTS = ('default', 'noisy_a', 'bayesian_e')
+
+
+def golden_samplers(rn, outdir):
+    """sample_from_prior() / sample_from_label(l) of wsgan_emb (models/wsgan_emb_model.py:279-298), the reference's own
+    methods on the tiny config: the image generated from the encoder's rating of real_B, and one image per fixed rating bin.
+    Both run G (and E) in TRAIN mode as the reference does (train.py never calls eval()), so the InstanceNorm / BatchNorm
+    running statistics move; recorded: the images, embedding_B and the G / E buffer checksums afterwards.  The noisy / bayesian
+    branches read `self.real_B_E`, an attribute only forward() sets (:281-288), so forward() runs first in every variant."""
+    from options.train_options import TrainOptions
+    from models import create_model
+    tmp = tempfile.mkdtemp(prefix='pcgan_golden_samp_')
+    out = {}
+    for name in SAMPLER_VARIANTS:
+        extra = STEP_VARIANTS[name]
+        noisy = '--noisy' in extra and extra[extra.index('--noisy') + 1] == 'true'
+        drop = 0.2 if '--bnn_dropout' in extra else 0.0
+        e = rn.SiameseFeature(rn.ResNetFeature(3, 'resnet18', dropout=drop), pooling='avg', cnn_dim=[32, 1], cnn_pad=1,
+                              cnn_relu_slope=0.7, noisy=noisy, drop_layer=rn.get_dropout_layer(drop))
+        e_path = os.path.join(tmp, 'E_%s.pth' % name)
+        torch.save(W.fill_state_dict(e.state_dict(), 30), e_path)
+        ip = rn.AlexNetFeature(input_nc=3, pooling='None')
+        ip_path = os.path.join(tmp, 'IP.pth')
+        torch.save(W.fill_state_dict(ip.state_dict(), 40), ip_path)
+        sys.argv = ['train.py', '--dataroot', tmp, '--model', 'wsgan_emb', '--name', 'g_samp_' + name, '--checkpoints_dir', tmp,
+                    '--gpu_ids', '-1', '--which_model_netG', 'resnet_9blocks', '--which_model_netD', 'n_layers', '--n_layers_D', '3',
+                    '--ngf', '8', '--ndf', '8', '--fineSize', '32', '--loadSize', '32', '--fineSize_E', '64', '--fineSize_IP', '64',
+                    '--batchSize', '4', '--pretrained_model_path_E', e_path, '--pretrained_model_path_IP', ip_path,
+                    '--display_id', '-1', '--embedding_bins', '[-1.0, 0.0, 1.5]', '--embedding_mean', '0.1',
+                    '--embedding_std', '0.8'] + extra
+        opt = TrainOptions().parse()
+        model = create_model(opt)
+        model.setup(opt)
+        model.netG.load_state_dict(W.damp_generator_head(W.fill_state_dict(model.netG.state_dict(), 19)))
+        model.netD.load_state_dict(W.fill_state_dict(model.netD.state_dict(), 20))
+        torch.manual_seed(1234)
+        model.set_input(step_batch(name, 0))
+        model.forward()
+        torch.manual_seed(777)                   # the MC-dropout passes of the bayesian sampler draw from here
+        with torch.no_grad():
+            out[name + '/prior'] = t2n(model.sample_from_prior())
+            out[name + '/embedding_B'] = t2n(model.embedding_B)
+            for label in range(3):
+                out['%s/label%d' % (name, label)] = t2n(model.sample_from_label(label))
+        for tag, net in (('G', model.netG), ('E', model.netE)):
+            for k, v in net.state_dict().items():
+                if 'running' in k or 'num_batches' in k:
+                    a = t2n(v).astype(np.float64)
+                    out['%s/after%s/%s' % (name, tag, k)] = np.array([a.sum(), np.abs(a).sum()])
+    np.savez_compressed(os.path.join(outdir, 'samplers.npz'), **out)
+    print('samplers.npz: %d arrays' % len(out))
+
+
 def golden_cycle_step(rn, outdir):
     """wsgan_cycle: optimize_parameters() x2 through the reference's own parser and model class:
     unconditional D, trained ResNet-18 encoder (max pooling, cnn_dim [64, 1]), resnet generator."""
@@ -512,6 +565,8 @@ if __name__ == '__main__':
         golden_steps(rn, a.out, [v for v in a.variants.split(',') if v] or None)
     if a.only in ('', 'visuals'):
         golden_visuals(rn, a.out)
+    if a.only in ('', 'samplers'):
+        golden_samplers(rn, a.out)
     if a.only in ('', 'cycle'):
         golden_cycle_step(rn, a.out)
     if a.only in ('', 'siamese'):

@@ -154,6 +154,27 @@ class WSGANEmbStepRef:
             p.requires_grad = True
         return ret
 
+    def sample_from_prior(self):
+        """models/wsgan_emb_model.py:279-292: the rating of real_B (the noisy / bayesian branches read the real_B_E attribute
+        that forward() left) -> normalised -> G(real_A, rating)"""
+        o = self.opt
+        real_B_E = upsample2d(self.real_B, o.fineSize_E)
+        if not o.bayesian and not o.noisy:
+            y_B = self.netE(real_B_E)
+        elif not o.bayesian and o.noisy:
+            y_B, _ = self.netE(self.real_B_E)
+        elif o.bayesian and not o.noisy:
+            y_B, _ = self.compute_mu_and_var(self.real_B_E, o.bnn_T, False)
+        else:
+            y_B, _, _ = self.compute_mu_and_var(self.real_B_E, o.bnn_T, True)
+        self.embedding_B = self.embedding_normalize(y_B.detach())
+        return self.netG(self.real_A, self.embedding_B)
+
+    def sample_from_label(self, label, embedding_bins):
+        """models/wsgan_emb_model.py:294-298: the bin centre of `label` as a (1, 1, 1, 1) rating broadcast over the batch"""
+        emb_B = torch.tensor([float(embedding_bins[label])], dtype=self.real_A.dtype).reshape(1, 1, 1, 1)
+        return self.netG(self.real_A, self.embedding_normalize(emb_B))
+
     def forward(self):
         """models/wsgan_emb_model.py:214-259 (transform_E / transform_IP are identities)"""
         o = self.opt

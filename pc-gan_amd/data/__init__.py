@@ -101,12 +101,21 @@ class CustomDatasetDataLoader(object):
         collate = _collate_keep_raw if self.gpu_transform else None
         self.sampler = None
         if world > 1:
-            seed = shared_seed(opt)
-            # the data set reshuffles its pair list whenever its length is taken (reference quirk kept): with a shared
-            # generator every rank holds the same list order, so index i means the same pair everywhere
-            self.dataset.shuffle_rng = random.Random(seed)
-            self.sampler = RankShardedBatchSampler(min(len(self.dataset), opt.max_dataset_size), opt.batchSize, world, rank,
-                                                   not opt.serial_batches, seed)
+            seed = self.seed = shared_seed(opt)
+            # the data set reshuffles its pair list whenever its length is taken (reference quirk); here every rank must hold the
+            # same list order (index i = the same pair everywhere), so the loader reshuffles once per epoch from __iter__ with a
+            # generator keyed by (shared seed, epoch) and a bare len() -- rank-0-only logging -- changes nothing
+            self.dataset.external_shuffle = True
+            n_samples = min(len(self.dataset), opt.max_dataset_size)
+            # everything drawn PER SAMPLE must differ between ranks (DataParallel draws crop / flip / resample noise / dropout
+            # independently over the global batch): python's and torch's generators -- and through torch's the DataLoader's
+            # worker base seed -- continue from seed + rank.  numpy's global generator stays shared: --no_mixed_label_D draws ONE
+            # label for the whole global batch from it (reference models/wsgan_emb_model.py:199-207).
+            random.seed(seed * 1000003 + rank + 1)
+            torch.manual_seed(seed * 1000003 + rank + 1)
+            import numpy as np
+            np.random.seed(seed % (1 << 32))
+            self.sampler = RankShardedBatchSampler(n_samples, opt.batchSize, world, rank, not opt.serial_batches, seed)
             self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_sampler=self.sampler, num_workers=int(opt.nThreads),
                                                           collate_fn=collate)
         else:
@@ -133,7 +142,7 @@ class CustomDatasetDataLoader(object):
     def __iter__(self):
         if self.sampler is not None:
             # one reshuffle of the pair list per epoch, in the parent and BEFORE the workers fork: identical on every rank
-            len(self.dataset)
+            self.dataset.reshuffle(random.Random(self.seed * 7919 + self._epochs))
             self.sampler.set_epoch(self._epochs)
             self._epochs += 1
         seen = 0

@@ -59,9 +59,14 @@ class WSGANCycleDataset(BaseDataset):
             A = (A[0] * 0.299 + A[1] * 0.587 + A[2] * 0.114).unsqueeze(0)
         return {'A': A, 'B_attr': B_attr, 'A_paths': A_path, 'B_paths': B_path}
 
+    def reshuffle(self, rng=random):
+        if not self.synthetic:
+            rng.shuffle(self.A_paths)
+            rng.shuffle(self.B_paths)
+
     def __len__(self):
-        if not self.synthetic:      # the reference reshuffles both lists every time len() is taken (:53-59)
-            shuffle = (getattr(self, 'shuffle_rng', None) or random).shuffle    # shared generator under torch.distributed
-            shuffle(self.A_paths)
-            shuffle(self.B_paths)
+        # the reference reshuffles both lists every time len() is taken (:53-59); under torch.distributed the loader does it once
+        # per epoch with a generator shared by all ranks (`external_shuffle`, data/__init__.py) and len() leaves the lists alone
+        if not getattr(self, 'external_shuffle', False):
+            self.reshuffle()
         return max(self.A_size, self.B_size)

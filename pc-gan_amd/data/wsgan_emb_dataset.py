@@ -82,14 +82,21 @@ class WSGANEmbDataset(BaseDataset):
             ret[str(L) + '_A_paths'], ret[str(L) + '_B_paths'] = pa, pb
         return ret
 
+    def reshuffle(self, rng=random):
+        """the reference's pair-list reshuffle (wsgan_emb_dataset.py:72-79), with the generator given"""
+        if self.synthetic:
+            return
+        if not self.opt.no_mixed_label_D:
+            rng.shuffle(self.sourcefile)
+        else:
+            for L in self.sourcefiles:
+                rng.shuffle(self.sourcefiles[L])
+
     def __len__(self):
-        # the reference reshuffles its pair list every time len() is taken (wsgan_emb_dataset.py:72-79); under
-        # torch.distributed the loader installs a generator shared by all ranks (data/__init__.py)
-        if not self.synthetic:
-            shuffle = (getattr(self, 'shuffle_rng', None) or random).shuffle
-            if not self.opt.no_mixed_label_D:
-                shuffle(self.sourcefile)
-            else:
-                for L in self.sourcefiles:
-                    shuffle(self.sourcefiles[L])
+        # the reference reshuffles its pair list every time len() is taken (wsgan_emb_dataset.py:72-79).  Under
+        # torch.distributed every rank must hold the same list order, so the loader takes that over (`external_shuffle`:
+        # one reshuffle per epoch from __iter__ with a generator keyed by (shared seed, epoch), data/__init__.py) and len()
+        # -- which a single rank may call on its own, e.g. for logging -- leaves the list alone
+        if not getattr(self, 'external_shuffle', False):
+            self.reshuffle()
         return self.size

@@ -335,13 +335,21 @@ _FLAG_POOL_SIZE = 1 << 16
 def _keep_flags(n, p, device):
     if n > _FLAG_POOL_SIZE // 4:
         return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(1.0 - p)
-    key = (device, float(p), torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+    # (the generator's seed in the key: after torch.manual_seed() leftover flags of the old stream are not handed out any more, so
+    # a seeded MC-dropout run is reproducible from its seed)
+    key = (device, float(p), torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0,
+           torch.cuda.initial_seed() if device.type == 'cuda' else torch.initial_seed())
     ent = _FLAG_POOL.get(key)
     if ent is None or ent[1] + n > _FLAG_POOL_SIZE:
         ent = _FLAG_POOL[key] = [torch.empty(_FLAG_POOL_SIZE, dtype=torch.float32, device=device).bernoulli_(1.0 - p), 0]
     o = ent[1]
     ent[1] = o + n
     return ent[0][o:o + n]
+
+
+def reset_flag_pool():
+    """drop every pre-drawn keep flag (call after re-seeding by other means than torch.manual_seed, e.g. set_rng_state)"""
+    _FLAG_POOL.clear()
 
 
 # ---------------------------------------------------------------------------- pooling / resize

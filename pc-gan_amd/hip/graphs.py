@@ -13,8 +13,11 @@ Dropout2d inside a captured net: the keep flags of every site are slices of ONE 
 
 Not used while autograd is recording, while a parity test injects masks (`Dropout2d.mask_source`), under torch.distributed, or with
 PCGAN_GRAPH_NOGRAD=0.
-A capture is tied to the packed-weight epoch: anything that re-packs every weight (load_networks, broadcast) starts over with
-eager calls."""
+A capture is tied to the packed-weight epoch, to the train / eval mode of every sub-module and to the versions of the parameters and
+buffers it reads: anything that re-packs every weight (load_networks, broadcast), `net.eval()` / `net.train()`, or a direct
+`load_state_dict` / `load_pretrained` starts over with eager calls instead of replaying the other mode's launches or stale packed
+weights.  A capture that fails (out of the flag arena, an op that cannot be captured) marks its key "eager only": the call is served by
+fn(x) and never retried."""
 import os
 
 import torch
@@ -38,8 +41,8 @@ def _map(out, f):
 class FlagArena(object):
     """static keep-flag storage of the Dropout2d sites of one captured forward"""
 
-    def __init__(self, device, size=1 << 17):
-        self.buf = torch.ones(size, dtype=torch.float32, device=device)
+    def __init__(self, device, size):
+        self.buf = torch.ones(max(int(size), 1), dtype=torch.float32, device=device)
         self.used = 0
         self.p = None
 
@@ -48,12 +51,27 @@ class FlagArena(object):
         self.p = p
         o = self.used
         self.used = o + n
-        assert self.used <= self.buf.numel(), 'flag arena too small'
+        if self.used > self.buf.numel():     # (sized from the warm-up calls: only a net whose dropout sites change between calls gets here)
+            raise RuntimeError('pcgan_amd: dropout flag arena too small (%d > %d)' % (self.used, self.buf.numel()))
         return self.buf[o:o + n]
 
     def refill(self):
         if self.used:
             self.buf[:self.used].bernoulli_(1.0 - self.p)
+
+
+def _module_stamp(fn):
+    """(train / eval pattern, parameter versions) of a module: what a captured launch sequence silently depends on.  Buffers are
+    left out on purpose: a train-mode pass updates its own running statistics in place, through raw pointers, inside the replay."""
+    if not isinstance(fn, torch.nn.Module):
+        return None
+    mode = 0
+    for m in fn.modules():
+        mode = (mode * 3 + (1 if m.training else 2)) % 1000000007
+    ver = 0
+    for p_ in fn.parameters():      # (tensor version: load_state_dict / copy_; _pcgan_wepoch: an optimizer writing through raw pointers)
+        ver += p_._version + p_.__dict__.get('_pcgan_wepoch', 0) + (p_.data_ptr() & 0xffff)
+    return mode, ver
 
 
 class GraphedNoGrad(object):
@@ -66,24 +84,40 @@ class GraphedNoGrad(object):
         if (not ENABLED or torch.is_grad_enabled() or not (isinstance(x, torch.Tensor) and x.is_cuda)
                 or hnn.Dropout2d.mask_source is not None or torch.cuda.is_current_stream_capturing() or parallel.is_distributed()):
             return self.fn(x)      # (under torch.distributed: RCCL's watchdog thread and stream capture do not mix; eager there)
-        key = (tuple(x.shape), x.dtype, ops._PACK_EPOCH[0], ops.BF16X6, ops.HSPLIT, ops.HGEMM, ops.BSPLIT_MIN_PIXELS)
+        key = (tuple(x.shape), x.dtype, ops._PACK_EPOCH[0], ops.BF16X6, ops.HSPLIT, ops.HGEMM, ops.BSPLIT_MIN_PIXELS, _module_stamp(self.fn))
         ent = self.state.get(key)
         if ent is None:
-            if len(self.state) > 8:      # shapes keep changing (a last partial batch, ...): do not hoard graph pools
+            if len(self.state) > 8:      # shapes / modes keep changing (a last partial batch, ...): do not hoard graph pools
                 self.state.clear()
-            ent = self.state[key] = {'calls': 0}
+            ent = self.state[key] = {'calls': 0, 'flags': 0}
+        if ent.get('eager_only'):
+            STATS['eager'] += 1
+            return self.fn(x)
         if 'graph' not in ent:
             if ent['calls'] < self.warm:
                 ent['calls'] += 1
                 STATS['eager'] += 1
-                return self.fn(x)
+                hnn.Dropout2d.flag_demand = demand = [0]      # how many keep flags one pass draws (sizes the capture's arena)
+                try:
+                    return self.fn(x)
+                finally:
+                    hnn.Dropout2d.flag_demand = None
+                    ent['flags'] = max(ent['flags'], demand[0])
             inp = x.clone()
-            arena = FlagArena(x.device)
+            arena = FlagArena(x.device, ent['flags'] if ent['calls'] > 0 else 1 << 17)      # (no warm-up call measured the demand: a generous default)
             g = torch.cuda.CUDAGraph()
             hnn.Dropout2d.flag_arena = arena
             try:
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     out = self.fn(inp)
+            except Exception as exc:      # never abort training over an optimisation: this key stays eager
+                ent['eager_only'] = True
+                STATS['capture_failed'] = STATS.get('capture_failed', 0) + 1
+                import warnings
+                warnings.warn('pcgan_amd: hipGraph capture of a no-grad pass failed (%s); this shape runs eagerly' % (exc,))
+                hnn.Dropout2d.flag_arena = None
+                torch.cuda.synchronize()
+                return self.fn(x)
             finally:
                 hnn.Dropout2d.flag_arena = None
             ent.update(graph=g, inp=inp, out=out, arena=arena)

@@ -65,10 +65,13 @@ class Dropout2d(tnn.Dropout2d):
     order) lets a parity test replay the masks the oracle drew."""
     mask_source = None
     flag_arena = None      # hip/graphs.py: static flag storage while a forward is captured into a hipGraph
+    flag_demand = None     # hip/graphs.py: [count] -- the warm-up calls add the flags every site draws (sizes the arena)
 
     def forward(self, x):
         mask = None
         if self.training and self.p > 0:
+            if Dropout2d.flag_demand is not None:
+                Dropout2d.flag_demand[0] += x.shape[0] * x.shape[1]
             if Dropout2d.mask_source is not None:
                 mask = next(Dropout2d.mask_source).to(device=x.device, dtype=torch.float32)
             elif Dropout2d.flag_arena is not None:

@@ -227,6 +227,12 @@ HGEMM = os.environ.get('PCGAN_HGEMM', '1') == '1'
 
 
 AMAX_STATS = {'attached': 0, 'computed': 0}     # operand maxima handed over by the producing kernel / taken by an absmax pass
+ROUTE_STATS = {}     # (pass, route) -> number of convolution calls that took it: tests assert the kernels under test are the production ones
+
+
+def _count_route(pass_, route):
+    k = (pass_, route)
+    ROUTE_STATS[k] = ROUTE_STATS.get(k, 0) + 1
 
 
 def _want_maxima(dt, C):
@@ -399,6 +405,7 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
     ws = _ws(pl.ws_bytes, x.device)
     if pack_cache is not None:
         pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache)
+        _count_route('fwd', pl.route)
         ev = None
         if KERNEL_TIMER is not None and KERNEL_TIMER['key'] == (N, C, H, W, K, R, S, stride, pad, pad_mode):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -440,6 +447,7 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
     ws = _ws(pl.ws_bytes, dy.device)
     if pack_cache is not None:
         pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache)
+        _count_route('dgrad', pl.route)
         if pl.route == 'hsplit':
             dmax = amax_of(dy)
             _L.check(lib.pcgan_conv2d_bwd_data_hsplit(d, _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_hsplit')
@@ -475,6 +483,7 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=N
         dw = torch.empty((K, C, R, S), dtype=torch.float32, device=x.device)
     acc = int(accumulate_into is not None)
     ws = _ws(pl.ws_bytes, x.device)
+    _count_route('wgrad', pl.route)
     if pl.route == 'hsplit':
         if dt == F32:
             xmax, dmax = amax_of(x), amax_of(dy)

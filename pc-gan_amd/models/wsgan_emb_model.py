@@ -25,6 +25,7 @@ from ..hip import parallel
 from ..hip.optim import FusedAdam
 from ..util.util import upsample2d, str2list, str2bool, resample, compute_mu_and_var
 
+_DDP_OVERLAP = os.environ.get('PCGAN_DDP_OVERLAP', '0') == '1'
 _G2_BRANCH = os.environ.get('PCGAN_G2_BRANCH', '0') == '1'
 
 MAGIC_EPS = 1e-20
@@ -399,10 +400,11 @@ class WSGANEmbModel(BaseModel):
 
     def optimize_parameters(self):
         self.forward()
-        if not parallel.is_distributed():
-            self.update_G()
+        if not (parallel.is_distributed() and _DDP_OVERLAP):
+            self.update_G()          # (under torch.distributed each ends in a blocking all-reduce of its flat gradient buffer)
             self.update_D()
             return
+        # PCGAN_DDP_OVERLAP=1 (opt-in until one multi-GPU RCCL run has confirmed bit-equal replicas and the overlap):
         # data parallel: the generator's gradient all-reduce is launched after backward_G and runs under backward_D, which neither
         # reads the generator's weights (fake_B is detached and was computed in forward()) nor touches its gradients; both optimizer
         # steps follow -- same arithmetic as update_G(); update_D() (reference models/wsgan_emb_model.py:451-461, 478-484)

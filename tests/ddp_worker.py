@@ -1,7 +1,8 @@
 """Child process of tests/test_gpu_ddp.py (not a test module): one rank of a data-parallel step of the PRODUCT model.
 
     RANK / WORLD_SIZE / MASTER_* in the environment, PCGAN_DIST_BACKEND=gloo (several ranks share the one GPU of the box).
-    argv: <out.pt> <lo> <hi>   -- this rank steps samples [lo, hi) of the fixed 4-sample batch
+    argv: <out.pt> <lo> <hi> [fp32|bf16]   -- this rank steps samples [lo, hi) of the fixed 4-sample batch, activations stored as given
+    (bf16 x ranks = BASELINE configs[2]); PCGAN_DDP_OVERLAP=1 selects the overlapped all-reduce of the generator's gradients
 
 Writes the flat G / D gradient buffers as they are when each optimizer steps (i.e. after the all-reduce), the flat
 parameter buffers after the step and the losses."""
@@ -17,13 +18,14 @@ import torch  # noqa: E402
 
 def main():
     out, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    dtype = sys.argv[4] if len(sys.argv) > 4 else 'fp32'
     from pcgan_amd.hip import parallel
     import bench
     world, rank, _ = parallel.init_process_group()
     torch.cuda.set_device(0)
     tmp = tempfile.mkdtemp(prefix='pcgan_ddp_%d_' % rank)
     # every rank builds from its own seed: broadcast_parameters must then install rank 0's weights everywhere
-    model, opt = bench.build_model(0, hi - lo, 32, tmp, seed=7 + (rank if world > 1 else 0), ngf=8, ndf=8, fine_e=64, n_blocks=2)
+    model, opt = bench.build_model(0, hi - lo, 32, tmp, seed=7 + (rank if world > 1 else 0), ngf=8, ndf=8, fine_e=64, n_blocks=2, dtype=dtype)
     grabbed = {}
     for tag, optim in (('G', model.optimizer_G), ('D', model.optimizer_D)):
         orig = optim.step

@@ -59,7 +59,7 @@ def _half_step(m, A, B, label, sync):
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     from pcgan_amd.hip import parallel
     from pcgan_amd.hip.optim import FusedAdam
     from pcgan_amd.models import networks
@@ -67,57 +67,75 @@ def _worker(rank, world, port, out):
     assert (w, r) == (world, rank) and parallel.is_distributed()
     # (a) sharding
     full = torch.arange(8).view(8, 1)
-    assert parallel.shard_batch(full).flatten().tolist() == list(range(rank * 4, rank * 4 + 4))
+    per8 = 8 // world
+    assert parallel.shard_batch(full).flatten().tolist() == list(range(rank * per8, rank * per8 + per8))
     # (b) fused optimizer's flat gradient buffer: one all-reduce, average
     D = networks.define_D(3, 1, 8, 'n_layers', 3, 'batch', True, 'normal')
     parallel.broadcast_parameters(D)
     opt = FusedAdam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
     opt.gflat.fill_(float(rank + 1))
     parallel.sync_gradients(opt)
-    assert torch.allclose(opt.gflat, torch.full_like(opt.gflat, 1.5))
+    assert torch.allclose(opt.gflat, torch.full_like(opt.gflat, (world + 1) / 2.0))
+    # ... and the launched-now / waited-later form the overlapped step uses (PCGAN_DDP_OVERLAP=1)
+    opt.gflat.fill_(float(2 * rank))
+    finish = parallel.sync_gradients(opt, async_op=True)
+    finish()
+    assert torch.allclose(opt.gflat, torch.full_like(opt.gflat, float(world - 1)))
     chk = torch.stack([p.detach().sum() for p in D.parameters()]).sum().reshape(1)
-    both = [torch.zeros(1), torch.zeros(1)]
+    both = [torch.zeros(1) for _ in range(world)]
     dist.all_gather(both, chk)
-    assert torch.equal(both[0], both[1]), 'replicas must start from rank 0 weights'
+    assert all(torch.equal(both[0], b) for b in both), 'replicas must start from rank 0 weights'
     # (c) the step on this rank's contiguous slice with averaged gradients
     m = _build_step()
     A = W.seeded_tensor((4, 3, 32, 32), 900)
     B = W.seeded_tensor((4, 3, 32, 32), 901)
     label = [0, 2, 2, 0]
-    sl = slice(rank * 2, rank * 2 + 2)
+    per = 4 // world
+    sl = slice(rank * per, rank * per + per)
     gG, gD = _half_step(m, A[sl], B[sl], label[sl], parallel.sync_gradients)
     # replicas must hold identical weights after the step (same averaged gradients into the same Adam state)
     flat = torch.cat([p.detach().reshape(-1) for net in (m.netG, m.netD) for p in net.parameters()])
-    both = [torch.zeros_like(flat), torch.zeros_like(flat)]
+    both = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
-    assert torch.equal(both[0], both[1]), 'replicas diverged after one step'
+    assert all(torch.equal(both[0], b) for b in both), 'replicas diverged after one step'
     if rank == 0:
         torch.save({'gG': gG, 'gD': gD, 'pG': {k: v.detach() for k, v in m.netG.named_parameters()}}, out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_two_rank_step_equals_single_process_reference(tmp_path):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('world', [2, 4])
+def test_n_rank_step_equals_single_process_reference(tmp_path, world):
+    """world 2: two samples per rank; world 4: ONE sample per rank (per-rank BatchNorm statistics over a single image: the
+    extreme of DataParallel's per-replica statistics)"""
     out = str(tmp_path / 'rank0.pt')
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got = torch.load(out)
     # single-process restatement of "per-rank statistics, averaged gradients"
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)      # (as in the workers: oneDNN's reduction order depends on it)
     A = W.seeded_tensor((4, 3, 32, 32), 900)
     B = W.seeded_tensor((4, 3, 32, 32), 901)
     label = [0, 2, 2, 0]
+
+    def close(g, want, what):
+        if world == 2:
+            assert torch.allclose(g, want, rtol=1e-4, atol=1e-6), what
+        else:      # one image per rank: BatchNorm statistics over a handful of values amplify rounding; judged per tensor
+            err = float((g.double() - want.double()).norm() / (want.double().norm() + 1e-12))
+            assert err <= 1e-3 or float((g - want).abs().max()) <= 1e-6, '%s: relative L2 %.3e' % (what, err)
     halves = []
-    for r in range(2):
+    per = 4 // world
+    for r in range(world):
         m = _build_step()
-        sl = slice(r * 2, r * 2 + 2)
+        sl = slice(r * per, r * per + per)
         halves.append(_half_step(m, A[sl], B[sl], label[sl], lambda o: None))
     for k, g in got['gG'].items():
-        want = 0.5 * (halves[0][0][k] + halves[1][0][k])
-        assert torch.allclose(g, want, rtol=1e-4, atol=1e-6), 'G grad ' + k
+        want = sum(h[0][k] for h in halves) / world
+        close(g, want, 'G grad ' + k)
     # backward_D runs on fake_B from forward() (made BEFORE the G step, models/wsgan_emb_model.py:478-484) and on D's own
     # weights, so the D gradients do not depend on how G was stepped in between: they are comparable term by term too
     assert set(got['gD']) == set(halves[0][1])
     for k, g in got['gD'].items():
-        want = 0.5 * (halves[0][1][k] + halves[1][1][k])
-        assert torch.allclose(g, want, rtol=1e-4, atol=1e-6), 'D grad ' + k
+        want = sum(h[1][k] for h in halves) / world
+        close(g, want, 'D grad ' + k)

@@ -106,15 +106,34 @@ def _check_buffers(tag, hip_net, ref_net, tol=1e-3):
             assert_close(v, rsd[k], tol, '%s %s after the step' % (tag, k), atol=1e-5)
 
 
-@pytest.fixture(autouse=True)
-def _route_like_the_real_batch(monkeypatch):
-    """configs 4 / 5 run at batch 8 / 16 (32768 / 65536 output pixels per residual convolution: the matrix-pipe split kernels);
-    the batch of 2 used here would stay under the host's routing threshold -- lower it so the same kernels are under test"""
+@pytest.fixture
+def production_route(monkeypatch):
+    """configs 4 / 5 run at batch 8 / 16 (32768 / 65536 output pixels per residual convolution: the matrix-pipe window / split
+    kernels at image width 64); the batch of 2 used here would stay under the host's routing threshold -- lower it so the same
+    kernels are under test.  Both tests REQUEST this fixture by name and assert afterwards (`_assert_production_route`) that
+    the residual convolutions really went that way and that their operand maxima came from the norm kernels."""
     from pcgan_amd.hip import ops
     monkeypatch.setattr(ops, 'BSPLIT_MIN_PIXELS', 0)
+    assert ops._plan(ops._L.PASS_FWD, BATCH, 256, 64, 64, 256, 3, 3, 1, 1, 1, ops.F32).route == 'hsplit'
+    assert ops._plan(ops._L.PASS_BWD_DATA, BATCH, 256, 64, 64, 256, 3, 3, 1, 1, 1, ops.F32).route == 'hsplit'
+    assert ops._plan(ops._L.PASS_BWD_WEIGHT, BATCH, 256, 64, 64, 256, 3, 3, 1, 1, 1, ops.F32).route == 'hsplit'
+    return dict(ops.ROUTE_STATS), dict(ops.AMAX_STATS)
 
 
-def test_config4_bayesian_noisy_256(tmp_path, dev):
+def _assert_production_route(before, g_passes):
+    """the 18 residual convolutions of every generator pass ran forward, data gradient AND weight gradient on the window /
+    split kernels of the fp16 route (`hsplit`: bsplit_halo_kernel<..., 64>, hsplit_wgrad_kernel), with the operand maxima handed
+    over by the instance-norm kernels"""
+    from pcgan_amd.hip import ops
+    routes0, amax0 = before
+    for pass_ in ('fwd', 'dgrad', 'wgrad'):
+        n = ops.ROUTE_STATS.get((pass_, 'hsplit'), 0) - routes0.get((pass_, 'hsplit'), 0)
+        assert n >= 18 * g_passes, 'residual convolutions on the hsplit route, %s: %d < %d (%s)' % (pass_, n, 18 * g_passes, dict(ops.ROUTE_STATS))
+    attached = ops.AMAX_STATS['attached'] - amax0['attached']
+    assert attached >= 18 * g_passes * 4, ops.AMAX_STATS
+
+
+def test_config4_bayesian_noisy_256(tmp_path, dev, production_route):
     from pcgan_amd.hip import nn as hnn
     from pcgan_amd.models import networks
     from pcgan_amd.util import util as hutil
@@ -166,9 +185,10 @@ def test_config4_bayesian_noisy_256(tmp_path, dev):
     _check_grads('D', grabbed['D'], oracle.grads_D)
     for tag, hn, on in (('G', model.netG, G), ('D', model.netD, D), ('E', model.netE, E)):
         _check_buffers(tag, hn, on)
+    _assert_production_route(production_route, 2)
 
 
-def test_config5_cycle_256(tmp_path, dev):
+def test_config5_cycle_256(tmp_path, dev, production_route):
     from pcgan_amd.models import networks
     tmp = str(tmp_path)
     torch.manual_seed(12)
@@ -204,3 +224,4 @@ def test_config5_cycle_256(tmp_path, dev):
         _check_grads(tag, grabbed[tag], oracle.grads[tag])
     for tag, hn, on in (('G', model.netG, G), ('D', model.netD, D), ('E', model.netE, E)):
         _check_buffers(tag, hn, on)
+    _assert_production_route(production_route, 2)

@@ -31,10 +31,11 @@ def _free_port():
     return p
 
 
-def _env(rank, world, port):
+def _env(rank, world, port, overlap='0'):
     env = dict(os.environ)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
+    env['PCGAN_DDP_OVERLAP'] = overlap
     if world > 1:
         env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    PCGAN_DIST_BACKEND='gloo')
@@ -43,10 +44,12 @@ def _env(rank, world, port):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_product_step(dev, tmp_path):
+@pytest.mark.parametrize('dtype,overlap', [('fp32', '0'), ('fp32', '1'), ('bf16', '0')],
+                         ids=['fp32-sequential', 'fp32-overlapped-allreduce', 'bf16-sequential(config 3: bf16 x ranks)'])
+def test_two_ranks_product_step(dev, tmp_path, dtype, overlap):
     port = _free_port()
     outs = [str(tmp_path / ('rank%d.pt' % r)) for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, WORKER, outs[r], str(2 * r), str(2 * r + 2)], cwd=ROOT, env=_env(r, 2, port),
+    procs = [subprocess.Popen([sys.executable, WORKER, outs[r], str(2 * r), str(2 * r + 2), dtype], cwd=ROOT, env=_env(r, 2, port, overlap),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     logs = [p.communicate(timeout=600)[0] for p in procs]
     for r, p in enumerate(procs):
@@ -57,7 +60,7 @@ def test_two_ranks_product_step(dev, tmp_path):
     singles = []
     for h in range(2):
         o = str(tmp_path / ('single%d.pt' % h))
-        p = subprocess.run([sys.executable, WORKER, o, str(2 * h), str(2 * h + 2)], cwd=ROOT, env=_env(0, 1, 0), capture_output=True,
+        p = subprocess.run([sys.executable, WORKER, o, str(2 * h), str(2 * h + 2), dtype], cwd=ROOT, env=_env(0, 1, 0), capture_output=True,
                            text=True, timeout=600)
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
         singles.append(torch.load(o))

@@ -81,3 +81,59 @@ def test_dropout_flags_inside_a_replay(dev, monkeypatch):
     assert len(filled) == 3 and not torch.equal(filled[0], filled[1]), 'every replay draws its own flags'
     keep = torch.cat(filled).mean().item()
     assert abs(keep - (1 - p)) < 0.03, keep
+
+
+def test_capture_follows_mode_and_weights_and_survives_a_failed_capture(dev, monkeypatch):
+    """a capture is keyed on the train / eval pattern and on the parameter versions: eval() after a capture must not
+    replay the train-mode launches (batch statistics, running-statistics updates), load_state_dict must not replay stale packed
+    weights; the flag arena is sized from the warm-up calls (a large MC-dropout batch fits); a failing capture leaves the call eager."""
+    from pcgan_amd.hip import graphs
+    e1 = _encoder(dev, 0.0)
+    e2 = copy.deepcopy(e1)
+    g = graphs.GraphedNoGrad(e2)
+    x = (torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(5)) * 2 - 1).to(dev)
+    with torch.no_grad():
+        for _ in range(4):
+            assert torch.equal(e1(x), g(x))
+        e1.eval(), e2.eval()
+        n0 = int(e2.state_dict()['base.model.bn1.num_batches_tracked'])
+        for _ in range(4):
+            assert torch.equal(e1(x), g(x)), 'eval mode after a train-mode capture'
+        assert int(e2.state_dict()['base.model.bn1.num_batches_tracked']) == n0, 'an eval pass must not count batches'
+        e1.train(), e2.train()
+        sd = {k: (v * 1.5 if k.endswith('conv1.weight') else v) for k, v in e1.state_dict().items()}
+        e1.load_state_dict(sd), e2.load_state_dict(sd)
+        for _ in range(4):
+            assert torch.equal(e1(x), g(x)), 'new weights after a capture'
+    # arena sized from the warm-up: more flags than the old fixed 1 << 17 floats
+    big = _encoder(dev, 0.25)
+    gb = graphs.GraphedNoGrad(big)
+    xb = torch.rand(40, 3, 64, 64).to(dev)
+    before = dict(graphs.STATS)
+    with torch.no_grad():
+        for _ in range(4):
+            yb, _lv = gb(xb)
+    assert graphs.STATS['captured'] == before['captured'] + 1 and graphs.STATS.get('capture_failed', 0) == before.get('capture_failed', 0)
+    assert max(ent.get('flags', 0) for ent in gb.state.values()) > (1 << 17)
+    # a capture that raises: the key turns eager-only, the call still answers, nothing is retried
+    def boom(self, n, p):
+        raise RuntimeError('arena exhausted (test)')
+    monkeypatch.setattr(graphs.FlagArena, 'take', boom)
+    small = _encoder(dev, 0.25)
+    gs = graphs.GraphedNoGrad(small)
+    with torch.no_grad(), pytest.warns(UserWarning):
+        for _ in range(4):
+            ys, _lv = gs(x)
+            assert torch.isfinite(ys).all()
+    assert graphs.STATS.get('capture_failed', 0) == before.get('capture_failed', 0) + 1
+
+
+def test_flag_pool_follows_the_seed(dev):
+    """pre-drawn Dropout2d keep flags are dropped on torch.manual_seed(): a seeded MC-dropout run is reproducible from its seed"""
+    from pcgan_amd.hip import functional as F
+    torch.manual_seed(11)
+    a = F._keep_flags(1000, 0.2, dev).clone()
+    F._keep_flags(500, 0.2, dev)
+    torch.manual_seed(11)
+    b = F._keep_flags(1000, 0.2, dev).clone()
+    assert torch.equal(a, b)

@@ -63,14 +63,18 @@ def _worker(rank, world, port, tmp):
     loader = CreateDataLoader(opt)
     assert loader.world == world and loader.rank == rank
     n_images = len(loader)
+    import random
+    draw = (random.random(), float(torch.rand(1)), float(np.random.rand()))     # per-sample generators after the loader is up
     epochs = []
-    for _ in range(2):
+    for ep in range(2):
+        if rank == 0:          # rank-0-only logging takes len() on its own: must not desynchronise the pair lists
+            len(loader), len(loader.dataset)
         batches = []
         for b in loader.load_data():
             assert tuple(b['A'].shape) == (GLOBAL_BATCH // world, 3, 16, 16) and len(b['A_paths']) == GLOBAL_BATCH // world
             batches.append([(os.path.basename(a), os.path.basename(c), int(l)) for a, c, l in zip(b['A_paths'], b['B_paths'], b['label'])])
         epochs.append(batches)
-    torch.save({'epochs': epochs, 'seed': loader.sampler.seed, 'n': n_images}, os.path.join(tmp, 'rank%d.pt' % rank))
+    torch.save({'epochs': epochs, 'seed': loader.sampler.seed, 'n': n_images, 'draw': draw}, os.path.join(tmp, 'rank%d.pt' % rank))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -83,6 +87,10 @@ def test_two_ranks_hold_disjoint_slices_of_one_permutation(tmp_path):
     r = [torch.load(os.path.join(tmp, 'rank%d.pt' % i)) for i in range(2)]
     assert r[0]['seed'] == r[1]['seed'], 'ranks must share the shuffle seed (broadcast from rank 0)'
     assert r[0]['n'] == r[1]['n'] == N_PAIRS
+    # crop / flip / noise draws are per sample: python's and torch's generators differ between ranks (DataParallel draws them
+    # independently over the global batch); numpy's stays shared (--no_mixed_label_D draws one label per GLOBAL batch from it)
+    assert r[0]['draw'][0] != r[1]['draw'][0] and r[0]['draw'][1] != r[1]['draw'][1]
+    assert r[0]['draw'][2] == r[1]['draw'][2]
     lines = {('img_%d.png' % i, 'img_%d.png' % (i + 1), (0, 2, 1)[i % 3]) for i in range(N_PAIRS)}
     orders = []
     for ep in range(2):
