@@ -11,10 +11,12 @@ Workload (BASELINE.json configs[1]): 9-block ResnetGenerator + 3-layer PatchGAN 
 (weak scaling: global batch = 32 x N), synthetic U[-1,1) images, labels in {0,2}, seeded-random
 "pretrained" E/IP weights (no checkpoints ship offline).
 
-One JSON line on rank 0: value = whole-job images/s; `roofline` = the dominant kernel (the 256->256
-3x3 residual convolution: fp32 contraction as an exact 3-piece bf16 split on the bf16 matrix pipe): every one of its
-forward launches inside the timed region is bracketed by HIP events on the launch stream;
-`cpu_baseline` = the oracle's PyTorch-CPU step on this host's cores, bounded sample.
+One JSON line on rank 0: value = whole-job images/s; `roofline` = the three kernels of the 256->256 3x3 residual
+convolution (forward, data gradient, weight gradient INCLUDING its padded-copy and reduce launches; 36 launches each per step;
+fp32 contraction as two scaled fp16 pieces / three products on the f16 matrix pipe by default): every launch inside the timed
+region is bracketed by HIP events on its launch stream inside the library (pcgan_timer_*), the slowest of the three is the
+dominant kernel the top-level fields describe; `cpu_baseline` = the oracle's PyTorch-CPU step on this host's cores, bounded sample.
+`python bench.py --dtype bf16` is the same line for BASELINE configs[2] per GPU (bf16 activations).
 """
 import argparse
 import contextlib
@@ -37,20 +39,26 @@ F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16 MFMA (v_mfma_f32_32x32x16_f16): sam
 F16_SPLIT_PRODUCTS = 3           # fp16 piece products that stand for one fp32 product (the default route, "fp16 route" in bf16x6_conv.hip)
 PER_GPU_BATCH = 32
 SIZE = 128
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_dominant_kernel_traffic.json')   # written from the --pmc passes of this round
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r03_residual_kernel_traffic.json')   # written from the --pmc passes of this round
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from this round's separate rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE cannot share a pass), committed under profiles/; None when the file is absent or describes another kernel."""
+def measured_traffic(route):
+    """HBM bytes per launch of the three residual-convolution kernels from this round's separate rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE cannot share a pass), committed under profiles/: {'fwd' | 'dgrad' | 'wgrad': {...}}; None when
+    the file is absent or was counted on another route."""
     try:
         with open(TRAFFIC_FILE) as f:
             t = json.load(f)
-        if t.get('kernel') != kernel:
+        if t.get('route') != route:
             return None
-        return {'bytes_per_launch': int(t['fetch_bytes'] + t['write_bytes']), 'fetch_bytes': int(t['fetch_bytes']),
-                'write_bytes': int(t['write_bytes']), 'algorithmic_bytes': int(t['algorithmic_bytes']), 'source': t['source']}
-    except (OSError, KeyError, ValueError):
+        out = {}
+        for k in ('fwd', 'dgrad', 'wgrad'):
+            e = t[k]
+            out[k] = {'bytes_per_launch': int(e['fetch_bytes'] + e['write_bytes']), 'fetch_bytes': int(e['fetch_bytes']),
+                      'write_bytes': int(e['write_bytes']), 'algorithmic_bytes': int(e['algorithmic_bytes']), 'kernels': e.get('kernels')}
+        out['source'] = t['source']
+        return out
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
@@ -162,8 +170,11 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    # HIP events on the launch stream around every forward launch of the dominant kernel inside the timed region
-    ops.KERNEL_TIMER = {'key': RES_CONV_KEY, 'events': []}
+    # HIP events on the launch stream around every launch of the three residual-convolution kernels inside the timed region
+    # (recorded inside the library, pcgan_timer_*: whichever host path -- per-op call or composite -- issues the launch)
+    ops.timer_enable(36 * args.steps + 8)
+    if world > 1:
+        parallel.COMM_TIMER = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -171,53 +182,133 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
-    dt = time.perf_counter() - t0
+    dt = dt_rank = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        # per-rank view (diagnostics of the first multi-GPU runs): own wall time and the time inside the gradient all-reduces
+        # (collective + waiting for the slowest rank), HIP events on the launch stream
+        comm, parallel.COMM_TIMER = parallel.COMM_TIMER, None
+        comm_ms = sum(a.elapsed_time(b) for a, b in comm) / args.steps
+        mine = {'rank': rank, 'ms_per_step': round(dt_rank / args.steps * 1e3, 3), 'allreduce_ms_per_step': round(comm_ms, 3),
+                'allreduces_per_step': round(len(comm) / args.steps, 2), 'host_issue_ms_per_step': round(t_issued / args.steps * 1e3, 3)}
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine)
     losses = model.get_current_losses()
     assert all(v == v and abs(v) < 1e6 for v in losses.values()), 'non-finite loss: %r' % losses
 
-    timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
-    conv_launches = len(timer['events'])
-    conv_ms = sum(a.elapsed_time(b) for a, b in timer['events']) / max(conv_launches, 1)
-    conv_flop = RES_CONV_FLOP
+    timed = {k: ops.timer_read(k) for k in ('res_fwd', 'res_dgrad', 'res_wgrad', 'res_wgrad_main')}
+    # the same kernels running ALONE: three more steps with the parameter-gradient and branch streams off (in the step the data
+    # gradient on the main stream and the weight gradient on the side stream share the GPU, so each in-region duration above holds
+    # the other kernel's work too)
+    saved_streams = (ops.SIDE_STREAM, ops.BRANCH_STREAMS)
+    ops.SIDE_STREAM = ops.BRANCH_STREAMS = False
+    try:
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+    finally:
+        ops.SIDE_STREAM, ops.BRANCH_STREAMS = saved_streams
+    alone = {k: ops.timer_read(k) for k in ('res_fwd', 'res_dgrad', 'res_wgrad', 'res_wgrad_main')}
+    ops.timer_enable(0)
+    # host work per step: time to ISSUE one step starting from an idle GPU.  (Inside the timed region the HIP queue back-pressures
+    # the host about one step ahead of the GPU, so the in-region issue time tracks the GPU time from below, not the host's work.)
+    idle_issue = []
+    for i in range(5):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step(i)
+        idle_issue.append(time.perf_counter() - th)
+    torch.cuda.synchronize()
+    idle_issue.sort()
+    host_ms = idle_issue[len(idle_issue) // 2] * 1e3
     if rank != 0:
         return
     ms_per_step = dt / args.steps * 1e3
     value = PER_GPU_BATCH * world * args.steps / dt
-    assert conv_launches > 0, 'the residual convolution was not launched inside the timed region'
+    assert all(len(timed[k]) > 0 for k in ('res_fwd', 'res_dgrad', 'res_wgrad')), 'the residual convolutions were not launched inside the timed region'
+    kern = {k: {'ms_per_launch': sum(v) / len(v), 'launches_timed': len(v)} for k, v in timed.items() if v}
+    conv_flop = RES_CONV_FLOP
+    dominant = max(('res_fwd', 'res_dgrad', 'res_wgrad'), key=lambda k: kern[k]['ms_per_launch'])
+    conv_ms, conv_launches = kern[dominant]['ms_per_launch'], kern[dominant]['launches_timed']
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12
     split = ops.BF16X6
     hsplit = split and ops.HSPLIT
     bf16 = args.dtype == 'bf16'
+    shape = '256->256 3x3 reflect @32x32, bs32'
     if bf16:
-        # bf16 storage, one bf16 product per term: 16x the fp32 MFMA rate makes the kernel HBM / gather bound -> HBM roofline
-        kname = ('bsplit_conv_fwd_kernel<BS_FWD_REFLECT,256,1,bf16> (bf16 activations and weights, v_mfma_f32_32x32x16_bf16, fp32 accumulate) '
-                 '256->256 3x3 reflect @32x32, bs32')
+        # bf16 storage, one bf16 product per term: 16x the fp32 MFMA rate makes the kernels LDS / issue bound -> judged against HBM
+        route, peak, basis = 'bf16', None, None
+        names = {'res_fwd': 'bsplit_halo_kernel<BH_FWD,PK_BF16,bf16,32> (bf16 activations and weights, v_mfma_f32_32x32x16_bf16, fp32 accumulate)',
+                 'res_dgrad': 'bsplit_halo_kernel<BH_DGRAD,PK_BF16,bf16,32>',
+                 'res_wgrad': 'bsplit_pad_wave_kernel + hsplit_wgrad_kernel<256,1,bf16,2> + bsplit_wgrad_reduce_kernel'}
     elif hsplit:
-        # the dominant kernel runs the fp32 contraction as 3 fp16 piece products per term (two scaled fp16 pieces per operand) on
-        # the f16 matrix pipe: its MFMA roofline in ALGORITHMIC (fp32) FLOP is the dense f16 peak / 3
-        peak = F16_MFMA_PEAK_TFLOPS / F16_SPLIT_PRODUCTS
-        kname = ('bsplit_halo_kernel<BH_FWD,PK_F16X2,float,32> (two scaled fp16 pieces per operand, 3 x v_mfma_f32_32x32x16_f16 per K=16 '
-                 'step, 256 x 128 tile, input window split once per 16-channel chunk) 256->256 3x3 reflect @32x32, bs32')
+        # the fp32 contraction runs as 3 fp16 piece products per term (two scaled fp16 pieces per operand) on the f16 matrix pipe:
+        # the MFMA roofline in ALGORITHMIC (fp32) FLOP is the dense f16 peak / 3
+        route, peak = 'f16x2', F16_MFMA_PEAK_TFLOPS / F16_SPLIT_PRODUCTS
+        basis = 'dense f16 MFMA %.0f TFLOP/s / %d piece products per fp32 product' % (F16_MFMA_PEAK_TFLOPS, F16_SPLIT_PRODUCTS)
+        names = {'res_fwd': 'bsplit_halo_kernel<BH_FWD,PK_F16X2,float,32> (two scaled fp16 pieces per operand, 3 x v_mfma_f32_32x32x16_f16 per '
+                            'K=16 step, 256 x 128 tile, input window split once per 16-channel chunk)',
+                 'res_dgrad': 'bsplit_halo_kernel<BH_DGRAD,PK_F16X2,float,32> (the same window kernel on dy with its sum rows / columns)',
+                 'res_wgrad': 'bsplit_pad_wave_kernel + hsplit_wgrad_kernel<256,1,float,1> + bsplit_wgrad_reduce_kernel (padded copy of x, '
+                              '14 splits of the pixel reduction, fixed-order reduce into the gradient buffer)'}
     elif split:
-        # the dominant kernel runs the fp32 contraction as 6 bf16 piece products per term on the bf16 matrix pipe: its MFMA
-        # roofline in ALGORITHMIC (fp32) FLOP is the dense bf16 peak / 6
-        peak = BF16_MFMA_PEAK_TFLOPS / BF16_SPLIT_PRODUCTS
-        kname = ('bsplit_conv_fwd_kernel<BS_FWD_REFLECT,256> (exact 3-piece bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per K=16 step, '
-                 '256 x 128 tile) 256->256 3x3 reflect @32x32, bs32')
+        route, peak = 'bf16x3', BF16_MFMA_PEAK_TFLOPS / BF16_SPLIT_PRODUCTS
+        basis = 'dense bf16 MFMA %.0f TFLOP/s / %d piece products per fp32 product' % (BF16_MFMA_PEAK_TFLOPS, BF16_SPLIT_PRODUCTS)
+        names = {'res_fwd': 'bsplit_halo_kernel<BH_FWD,PK_BF16X3,float,32> (exact 3-piece bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per K=16 step)',
+                 'res_dgrad': 'bsplit_halo_kernel<BH_DGRAD,PK_BF16X3,float,32>',
+                 'res_wgrad': 'bsplit_pad_reflect + bsplit_pack_dy + bsplit_conv_fwd_kernel<BS_WGRAD> + reduce'}
     else:
-        peak = FP32_MFMA_PEAK_TFLOPS
-        kname = 'igemm2_kernel<1,128,128,16> (FWD_REFLECT, 128x128 tile, 16-channel K stages) 256->256 3x3 reflect @32x32, bs32'
-    traffic = measured_traffic('bsplit_halo_kernel<0, 2, float, 32>' if hsplit else 'bsplit_halo_kernel<0, 0, float, 32>') if (split and not bf16) else None
+        route, peak, basis = 'fp32_mfma', FP32_MFMA_PEAK_TFLOPS, 'fp32 MFMA v_mfma_f32_32x32x2_f32'
+        names = {'res_fwd': 'igemm2_kernel<1,128,128,16> (FWD_REFLECT, 128x128 tile, 16-channel K stages)',
+                 'res_dgrad': 'igemm2_kernel (reflect data gradient, three row classes)', 'res_wgrad': 'wgrad2_kernel + wgrad_reduce_kernel'}
+    traffic = measured_traffic(route)
+    tkey = {'res_fwd': 'fwd', 'res_dgrad': 'dgrad', 'res_wgrad': 'wgrad'}
+    alg_bytes_bf16 = 2 * PER_GPU_BATCH * 256 * 32 * 32 * 2 + 256 * 256 * 9 * 2     # x + y as bf16, bf16 weights
+
+    def kernel_entry(k):
+        ms = kern[k]['ms_per_launch']
+        tf = conv_flop / (ms * 1e-3) / 1e12
+        e = {'kernel': names[k] + ' ' + shape, 'ms_per_launch': round(ms, 4), 'launches_timed': kern[k]['launches_timed'],
+             'achieved_tflops': round(tf, 2)}
+        if peak is not None:
+            e['frac'] = round(tf / peak, 4)
+        if alone.get(k):
+            ms_a = sum(alone[k]) / len(alone[k])
+            e['ms_per_launch_alone'] = round(ms_a, 4)
+            if peak is not None:
+                e['frac_alone'] = round(conv_flop / (ms_a * 1e-3) / 1e12 / peak, 4)
+        if k == 'res_wgrad' and 'res_wgrad_main' in kern:
+            e['ms_main_kernel_only'] = round(kern['res_wgrad_main']['ms_per_launch'], 4)
+            if alone.get('res_wgrad_main'):
+                e['ms_main_kernel_only_alone'] = round(sum(alone['res_wgrad_main']) / len(alone['res_wgrad_main']), 4)
+        t = traffic.get(tkey[k]) if traffic else None
+        e['traffic'] = t['bytes_per_launch'] if t else None
+        if t:
+            e['traffic_detail'] = t
+        return e
+    per_kernel = {k: kernel_entry(k) for k in ('res_fwd', 'res_dgrad', 'res_wgrad')}
+    dom = per_kernel[dominant]
     if bf16:
-        alg_bytes = 2 * PER_GPU_BATCH * 256 * 32 * 32 * 2 + 256 * 256 * 9 * 2     # x + y as bf16, bf16 weights
-        roof = {'bound': 'hbm', 'kernel': kname, 'achieved': round(alg_bytes / (conv_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                'frac': round(alg_bytes / (conv_ms * 1e-3) / 1e9 / 8000.0, 4), 'ms_per_launch': round(conv_ms, 4),
-                'launches_timed': conv_launches, 'algorithmic_bytes_per_launch': alg_bytes, 'flop_per_launch': conv_flop,
-                'mfma_tflops': round(achieved, 1), 'traffic': None}
+        roof = {'bound': 'hbm', 'kernel': dom['kernel'], 'dominant': dominant, 'achieved': round(alg_bytes_bf16 / (conv_ms * 1e-3) / 1e9, 1),
+                'peak': 8000.0, 'unit': 'GB/s', 'frac': round(alg_bytes_bf16 / (conv_ms * 1e-3) / 1e9 / 8000.0, 4),
+                'ms_per_launch': round(conv_ms, 4), 'launches_timed': conv_launches, 'algorithmic_bytes_per_launch': alg_bytes_bf16,
+                'flop_per_launch': conv_flop, 'mfma_tflops': round(achieved, 1), 'traffic': dom['traffic'], 'kernels': per_kernel}
+    else:
+        roof = {'bound': 'mfma', 'kernel': dom['kernel'], 'dominant': dominant,
+                'dominant_rule': 'the slowest of the three residual-convolution kernels (36 launches each per step) by its launch duration '
+                                 'inside the timed region; all three under "kernels".  In the region the data gradient (main stream) and '
+                                 'the weight gradient (parameter-gradient stream) run CONCURRENTLY and share the GPU: "ms_per_launch_alone" / '
+                                 '"frac_alone" are the same launches with those streams off (3 extra steps after the region)',
+                'frac_alone': dom.get('frac_alone'), 'ms_per_launch_alone': dom.get('ms_per_launch_alone'),
+                'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                'ms_per_launch': round(conv_ms, 4), 'launches_timed': conv_launches, 'flop_per_launch': conv_flop, 'peak_basis': basis,
+                # memory-side bytes per launch from this round's separate rocprofv3 --pmc passes (profiles/README.md); null when no
+                # counter file of this round is committed
+                'traffic': dom['traffic'], 'traffic_detail': dom.get('traffic_detail'), 'kernels': per_kernel}
+    step_tflops = GFLOP_PER_IMG_FULL * 1e9 * value / world / 1e12        # algorithmic FLOP of the whole step per GPU and second
     out = {
         'metric': 'images/sec (G+D step) 128x128 bs32 per GPU', 'value': round(value, 3), 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
@@ -226,21 +317,21 @@ def main():
                                'PatchGAN + ResNet-18 Elo encoder@224 + AlexNet IP@224, full optimize_parameters()' % (
                                    'bf16 activations (fp32 master weights, accumulation, statistics, losses, Adam)' if bf16 else 'fp32'),
                    'global_batch': PER_GPU_BATCH * world, 'parallelism': 'dp%d' % world},
-        'host_issue_ms_per_step': round(t_issued / args.steps * 1e3, 3),
-        'step_flop_fraction': round(GFLOP_PER_IMG_FULL * 1e9 * value / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4),
-        'roofline': roof if bf16 else {'bound': 'mfma', 'kernel': kname,
-                     'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                     'frac': round(achieved / peak, 4), 'ms_per_launch': round(conv_ms, 4),
-                     'launches_timed': conv_launches, 'flop_per_launch': conv_flop,
-                     'peak_basis': ('dense f16 MFMA %.0f TFLOP/s / %d piece products per fp32 product' % (F16_MFMA_PEAK_TFLOPS, F16_SPLIT_PRODUCTS))
-                     if hsplit else ('dense bf16 MFMA %.0f TFLOP/s / %d piece products per fp32 product' % (BF16_MFMA_PEAK_TFLOPS, BF16_SPLIT_PRODUCTS))
-                     if split else 'fp32 MFMA v_mfma_f32_32x32x2_f32',
-                     'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                     # memory-side bytes per launch from this round's separate rocprofv3 --pmc passes (profiles/README.md);
-                     # null when no counter file of this round is committed
-                     'traffic': traffic['bytes_per_launch'] if traffic else None, 'traffic_detail': traffic},
+        # host work: median time to issue one step from an idle GPU (5 steps after the region); in the region the launch queue's
+        # back-pressure makes the issue time follow the GPU time (second number)
+        'host_issue_ms_per_step': round(host_ms, 3),
+        'host_issue_in_region_ms_per_step': round(t_issued / args.steps * 1e3, 3),
+        # whole-step algorithmic FLOP rate (183.95 GFLOP per image) against the bound of the route the convolutions run
+        # on -- THE step-level roofline fraction -- and, for orientation only, against the fp32 MFMA peak (a pipe the default route
+        # does not use: that ratio is not a roofline fraction and may exceed 1)
+        'step_algorithmic_tflops': round(step_tflops, 2),
+        'step_frac_of_route_bound': round(step_tflops / peak, 4) if peak else None,
+        'step_flop_over_fp32_mfma_peak_not_a_roofline_fraction': round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+        'roofline': roof,
         'losses': {k: round(v, 5) for k, v in losses.items()},
     }
+    if per_rank is not None:
+        out['per_rank'] = per_rank
     if world == 1 and not args.no_experiment and ops.BF16X6 and not bf16:
         # NOT the headline: the same K steps once more with the 108 residual-convolution launches on the two other routes -- the
         # exact three-piece bf16 split (PCGAN_SPLIT=bf16, the default before the fp16 route) and the fp32 MFMA implicit GEMM

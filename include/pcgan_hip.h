@@ -302,6 +302,10 @@ int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, const float
                             const float* bias, void* y, int act, float slope, pcgan_stream_t s);
 int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed,
                                  void* dx, pcgan_stream_t s);
+/* ... the same with dx = conv^T(dy, w) + add: the gradient that reaches a ResnetBlock's input through the skip connection
+ * (`x + conv_block(x)`, models/networks.py:650-652) summed in the epilogue instead of by a separate `grad +=` pass.  add may be NULL. */
+int pcgan_conv2d_bwd_data_hsplit_add(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed,
+                                     const void* add, void* dx, pcgan_stream_t s);
 /* Every other convolution whose gathered channel count is a multiple of 16 (<= 25 taps, more than 32 produced channels; any
  * stride; forward with zero / reflection padding, data gradient with zero padding -- incl. nn.ConvTranspose2d forward,
  * models/networks.py:584-602, 734-763; models/resnet.py): the fp16 two-piece form of pcgan_conv2d_fwd_packed /
@@ -324,6 +328,50 @@ size_t pcgan_conv2d_hsplit_wgrad_workspace_bytes(const pcgan_conv_desc* d);
 int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_xamax, const void* dy,
                                    const float* dy_amax, int n_dyamax, float* dw, int accumulate, void* ws, size_t ws_bytes,
                                    pcgan_stream_t s);
+
+
+/* ---- composite: one ResnetBlock per call -----------------------------------------------------------------------------------------
+ * `x + conv_block(x)` with conv_block = ReflectionPad2d(1), Conv2d(dim, dim, 3, bias), InstanceNorm2d, ReLU, ReflectionPad2d(1),
+ * Conv2d(dim, dim, 3, bias), InstanceNorm2d (models/networks.py:616-652; 9 blocks x 2 generator passes per step).  The per-op entry
+ * points above cost the host one call per launch (6 forward, 10 backward per block: ~12 ms of a 32 ms step); these two launch exactly
+ * the same kernels with the same arguments in the same order -- results are bit-identical to the per-op sequence -- from ONE call.
+ * fp32 tensors on the fp16 two-piece route only (pcgan_resblock_supported: the shapes pcgan_conv2d_hsplit_supported /
+ * pcgan_conv2d_hsplit_wgrad_supported / pcgan_instnorm_fused take); other shapes use the per-op calls.
+ *
+ * forward   y1 = conv1(x) ; h = relu(IN(y1)) ; y2 = conv2(h) ; out = IN(y2) + x.  pk1 / pk2: pcgan_conv2d_hsplit_pack(PASS_FWD).
+ *           stats[4][N*C] receives mean1, M2_1, mean2, M2_2 (kept for the backward pass); amax[2][N*C] the plane maxima of h and
+ *           out (operand maxima of the next convolution); running statistics are updated in place.
+ * backward  given dout: dy2 = IN2'(dout) ; dw2 += wgrad(h, dy2), db2 += sum dy2 ; dh = dgrad2(dy2) ; dy1 = (IN1 o relu)'(dh) ;
+ *           dw1 += wgrad(x, dy1), db1 += sum dy1 ; dx = dgrad1(dy1) + dout (skip connection).  pk1b / pk2b:
+ *           pcgan_conv2d_hsplit_pack(PASS_BWD_DATA).  The weight / bias gradients are launched on `side` (ordered behind the producer of
+ *           their operands through `fork_event`, an event the caller owns: pcgan_event_create); the caller joins `side` before it reads
+ *           dw / db.  scratch: 5*N*C floats (plane sums and maxima of dy2 / dy1); wgrad_ws: pcgan_resblock_wgrad_workspace_bytes(d),
+ *           used on `side` only.  dy2, dh, dy1 are caller-allocated temporaries the size of x. */
+typedef struct {
+    int N, C, H, W;
+    float eps, momentum;
+} pcgan_resblock_desc;
+typedef void* pcgan_event_t; /* hipEvent_t */
+int pcgan_event_create(pcgan_event_t* ev);
+int pcgan_event_destroy(pcgan_event_t ev);
+int pcgan_resblock_supported(const pcgan_resblock_desc* d);
+size_t pcgan_resblock_wgrad_workspace_bytes(const pcgan_resblock_desc* d);
+int pcgan_resblock_fwd(const pcgan_resblock_desc* d, const void* x, const float* x_amax, int n_xamax, const void* pk1, const float* b1,
+                       const void* pk2, const float* b2, float* rm1, float* rv1, float* rm2, float* rv2, void* y1, void* h, void* y2,
+                       void* out, float* stats, float* amax, pcgan_stream_t s);
+int pcgan_resblock_bwd(const pcgan_resblock_desc* d, const void* dout, const void* x, const float* x_amax, int n_xamax, const void* y1,
+                       const void* h, const float* h_amax, const void* y2, const float* stats, const void* pk1b, const void* pk2b,
+                       float* dw1, float* db1, float* dw2, float* db2, void* dy2, void* dh, void* dy1, void* dx, float* scratch,
+                       void* wgrad_ws, size_t wgrad_ws_bytes, pcgan_stream_t s, pcgan_stream_t side, pcgan_event_t fork_event);
+
+/* ---- kernel timer (measurement only) -----------------------------------------------------------------------------------------------
+ * bench.py's roofline block: HIP events on the launch stream around every launch of the three residual-block convolution kernels
+ * (kind 0 forward, 1 data gradient, 2 weight gradient incl. its padded copy and reduce, 3 the weight gradient's main kernel),
+ * whichever entry point issued them.  pcgan_timer_enable(capacity) creates `capacity` event pairs per kind and switches recording on
+ * (0: off, events destroyed); pcgan_timer_read waits for the recorded pairs of one kind, writes their durations in ms (at most cap) and
+ * resets that kind; returns the count or -1.  The only global state of the library; off by default, never records inside a graph capture. */
+int pcgan_timer_enable(int capacity);
+int pcgan_timer_read(int kind, float* ms, int cap);
 
 #ifdef __cplusplus
 }

@@ -590,6 +590,8 @@ struct HaloArgs {
     const float* x_amax;   // PK_F16X2: x_namax partial maxima of |X| (device), and the weights' largest magnitude (pack kernel)
     const float* w_amax;
     int x_namax;
+    const void* R;         // optional [N][M][H][W] tensor added to the result (after bias / activation): the skip connection's gradient
+                           // summed into the data gradient of a residual block's first convolution (autograd's `grad +=` pass)
 };
 
 // piece kinds: what an operand element becomes on its way to the matrix pipe
@@ -979,7 +981,8 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
                 const int m = mt * BM + wave * 32 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
                 if (m < a.M) {
                     const float av = PK == PK_F16X2 ? (acc[i][j][r] * isx) * isw : acc[i][j][r];
-                    const float v = act_apply(av + (a.bias ? a.bias[m] : 0.f), a.act, a.slope);
+                    float v = act_apply(av + (a.bias ? a.bias[m] : 0.f), a.act, a.slope);
+                    if (a.R) v += ld1((const TA*)a.R + yo + (size_t)m * HW);
                     st1((TA*)a.Y + yo + (size_t)m * HW, v);
                 }
             }
@@ -1425,6 +1428,7 @@ extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const void* x, 
                                        int act, float slope, pcgan_stream_t s) {
     if (pcgan::bsplit_check(d)) return 1;
     PCGAN_CHECK(x && packed && y, "conv2d_fwd_bsplit: null pointer");
+    pcgan::TimerScope timer(pcgan::timer_kind_res(d, pcgan::TIMER_RES_FWD), (hipStream_t)s);
     pcgan::BsplitArgs a;
     a.X = x; a.A = packed; a.bias = bias; a.Y = y;
     a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->K; a.R = d->R; a.S = d->S; a.pad = d->pad; a.reflect = d->pad_mode;
@@ -1443,7 +1447,7 @@ extern "C" int pcgan_conv2d_fwd_bsplit(const pcgan_conv_desc* d, const void* x, 
     const long ptiles = ((long)d->N * d->P * d->Q + 127) / 128;
     const dim3 grid((unsigned)(ptiles * a.nMt));
     if (d->pad_mode == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && pcgan::halo_shape(d->C, d->K, d->H, d->W)) {
-        pcgan::HaloArgs h;
+        pcgan::HaloArgs h{};
         h.X = x; h.A = packed; h.bias = bias; h.Y = y;
         h.N = d->N; h.C = d->C; h.H = d->H; h.M = d->K; h.nMt = a.nMt; h.nch = d->C / 16; h.act = act; h.slope = slope;
         h.x_bytes = a.x_bytes; h.a_bytes = a.a_bytes; h.x_amax = h.w_amax = nullptr; h.x_namax = 0;
@@ -1489,6 +1493,7 @@ extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const void
     PCGAN_CHECK(pcgan_conv2d_bsplit_dgrad_supported(d), "conv2d_bwd_data_bsplit: unsupported shape");
     PCGAN_CHECK(d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16, "conv2d_bwd_data_bsplit: dtype %d", d->dtype);
     PCGAN_CHECK(dy && packed && dx, "conv2d_bwd_data_bsplit: null pointer");
+    pcgan::TimerScope timer(pcgan::timer_kind_res(d, pcgan::TIMER_RES_DGRAD), (hipStream_t)s);
     pcgan::BsplitArgs a;
     a.X = dy; a.A = packed; a.bias = nullptr; a.Y = dx;
     a.N = d->N; a.C = d->K; a.H = d->H; a.W = d->W; a.M = d->C; a.R = 3; a.S = 3; a.pad = 1; a.reflect = 1;
@@ -1504,7 +1509,7 @@ extern "C" int pcgan_conv2d_bwd_data_bsplit(const pcgan_conv_desc* d, const void
     a.a_bytes = (unsigned)(3 * per_phase);
     a.nst_split = 0;
     if (pcgan::halo_shape(d->K, d->C, d->H, d->W)) {      // plain flipped weights = row class 0 of the packed buffer
-        pcgan::HaloArgs h;
+        pcgan::HaloArgs h{};
         h.X = dy; h.A = packed; h.bias = nullptr; h.Y = dx;
         h.N = d->N; h.C = d->K; h.H = d->H; h.M = d->C; h.nMt = a.nMt; h.nch = d->K / 16; h.act = PCGAN_ACT_NONE; h.slope = 0.f;
         h.x_bytes = a.x_bytes; h.a_bytes = (unsigned)per_phase; h.x_amax = h.w_amax = nullptr; h.x_namax = 0;
@@ -1560,6 +1565,7 @@ extern "C" int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const vo
     PCGAN_CHECK(pcgan_conv2d_bsplit_wgrad_supported(d), "conv2d_bwd_weight_bsplit: unsupported shape");
     PCGAN_CHECK(d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16, "conv2d_bwd_weight_bsplit: dtype %d", d->dtype);
     PCGAN_CHECK(x && dy && dw && ws && ws_bytes >= pcgan_conv2d_bsplit_wgrad_workspace_bytes(d), "conv2d_bwd_weight_bsplit: null pointer or small workspace");
+    pcgan::TimerScope timer(pcgan::timer_kind_res(d, pcgan::TIMER_RES_WGRAD), (hipStream_t)s);
     const int bm = d->K % 256 == 0 ? 256 : 128;
     PCGAN_CHECK(d->K % bm == 0, "conv2d_bwd_weight_bsplit: output channels must fill the %d-row tile", bm);
     hipStream_t st = (hipStream_t)s;
@@ -1669,8 +1675,9 @@ extern "C" int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, 
                                        const float* bias, void* y, int act, float slope, pcgan_stream_t s) {
     PCGAN_CHECK(pcgan_conv2d_hsplit_supported(d, PCGAN_PASS_FWD), "conv2d_fwd_hsplit: unsupported shape");
     PCGAN_CHECK(x && x_amax && n_amax > 0 && packed && y, "conv2d_fwd_hsplit: null pointer");
+    pcgan::TimerScope timer(pcgan::timer_kind_res(d, pcgan::TIMER_RES_FWD), (hipStream_t)s);
     const size_t body = hsplit_body_bytes(d, PCGAN_PASS_FWD);
-    pcgan::HaloArgs h;
+    pcgan::HaloArgs h{};
     h.X = x; h.A = packed; h.bias = bias; h.Y = y;
     h.N = d->N; h.C = d->C; h.H = d->H; h.M = d->K; h.nMt = (d->K + 255) / 256; h.nch = d->C / 16; h.act = act; h.slope = slope;
     h.x_bytes = (unsigned)((size_t)d->N * d->C * d->H * d->W * 4);
@@ -1686,10 +1693,16 @@ extern "C" int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, 
 
 extern "C" int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed,
                                             void* dx, pcgan_stream_t s) {
+    return pcgan_conv2d_bwd_data_hsplit_add(d, dy, dy_amax, n_amax, packed, nullptr, dx, s);
+}
+
+extern "C" int pcgan_conv2d_bwd_data_hsplit_add(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed,
+                                                const void* add, void* dx, pcgan_stream_t s) {
     PCGAN_CHECK(pcgan_conv2d_hsplit_supported(d, PCGAN_PASS_BWD_DATA), "conv2d_bwd_data_hsplit: unsupported shape");
     PCGAN_CHECK(dy && dy_amax && n_amax > 0 && packed && dx, "conv2d_bwd_data_hsplit: null pointer");
+    pcgan::TimerScope timer(pcgan::timer_kind_res(d, pcgan::TIMER_RES_DGRAD), (hipStream_t)s);
     const size_t body = hsplit_body_bytes(d, PCGAN_PASS_BWD_DATA);
-    pcgan::HaloArgs h;
+    pcgan::HaloArgs h{};
     h.X = dy; h.A = packed; h.bias = nullptr; h.Y = dx;
     h.N = d->N; h.C = d->K; h.H = d->H; h.M = d->C; h.nMt = (d->C + 255) / 256; h.nch = d->K / 16; h.act = PCGAN_ACT_NONE; h.slope = 0.f;
     h.x_bytes = (unsigned)((size_t)d->N * d->K * d->H * d->W * 4);
@@ -1697,6 +1710,7 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit(const pcgan_conv_desc* d, const void
     h.x_amax = dy_amax;
     h.x_namax = n_amax;
     h.w_amax = (const float*)((const char*)packed + body);
+    h.R = add;
     const dim3 grid((unsigned)((long)d->N * d->H * d->W / 128 * h.nMt));
     pcgan::launch_halo<pcgan::BH_DGRAD>(d, d->W, grid, (hipStream_t)s, h, true);
     PCGAN_LAUNCH_CHECK();
@@ -1750,6 +1764,8 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     PCGAN_CHECK(x && dy && dw && ws && ws_bytes >= pcgan_conv2d_hsplit_wgrad_workspace_bytes(d), "conv2d_bwd_weight_hsplit: null pointer or small workspace");
     PCGAN_CHECK(half || (x_amax && dy_amax && n_xamax > 0 && n_dyamax > 0), "conv2d_bwd_weight_hsplit: fp32 tensors need their operand maxima");
     hipStream_t st = (hipStream_t)s;
+    const bool res_like = pcgan::timer_kind_res(d, 0) == 0;
+    pcgan::TimerScope timer(res_like ? pcgan::TIMER_RES_WGRAD : -1, st);       // padded copy + main kernel + reduce
     int per;
     const int splits = hsplit_wgrad_splits(d, &per);
     const int Hp = d->H + 2 * d->pad, Wp = d->W + 2 * d->pad;
@@ -1778,12 +1794,15 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     const int bm = hsplit_wgrad_bm(d);
 #define LWH(BMV, SV, NCV) do { if (half) hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, pcgan::bf16, NCV>), grid, dim3(BMV * 2), 0, st, a); \
                                else hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, float, NCV>), grid, dim3(BMV * 2), 0, st, a); } while (0)
+    {
+    pcgan::TimerScope timer_main(res_like ? pcgan::TIMER_RES_WGRAD_MAIN : -1, st);
     if (bm == 256 && cw == 256 && d->stride == 1) LWH(256, 1, 2);
     else if (bm == 256 && cw == 256) LWH(256, 2, 2);
     else if (bm == 256 && d->stride == 1) LWH(256, 1, 1);
     else if (bm == 256) LWH(256, 2, 1);
     else if (d->stride == 1) LWH(128, 1, 1);
     else LWH(128, 2, 1);
+    }
 #undef LWH
     PCGAN_LAUNCH_CHECK();
     const size_t total = (size_t)d->K * d->C * d->R * d->S;

@@ -1,6 +1,9 @@
 // Status / diagnostics part of the C-ABI (include/pcgan_hip.h).
 #include "common.h"
 #include <stdarg.h>
+#include <atomic>
+#include <mutex>
+#include <vector>
 
 namespace pcgan {
 static thread_local char g_err[512] = "";
@@ -11,6 +14,78 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 }  // namespace pcgan
+
+// ---- kernel timer ---------------------------------------------------------------------------------------------------------------
+namespace pcgan {
+namespace {
+struct TimerKind {
+    std::vector<hipEvent_t> start, stop;
+    int used = 0;
+};
+std::mutex g_timer_mu;
+std::atomic<int> g_timer_on{0};
+TimerKind g_timer[TIMER_KINDS];
+}  // namespace
+
+TimerScope::TimerScope(int kind_, hipStream_t st_) : kind(kind_), slot(-1), st(st_) {
+    if (kind < 0 || kind >= TIMER_KINDS || !g_timer_on.load(std::memory_order_relaxed)) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;     // never inside a graph capture
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    TimerKind& t = g_timer[kind];
+    if (t.used >= (int)t.start.size()) return;
+    slot = t.used++;
+    (void)hipEventRecord(t.start[slot], st);
+}
+TimerScope::~TimerScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    (void)hipEventRecord(g_timer[kind].stop[slot], st);
+}
+}  // namespace pcgan
+
+extern "C" int pcgan_timer_enable(int capacity) {
+    using namespace pcgan;
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    g_timer_on.store(0);
+    for (int k = 0; k < TIMER_KINDS; ++k) {
+        TimerKind& t = g_timer[k];
+        for (hipEvent_t e : t.start) (void)hipEventDestroy(e);
+        for (hipEvent_t e : t.stop) (void)hipEventDestroy(e);
+        t.start.clear();
+        t.stop.clear();
+        t.used = 0;
+        for (int i = 0; i < capacity; ++i) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+                set_error("timer_enable: hipEventCreate failed");
+                return 1;
+            }
+            t.start.push_back(a);
+            t.stop.push_back(b);
+        }
+    }
+    g_timer_on.store(capacity > 0 ? 1 : 0);
+    return 0;
+}
+
+extern "C" int pcgan_timer_read(int kind, float* ms, int cap) {
+    using namespace pcgan;
+    if (kind < 0 || kind >= TIMER_KINDS || (!ms && cap > 0)) {
+        set_error("timer_read: bad kind / null output");
+        return -1;
+    }
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    TimerKind& t = g_timer[kind];
+    int n = 0;
+    for (int i = 0; i < t.used && n < cap; ++i) {
+        if (hipEventSynchronize(t.stop[i]) != hipSuccess) continue;
+        float v = 0.f;
+        if (hipEventElapsedTime(&v, t.start[i], t.stop[i]) == hipSuccess) ms[n++] = v;
+    }
+    t.used = 0;
+    return n;
+}
 
 extern "C" const char* pcgan_last_error(void) { return pcgan::g_err; }
 extern "C" int pcgan_version(void) { return 100; }

@@ -29,6 +29,22 @@ void set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// ---- kernel timer (measurement only; off unless pcgan_timer_enable was called) --------------------------------------------------
+// HIP events on the LAUNCH stream around every launch of the kernels bench.py's roofline block reports (the three residual-block
+// convolutions), whichever host path issued them (per-op call or composite).  kind < 0: no-op.
+enum { TIMER_RES_FWD = 0, TIMER_RES_DGRAD = 1, TIMER_RES_WGRAD = 2, TIMER_RES_WGRAD_MAIN = 3, TIMER_KINDS = 4 };
+struct TimerScope {
+    int kind, slot;
+    hipStream_t st;
+    TimerScope(int kind, hipStream_t st);
+    ~TimerScope();
+};
+
+// the residual-block convolution (256 -> 256, 3x3, stride 1, reflection padding 1): the kind to time it under, or -1
+static inline int timer_kind_res(const pcgan_conv_desc* d, int kind) {
+    return (d && d->K == 256 && d->C == 256 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad_mode == 1 && d->pad == 1) ? kind : -1;
+}
+
 static inline int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

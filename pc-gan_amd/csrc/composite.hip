@@ -1,0 +1,100 @@
+// Composite entry points: a whole fused site of the generator per host call (include/pcgan_hip.h, "composite").
+//
+// The per-op C-ABI costs the host one Python -> ctypes round trip per launch; at config 2 the 18 ResnetBlocks x 2 generator passes are
+// ~290 such calls per step.  pcgan_resblock_fwd / pcgan_resblock_bwd issue exactly the launches the per-op sequence issues -- same
+// kernels, same arguments, same order on the same streams -- so their results are bit-identical to it (tests/test_gpu_composite.py);
+// the only arithmetic that moves is the skip connection's `grad +=`, which becomes the epilogue of the first convolution's data
+// gradient (one fp32 add either way).
+#include "common.h"
+
+namespace {
+inline pcgan_conv_desc conv_of(const pcgan_resblock_desc* d) {
+    pcgan_conv_desc c;
+    c.N = d->N; c.C = d->C; c.H = d->H; c.W = d->W; c.K = d->C; c.R = 3; c.S = 3;
+    c.stride = 1; c.pad = 1; c.pad_mode = 1; c.P = d->H; c.Q = d->W; c.dtype = PCGAN_F32;
+    return c;
+}
+}  // namespace
+
+extern "C" int pcgan_event_create(pcgan_event_t* ev) {
+    PCGAN_CHECK(ev, "event_create: null pointer");
+    hipEvent_t e;
+    hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    PCGAN_CHECK(r == hipSuccess, "event_create: %s", hipGetErrorString(r));
+    *ev = (pcgan_event_t)e;
+    return 0;
+}
+
+extern "C" int pcgan_event_destroy(pcgan_event_t ev) {
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+    return 0;
+}
+
+extern "C" int pcgan_resblock_supported(const pcgan_resblock_desc* d) {
+    if (!d || d->N < 1 || d->C < 1 || d->H < 3 || d->W < 3) return 0;
+    const pcgan_conv_desc c = conv_of(d);
+    return pcgan_conv2d_hsplit_supported(&c, PCGAN_PASS_FWD) && pcgan_conv2d_hsplit_supported(&c, PCGAN_PASS_BWD_DATA) &&
+           pcgan_conv2d_hsplit_wgrad_supported(&c) && pcgan_instnorm_fused(d->H * d->W);
+}
+
+extern "C" size_t pcgan_resblock_wgrad_workspace_bytes(const pcgan_resblock_desc* d) {
+    if (!pcgan_resblock_supported(d)) return 0;
+    const pcgan_conv_desc c = conv_of(d);
+    return pcgan_conv2d_hsplit_wgrad_workspace_bytes(&c);
+}
+
+#define STEP(call)            \
+    do {                      \
+        const int r__ = (call); \
+        if (r__) return r__;  \
+    } while (0)
+
+extern "C" int pcgan_resblock_fwd(const pcgan_resblock_desc* d, const void* x, const float* x_amax, int n_xamax, const void* pk1,
+                                  const float* b1, const void* pk2, const float* b2, float* rm1, float* rv1, float* rm2, float* rv2,
+                                  void* y1, void* h, void* y2, void* out, float* stats, float* amax, pcgan_stream_t s) {
+    PCGAN_CHECK(pcgan_resblock_supported(d), "resblock_fwd: unsupported shape");
+    PCGAN_CHECK(x && x_amax && n_xamax > 0 && pk1 && pk2 && y1 && h && y2 && out && stats && amax, "resblock_fwd: null pointer");
+    const pcgan_conv_desc c = conv_of(d);
+    const int N = d->N, C = d->C, HW = d->H * d->W, NC = N * C;
+    float *mean1 = stats, *m21 = stats + NC, *mean2 = stats + 2 * (size_t)NC, *m22 = stats + 3 * (size_t)NC;
+    float *h_amax = amax, *o_amax = amax + NC;
+    STEP(pcgan_conv2d_fwd_hsplit(&c, x, x_amax, n_xamax, pk1, b1, y1, PCGAN_ACT_NONE, 0.f, s));
+    STEP(pcgan_instnorm_fwd(y1, nullptr, h, mean1, m21, h_amax, N, C, HW, d->eps, PCGAN_ACT_RELU, 0.f, PCGAN_F32, s));
+    if (rm1 && rv1) STEP(pcgan_in_running_update(mean1, m21, rm1, rv1, N, C, HW, d->momentum, s));
+    STEP(pcgan_conv2d_fwd_hsplit(&c, h, h_amax, NC, pk2, b2, y2, PCGAN_ACT_NONE, 0.f, s));
+    STEP(pcgan_instnorm_fwd(y2, x, out, mean2, m22, o_amax, N, C, HW, d->eps, PCGAN_ACT_NONE, 0.f, PCGAN_F32, s));
+    if (rm2 && rv2) STEP(pcgan_in_running_update(mean2, m22, rm2, rv2, N, C, HW, d->momentum, s));
+    return 0;
+}
+
+extern "C" int pcgan_resblock_bwd(const pcgan_resblock_desc* d, const void* dout, const void* x, const float* x_amax, int n_xamax,
+                                  const void* y1, const void* h, const float* h_amax, const void* y2, const float* stats, const void* pk1b,
+                                  const void* pk2b, float* dw1, float* db1, float* dw2, float* db2, void* dy2, void* dh, void* dy1, void* dx,
+                                  float* scratch, void* wgrad_ws, size_t wgrad_ws_bytes, pcgan_stream_t s, pcgan_stream_t side,
+                                  pcgan_event_t fork_event) {
+    PCGAN_CHECK(pcgan_resblock_supported(d), "resblock_bwd: unsupported shape");
+    PCGAN_CHECK(dout && x && x_amax && n_xamax > 0 && y1 && h && h_amax && y2 && stats && pk1b && pk2b && dw1 && dw2 && dy2 && dh && dy1 &&
+                    dx && scratch && wgrad_ws && fork_event,
+                "resblock_bwd: null pointer");
+    PCGAN_CHECK(side && side != s, "resblock_bwd: the parameter-gradient stream must be a second stream");
+    const pcgan_conv_desc c = conv_of(d);
+    const int N = d->N, C = d->C, HW = d->H * d->W, NC = N * C;
+    const float *mean1 = stats, *m21 = stats + NC, *mean2 = stats + 2 * (size_t)NC, *m22 = stats + 3 * (size_t)NC;
+    float *psum = scratch, *dy2_amax = scratch + NC, *dy1_amax = scratch + 2 * (size_t)NC, *psum1 = scratch + 3 * (size_t)NC;
+    hipStream_t ms = (hipStream_t)s, ss = (hipStream_t)side;
+    hipEvent_t ev = (hipEvent_t)fork_event;
+    // second half of the block: out = IN(y2) + x
+    STEP(pcgan_instnorm_bwd(dout, y2, nullptr, mean2, m22, dy2, psum, dy2_amax, nullptr, N, C, HW, d->eps, PCGAN_ACT_NONE, 0.f, PCGAN_F32, s));
+    PCGAN_CHECK(hipEventRecord(ev, ms) == hipSuccess && hipStreamWaitEvent(ss, ev, 0) == hipSuccess, "resblock_bwd: stream fork failed");
+    STEP(pcgan_conv2d_bwd_weight_hsplit(&c, h, h_amax, NC, dy2, dy2_amax, NC, dw2, 1, wgrad_ws, wgrad_ws_bytes, side));
+    if (db2) STEP(pcgan_sum_planes(psum, db2, N, C, 1, side));
+    STEP(pcgan_conv2d_bwd_data_hsplit(&c, dy2, dy2_amax, NC, pk2b, dh, s));
+    // first half: h = relu(IN(y1))
+    STEP(pcgan_instnorm_bwd(dh, y1, h, mean1, m21, dy1, psum1, dy1_amax, nullptr, N, C, HW, d->eps, PCGAN_ACT_RELU, 0.f, PCGAN_F32, s));
+    PCGAN_CHECK(hipEventRecord(ev, ms) == hipSuccess && hipStreamWaitEvent(ss, ev, 0) == hipSuccess, "resblock_bwd: stream fork failed");
+    STEP(pcgan_conv2d_bwd_weight_hsplit(&c, x, x_amax, n_xamax, dy1, dy1_amax, NC, dw1, 1, wgrad_ws, wgrad_ws_bytes, side));
+    if (db1) STEP(pcgan_sum_planes(psum1, db1, N, C, 1, side));
+    // ... and the skip connection's gradient summed in the epilogue
+    STEP(pcgan_conv2d_bwd_data_hsplit_add(&c, dy1, dy1_amax, NC, pk1b, dout, dx, s));
+    return 0;
+}

@@ -2725,6 +2725,7 @@ extern "C" int pcgan_conv2d_fwd_packed(const pcgan_conv_desc* d, const void* x, 
                                        pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(packed, "conv2d_fwd_packed: null packed-weight pointer");
+    pcgan::TimerScope timer(pcgan::timer_kind_res(d, pcgan::TIMER_RES_FWD), (hipStream_t)s);
     return conv2d_fwd_impl(d, x, nullptr, packed, bias, y, act, slope, ws, ws_bytes, s);
 }
 
@@ -2889,6 +2890,7 @@ extern "C" int pcgan_conv2d_bwd_data_packed(const pcgan_conv_desc* d, const void
                                             pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(packed && dx, "conv2d_bwd_data_packed: null pointer");
+    pcgan::TimerScope timer(pcgan::timer_kind_res(d, pcgan::TIMER_RES_DGRAD), (hipStream_t)s);
     return conv2d_bwd_data_impl(d, dy, nullptr, packed, bias, dx, ws, ws_bytes, s);
 }
 
@@ -2942,6 +2944,7 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const void* x, 
     PCGAN_CHECK(ws && ws_bytes >= pcgan_conv2d_workspace_bytes(d, PCGAN_PASS_BWD_WEIGHT),
                 "conv2d_bwd_weight: workspace too small (%zu)", ws_bytes);
     hipStream_t st = (hipStream_t)s;
+    pcgan::TimerScope timer(pcgan::timer_kind_res(d, pcgan::TIMER_RES_WGRAD), st);
     const int Cgp = round4(d->C), RS = d->R * d->S;
     WgradArgs a;
     memset(&a, 0, sizeof(a));

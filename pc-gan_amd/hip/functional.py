@@ -86,6 +86,64 @@ class _Conv2dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
+class _ResBlockFn(torch.autograd.Function):
+    """One ResnetBlock (reference models/networks.py:616-652) as ONE autograd node and ONE library call per pass
+    (ops.resblock_fwd / resblock_bwd: the launches of the per-op path, bit for bit).  Taken by nn-level code only when the block's
+    shape is on the fp16 route and its parameters feed a FusedAdam gradient buffer (or nothing requires gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, pl, in1, in2):
+        upd1 = in1.training and in1.running_mean is not None
+        upd2 = in2.training and in2.running_mean is not None
+        pack1, pack2 = _pack_cache(w1), _pack_cache(w2)
+        out, saved = ops.resblock_fwd(pl, x, w1, b1, w2, b2, in1.running_mean if upd1 else None, in1.running_var if upd1 else None,
+                                      in2.running_mean if upd2 else None, in2.running_var if upd2 else None, pack1, pack2)
+        ctx.pl, ctx.saved, ctx.packs, ctx.params = pl, saved, (pack1, pack2), (w1, b1, w2, b2)
+        ctx.save_for_backward(x, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w1, w2 = ctx.saved_tensors
+        p1, pb1, p2, pb2 = ctx.params
+        tw1, tb1, tw2, tb2 = (_fused_grad_target(p) for p in (p1, pb1, p2, pb2))
+        assert tw1 is not None and tw2 is not None and (pb1 is None or tb1 is not None) and (pb2 is None or tb2 is not None), \
+            'pcgan_amd: the composite residual block needs FusedAdam gradient buffers (checked in forward)'
+        dx = ops.resblock_bwd(ctx.pl, _c(dout), x, ctx.saved, w1, w2, tw1, tb1, tw2, tb2, ctx.packs[0], ctx.packs[1])
+        ctx.saved = None
+        return dx, None, None, None, None, None, None, None
+
+
+def resblock_composite_ok(x, conv1, conv2, in1, in2):
+    """the launch plan if this ResnetBlock call can take the composite path, else None"""
+    if not (ops.COMPOSITE and ops.SIDE_STREAM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        return None
+    if in1.eps != in2.eps or in1.momentum != in2.momentum or in1.momentum is None:
+        return None
+    for m in (in1, in2):       # plane statistics (train mode, or no running statistics at all)
+        if m.affine or not (m.training or not m.track_running_stats):
+            return None
+    N, C, H, W = x.shape
+    for c in (conv1, conv2):
+        if tuple(c.weight.shape) != (C, C, 3, 3) or c.stride != (1, 1) or c.padding != (0, 0) or c.weight.dtype != torch.float32:
+            return None
+    if (conv1.bias is None) != (conv2.bias is None):
+        return None
+    pl = ops.resblock_plan(N, C, H, W, in1.eps, in1.momentum)
+    if not pl.ok:
+        return None
+    params = [p for p in (conv1.weight, conv1.bias, conv2.weight, conv2.bias) if p is not None]
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        # training: every parameter's gradient goes straight into its optimizer's flat buffer, and x carries a gradient
+        if not (x.requires_grad and all(p.requires_grad and _fused_grad_target(p) is not None for p in params)):
+            return None
+    return pl
+
+
+def resblock(x, conv1, conv2, in1, in2, pl):
+    return _ResBlockFn.apply(x, conv1.weight, conv1.bias, conv2.weight, conv2.bias, pl, in1, in2)
+
+
 def conv2d(x, w, b=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE, slope=0.0):
     """nn.Conv2d (optionally preceded by nn.ReflectionPad2d(pad): pad_mode=1) with the
     following pointwise activation fused into the epilogue."""
@@ -335,13 +393,17 @@ _FLAG_POOL_SIZE = 1 << 16
 def _keep_flags(n, p, device):
     if n > _FLAG_POOL_SIZE // 4:
         return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(1.0 - p)
-    # (the generator's seed in the key: after torch.manual_seed() leftover flags of the old stream are not handed out any more, so
-    # a seeded MC-dropout run is reproducible from its seed)
-    key = (device, float(p), torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0,
-           torch.cuda.initial_seed() if device.type == 'cuda' else torch.initial_seed())
+    # A re-seed (torch.manual_seed) must not be followed by leftover flags of the old stream: the pool remembers the generator's
+    # seed and its Philox offset right after the refill; a different seed, or an offset that went BACKWARDS (same seed again),
+    # means the generator was re-seeded since -> refill, so a seeded MC-dropout run is reproducible from its seed.
+    cuda = device.type == 'cuda'
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()] if cuda else torch.default_generator
+    seed, offset = gen.initial_seed(), (gen.get_offset() if cuda else 0)
+    key = (device, float(p), torch.cuda.current_stream(device).cuda_stream if cuda else 0)
     ent = _FLAG_POOL.get(key)
-    if ent is None or ent[1] + n > _FLAG_POOL_SIZE:
-        ent = _FLAG_POOL[key] = [torch.empty(_FLAG_POOL_SIZE, dtype=torch.float32, device=device).bernoulli_(1.0 - p), 0]
+    if ent is None or ent[1] + n > _FLAG_POOL_SIZE or ent[2] != seed or offset < ent[3]:
+        buf = torch.empty(_FLAG_POOL_SIZE, dtype=torch.float32, device=device).bernoulli_(1.0 - p)
+        ent = _FLAG_POOL[key] = [buf, 0, seed, gen.get_offset() if cuda else 0]
     o = ent[1]
     ent[1] = o + n
     return ent[0][o:o + n]

@@ -20,6 +20,12 @@ class ImageDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ('H', 'W', 'RH', 'RW', 'FH', 'FW', 'ksize_h', 'ksize_v', 'out_channels')]
 
 
+class ResBlockDesc(ctypes.Structure):
+    """pcgan_resblock_desc (include/pcgan_hip.h)."""
+    _fields_ = [('N', ctypes.c_int), ('C', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('eps', ctypes.c_float),
+                ('momentum', ctypes.c_float)]
+
+
 class ConvDesc(ctypes.Structure):
     """pcgan_conv_desc (include/pcgan_hip.h)."""
     _fields_ = [(n, ctypes.c_int) for n in
@@ -29,6 +35,7 @@ class ConvDesc(ctypes.Structure):
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 _dp = ctypes.POINTER(ConvDesc)
 _ip = ctypes.POINTER(ImageDesc)
+_rp = ctypes.POINTER(ResBlockDesc)
 
 # name -> (restype, argtypes); kept in one table so tests can check that the library
 # exports every symbol the header declares.
@@ -95,6 +102,16 @@ SIGNATURES = {
     'pcgan_conv2d_hsplit_pack': (_i, [_dp, _i, _vp, _vp, _vp]),
     'pcgan_conv2d_fwd_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp]),
     'pcgan_conv2d_bwd_data_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp]),
+    'pcgan_conv2d_bwd_data_hsplit_add': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    'pcgan_event_create': (_i, [ctypes.POINTER(_vp)]),
+    'pcgan_event_destroy': (_i, [_vp]),
+    'pcgan_resblock_supported': (_i, [_rp]),
+    'pcgan_resblock_wgrad_workspace_bytes': (_sz, [_rp]),
+    'pcgan_resblock_fwd': (_i, [_rp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pcgan_resblock_bwd': (_i, [_rp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _sz, _vp, _vp, _vp]),
+    'pcgan_timer_enable': (_i, [_i]),
+    'pcgan_timer_read': (_i, [_i, _vp, _i]),
     'pcgan_conv2d_hgemm_supported': (_i, [_dp, _i]),
     'pcgan_conv2d_fwd_packed_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
     'pcgan_conv2d_bwd_data_packed_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import lib as _L
-from .lib import ConvDesc, ACT_NONE, F32, BF16
+from .lib import ConvDesc, ResBlockDesc, ACT_NONE, F32, BF16
 
 _vp = ctypes.c_void_p
 
@@ -131,6 +131,25 @@ class fork_side(object):
         return self.ctx.__exit__(*exc)
 
 
+def side_stream_for(cur):
+    """the parameter-gradient stream of `cur`'s device (made on first use)"""
+    st = _side.get(cur.device)
+    if st is None:
+        st = _side[cur.device] = torch.cuda.Stream(device=cur.device)
+    return st
+
+
+def mark_side_used():
+    """work was queued on the side stream by a composite call (which forks inside the library): join when the backward pass ends"""
+    _side_state['dirty'] = True
+    if not _side_state['queued']:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+            _side_state['queued'] = True
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------- branch streams (independent sub-networks)
 # In backward_G the discriminator, the AlexNet identity branch and the Elo encoder all read the same fake image and
 # meet again only in the scalar loss sum.  Each branch can run on its own stream: autograd replays every backward node
@@ -190,10 +209,6 @@ def join_side_stream():
 # The epoch is bumped by everything that writes parameters behind autograd's back (the Adam kernels, which
 # update the flat buffer through raw pointers; model.set_input / load_networks / broadcast as a backstop).
 _PACK_EPOCH = [0]
-
-# bench.py: HIP events (on the launch stream) around every prepacked forward launch of one convolution shape,
-# {'key': (N, C, H, W, K, R, S, stride, pad, pad_mode), 'events': []}; None = off
-KERNEL_TIMER = None
 
 
 def invalidate_packed_weights(params=None):
@@ -406,10 +421,6 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
     if pack_cache is not None:
         pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache)
         _count_route('fwd', pl.route)
-        ev = None
-        if KERNEL_TIMER is not None and KERNEL_TIMER['key'] == (N, C, H, W, K, R, S, stride, pad, pad_mode):
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
         if pl.route == 'hgemm':
             xmax, wmax = amax_of(x), _weight_amax(lib, w, pack_cache)
             _L.check(lib.pcgan_conv2d_fwd_packed_hsplit(d, _p(x), _p(xmax), xmax.numel(), _p(pk), _p(wmax), _p(bias), _p(y), act,
@@ -423,9 +434,6 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
         else:
             _L.check(lib.pcgan_conv2d_fwd_packed(d, _p(x), _p(pk), _p(bias), _p(y), act, float(slope), _p(ws), ws.numel(), _stream()),
                      'conv2d_fwd_packed')
-        if ev is not None:
-            ev[1].record()
-            KERNEL_TIMER['events'].append(ev)
         return y
     _L.check(lib.pcgan_conv2d_fwd(d, _p(x), _p(w), _p(bias), _p(y), act, float(slope), _p(ws), ws.numel(), _stream()), 'conv2d_fwd')
     return y
@@ -498,6 +506,116 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=N
     else:
         _L.check(lib.pcgan_conv2d_bwd_weight(d, _p(x), _p(dy), _p(dw), acc, _p(ws), ws.numel(), _stream()), 'conv2d_bwd_weight')
     return dw
+
+
+# ---------------------------------------------------------------- composite: one ResnetBlock per call
+# (include/pcgan_hip.h "composite"): the same launches as the per-op sequence conv -> IN+ReLU -> conv -> IN+skip (and its backward)
+# from ONE ctypes call -- the host side of a config-2 step spends ~12 of its 27 ms on the 18 blocks x 2 generator passes.
+COMPOSITE = os.environ.get('PCGAN_COMPOSITE', '1') != '0'
+COMPOSITE_STATS = {'fwd': 0, 'bwd': 0}
+_RB_PLANS = {}
+_FORK_EVENTS = {}
+_WGRAD_WS = {}
+
+
+class _RBPlan(object):
+    __slots__ = ('d', 'dref', 'ok', 'conv', 'ws_bytes')
+
+
+def resblock_plan(N, C, H, W, eps, momentum):
+    key = (N, C, H, W, float(eps), float(momentum), BF16X6, HSPLIT, HGEMM, BSPLIT_MIN_PIXELS)
+    p = _RB_PLANS.get(key)
+    if p is None:
+        lib = _L.load()
+        p = _RBPlan()
+        p.d = ResBlockDesc(N, C, H, W, float(eps), float(momentum))
+        p.dref = ctypes.byref(p.d)
+        # the composite is the per-op sequence on the fp16 route: taken exactly where the host would route all three passes there
+        p.ok = bool(COMPOSITE and lib.pcgan_resblock_supported(p.dref)
+                    and _plan(_L.PASS_FWD, N, C, H, W, C, 3, 3, 1, 1, 1, F32).route == 'hsplit'
+                    and _plan(_L.PASS_BWD_DATA, N, C, H, W, C, 3, 3, 1, 1, 1, F32).route == 'hsplit'
+                    and _plan(_L.PASS_BWD_WEIGHT, N, C, H, W, C, 3, 3, 1, 1, 1, F32).route == 'hsplit')
+        p.conv = _plan(_L.PASS_FWD, N, C, H, W, C, 3, 3, 1, 1, 1, F32).d if p.ok else None
+        p.ws_bytes = int(lib.pcgan_resblock_wgrad_workspace_bytes(p.dref)) if p.ok else 0
+        _RB_PLANS[key] = p
+    return p
+
+
+def _fork_event(device):
+    ev = _FORK_EVENTS.get(device)
+    if ev is None:
+        box = _vp(0)
+        _L.check(_L.load().pcgan_event_create(ctypes.byref(box)), 'event_create')
+        ev = _FORK_EVENTS[device] = _vp(box.value)
+    return ev
+
+
+def resblock_fwd(pl, x, w1, b1, w2, b2, rm1, rv1, rm2, rv2, pack1, pack2):
+    """returns out, (y1, h, y2, stats, amax, x_amax): everything the backward call needs besides x"""
+    _chk(x, w1, b1, w2, b2, rm1, rv1, rm2, rv2)
+    lib = _L.load()
+    N, C = x.shape[0], x.shape[1]
+    pk1 = _packed_weights(lib, pl.conv, PASS_FWD_HSPLIT, w1, pack1)
+    pk2 = _packed_weights(lib, pl.conv, PASS_FWD_HSPLIT, w2, pack2)
+    xmax = amax_of(x)
+    y1, h, y2, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    stats = torch.empty(4 * N * C, dtype=torch.float32, device=x.device)
+    amax = torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
+    _L.check(lib.pcgan_resblock_fwd(pl.dref, _p(x), _p(xmax), xmax.numel(), _p(pk1), _p(b1), _p(pk2), _p(b2), _p(rm1), _p(rv1), _p(rm2),
+                                    _p(rv2), _p(y1), _p(h), _p(y2), _p(out), _p(stats), _p(amax), _stream()), 'resblock_fwd')
+    _count_route('fwd', 'hsplit')
+    _count_route('fwd', 'hsplit')
+    COMPOSITE_STATS['fwd'] += 1
+    _attach_amax(out, amax[N * C:])
+    return out, (y1, h, y2, stats, amax, xmax)
+
+
+def resblock_bwd(pl, dout, x, saved, w1, w2, dw1, db1, dw2, db2, pack1, pack2):
+    """dx (skip connection included); the parameter gradients are ADDED into dw* / db* on the parameter-gradient stream"""
+    _chk(dout, x, dw1, db1, dw2, db2)
+    y1, h, y2, stats, amax, xmax = saved
+    lib = _L.load()
+    N, C = x.shape[0], x.shape[1]
+    pk1b = _packed_weights(lib, pl.conv, PASS_BWD_HSPLIT, w1, pack1)
+    pk2b = _packed_weights(lib, pl.conv, PASS_BWD_HSPLIT, w2, pack2)
+    cur = torch.cuda.current_stream()
+    side = side_stream_for(cur)
+    wkey = (x.device, pl.ws_bytes)
+    ws = _WGRAD_WS.get(wkey)
+    if ws is None:     # one workspace for every weight-gradient launch of this shape: they run in issue order on the one side stream
+        with torch.cuda.stream(side):
+            ws = _WGRAD_WS[wkey] = _ws(pl.ws_bytes, x.device)
+    dy2, dh, dy1, dx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    scratch = torch.empty(5 * N * C, dtype=torch.float32, device=x.device)
+    for t in (x, h, dy2, dy1, scratch, amax, xmax):      # read by the side stream after this call returns
+        t.record_stream(side)
+    _L.check(lib.pcgan_resblock_bwd(pl.dref, _p(dout), _p(x), _p(xmax), xmax.numel(), _p(y1), _p(h), _p(amax), _p(y2), _p(stats), _p(pk1b),
+                                    _p(pk2b), _p(dw1), _p(db1), _p(dw2), _p(db2), _p(dy2), _p(dh), _p(dy1), _p(dx), _p(scratch), _p(ws),
+                                    ws.numel(), _vp(cur.cuda_stream), _vp(side.cuda_stream), _fork_event(x.device)), 'resblock_bwd')
+    for _ in range(2):
+        _count_route('dgrad', 'hsplit')
+        _count_route('wgrad', 'hsplit')
+    AMAX_STATS['attached'] += 6        # (x, h, dy2 x 2, dy1 x 2: the operand maxima all came from the norm kernels)
+    PLANE_SUM_STATS['fused'] += 2
+    COMPOSITE_STATS['bwd'] += 1
+    mark_side_used()
+    return dx
+
+
+# ---------------------------------------------------------------- kernel timer (bench.py's roofline block)
+TIMER_KINDS = {'res_fwd': 0, 'res_dgrad': 1, 'res_wgrad': 2, 'res_wgrad_main': 3}
+
+
+def timer_enable(capacity):
+    _L.check(_L.load().pcgan_timer_enable(int(capacity)), 'timer_enable')
+
+
+def timer_read(kind, cap=65536):
+    buf = (ctypes.c_float * cap)()
+    n = _L.load().pcgan_timer_read(TIMER_KINDS[kind], buf, cap)
+    if n < 0:
+        raise RuntimeError('pcgan_timer_read failed')
+    return [float(buf[i]) for i in range(n)]
 
 
 # ---------------------------------------------------------------- pointwise

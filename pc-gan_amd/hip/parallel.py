@@ -60,16 +60,28 @@ def shard_dict(batch, world=None, rank=None):
     return {k: shard_batch(v, rank, world) for k, v in batch.items()}
 
 
+# bench.py --gpus N: [(start, stop)] HIP-event pairs on the launch stream around every gradient all-reduce (the collective incl. the
+# wait for the slowest rank), so that the first multi-GPU run is diagnosable; None = off
+COMM_TIMER = None
+
+
 def allreduce_mean_(flat, async_op=False):
     """In-place average of a flat gradient buffer over all ranks.  async_op: the collective is only LAUNCHED (RCCL runs it on its own
     stream, after everything queued so far on the current stream); the returned callable makes the current stream wait for it."""
     if not is_distributed():
         return (lambda: flat) if async_op else flat
     world = dist.get_world_size()
+    ev = None
+    if COMM_TIMER is not None and flat.is_cuda and not async_op:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     if dist.get_backend() == 'nccl':
         work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=async_op)      # RCCL computes the average in the ring
         if async_op:
             return lambda: (work.wait(), flat)[1]
+        if ev is not None:
+            ev[1].record()
+            COMM_TIMER.append(ev)
         return flat
     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)      # gloo (CPU tests / single-GPU rehearsal): no AVG
     if async_op:
@@ -79,6 +91,9 @@ def allreduce_mean_(flat, async_op=False):
             return flat
         return finish
     flat.mul_(1.0 / world)
+    if ev is not None:
+        ev[1].record()
+        COMM_TIMER.append(ev)
     return flat
 
 

@@ -285,8 +285,17 @@ class ResnetBlock(tnn.Module):
             if half == 0:
                 blk += [tnn.ReLU(True)]
         self.conv_block = tnn.Sequential(*blk)
+        # the composite call (hip/functional.py: _ResBlockFn) covers the reference's default block -- reflection padding,
+        # InstanceNorm: [RefPad, Conv, IN, ReLU, RefPad, Conv, IN]; any other layout runs layer by layer
+        self._composite_layout = (padding_type == 'reflect' and len(blk) == 7 and isinstance(blk[2], hnn.InstanceNorm2d)
+                                  and isinstance(blk[6], hnn.InstanceNorm2d))
 
     def forward(self, x):
+        if self._composite_layout:
+            cb = self.conv_block
+            pl = HF.resblock_composite_ok(x, cb[1], cb[5], cb[2], cb[6])
+            if pl is not None:
+                return HF.resblock(x, cb[1], cb[5], cb[2], cb[6], pl)
         return run_sequential(self.conv_block, x, residual=x)
 
 
