@@ -309,9 +309,14 @@ int pcgan_conv2d_bwd_data_hsplit_add(const pcgan_conv_desc* d, const void* dy, c
 /* Every other convolution whose gathered channel count is a multiple of 16 (<= 25 taps, more than 32 produced channels; any
  * stride; forward with zero / reflection padding, data gradient with zero padding -- incl. nn.ConvTranspose2d forward,
  * models/networks.py:584-602, 734-763; models/resnet.py): the fp16 two-piece form of pcgan_conv2d_fwd_packed /
- * pcgan_conv2d_bwd_data_packed.  Same packed weights (pcgan_conv2d_pack_weights), workspace and semantics; w_amax[0 .. 64) =
- * partial maxima of |weight| (pcgan_absmax over w with 64 slots). */
+ * pcgan_conv2d_bwd_data_packed.  Same workspace and semantics; packed weights from pcgan_conv2d_hgemm_pack (desc.dtype = PCGAN_BF16:
+ * from pcgan_conv2d_pack_weights); w_amax[0 .. 64) = partial maxima of |weight| (pcgan_absmax over w with 64 slots). */
 int pcgan_conv2d_hgemm_supported(const pcgan_conv_desc* d, int pass);
+/* packed weights of the two calls below: pcgan_conv2d_pack_weights' image with every group of 4 consecutive k PRE-SPLIT into
+ * [4 fp16 high pieces | 4 fp16 low pieces] of the weights scaled by the power of two that w_amax (64 partial maxima, device) implies --
+ * the weights change once per optimizer step while each net runs 2-4 times in between, so the kernel's weight path is a plain copy.
+ * The SAME w_amax must be given to the convolution calls (their epilogue divides by that scale).  Size: pcgan_conv2d_packed_bytes. */
+int pcgan_conv2d_hgemm_pack(const pcgan_conv_desc* d, int pass, const float* w, const float* w_amax, float* packed, pcgan_stream_t s);
 int pcgan_conv2d_fwd_packed_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_amax, const float* packed,
                                    const float* w_amax, const float* bias, void* y, int act, float slope, void* ws, size_t ws_bytes,
                                    pcgan_stream_t s);
@@ -370,6 +375,11 @@ int pcgan_resblock_bwd(const pcgan_resblock_desc* d, const void* dout, const voi
  * whichever entry point issued them.  pcgan_timer_enable(capacity) creates `capacity` event pairs per kind and switches recording on
  * (0: off, events destroyed); pcgan_timer_read waits for the recorded pairs of one kind, writes their durations in ms (at most cap) and
  * resets that kind; returns the count or -1.  The only global state of the library; off by default, never records inside a graph capture. */
+/* Non-finite sentinel of the fp16 two-piece route: the kernels that scale their operands by a device-side maximum count the waves that
+ * produced an inf / NaN result into *dev_word (a device word the caller owns and zeroes; NULL switches the sentinel off).  An operand
+ * element above the maximum its scale came from -- a stale maximum -- overflows fp16 and poisons everything it touches, so a non-zero
+ * count means "stale operand maxima or non-finite inputs"; the host checks it where it synchronises anyway. */
+int pcgan_set_nonfinite_counter(unsigned int* dev_word);
 int pcgan_timer_enable(int capacity);
 int pcgan_timer_read(int kind, float* ms, int cap);
 

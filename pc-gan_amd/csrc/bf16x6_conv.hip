@@ -590,6 +590,7 @@ struct HaloArgs {
     const float* x_amax;   // PK_F16X2: x_namax partial maxima of |X| (device), and the weights' largest magnitude (pack kernel)
     const float* w_amax;
     int x_namax;
+    unsigned* ovf;         // non-finite sentinel (common.h), PK_F16X2 only; may be null
     const void* R;         // optional [N][M][H][W] tensor added to the result (after bias / activation): the skip connection's gradient
                            // summed into the data gradient of a residual block's first convolution (autograd's `grad +=` pass)
 };
@@ -971,6 +972,7 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
 
     // epilogue: acc[i][j][r] = Y[m0 + wave*32 + (r/4)*8 + hi*4 + r%4][pixel j*32 + lo]; a tile is RT full rows of image n
     const float isx = 1.f / sx, isw = 1.f / sw;    // powers of two: exact
+    bool bad = false;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const size_t yo = (size_t)n * a.M * HW + (size_t)y0 * QW + j * 32 + lo;
@@ -981,12 +983,14 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
                 const int m = mt * BM + wave * 32 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
                 if (m < a.M) {
                     const float av = PK == PK_F16X2 ? (acc[i][j][r] * isx) * isw : acc[i][j][r];
+                    if constexpr (PK == PK_F16X2) bad |= is_nonfinite(av);
                     float v = act_apply(av + (a.bias ? a.bias[m] : 0.f), a.act, a.slope);
                     if (a.R) v += ld1((const TA*)a.R + yo + (size_t)m * HW);
                     st1((TA*)a.Y + yo + (size_t)m * HW, v);
                 }
             }
     }
+    if constexpr (PK == PK_F16X2) report_nonfinite(a.ovf, bad);
 }
 
 // ---- fp16 two-piece route (fp32 tensors) / bf16 one-product route (bf16 tensors): weight gradient of a padded convolution -----------
@@ -1010,6 +1014,7 @@ struct HWgradArgs {
     const float* dy_amax;
     int x_namax, dy_namax;
     int ntile, nwg;        // column tiles, workgroups that have work (the grid is padded to a multiple of 8)
+    unsigned* ovf;         // non-finite sentinel (common.h), fp32 tensors only; may be null
 };
 
 // NC = column tiles of 128 per workgroup (2 with the 256-row tile: the dy tile is loaded and split once for 256 columns)
@@ -1325,6 +1330,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
 
     // epilogue: acc[i][j][r] = part[split][row wm*64 + i*32 + (r/4)*8 + hi*4 + r%4][column wp*64 + j*32 + lo]
     const float isx = 1.f / sx, isd = 1.f / sdy;
+    bool bad = false;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int cg = bx * CW + wp * (CW / 2) + j * 32 + lo;
@@ -1335,9 +1341,14 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
-                if (m < a.K) out[(size_t)m * CT] = (acc[i][j][r] * isx) * isd;
+                const float v = (acc[i][j][r] * isx) * isd;
+                if (m < a.K) {
+                    out[(size_t)m * CT] = v;
+                    if constexpr (!HALF) bad |= is_nonfinite(v);
+                }
             }
     }
+    if constexpr (!HALF) report_nonfinite(a.ovf, bad);
 }
 
 static int bsplit_check(const pcgan_conv_desc* d) {
@@ -1685,6 +1696,7 @@ extern "C" int pcgan_conv2d_fwd_hsplit(const pcgan_conv_desc* d, const void* x, 
     h.x_amax = x_amax;
     h.x_namax = n_amax;
     h.w_amax = (const float*)((const char*)packed + body);
+    h.ovf = pcgan::nonfinite_counter();
     const dim3 grid((unsigned)((long)d->N * d->H * d->W / 128 * h.nMt));
     pcgan::launch_halo<pcgan::BH_FWD>(d, d->W, grid, (hipStream_t)s, h, true);
     PCGAN_LAUNCH_CHECK();
@@ -1710,6 +1722,7 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit_add(const pcgan_conv_desc* d, const 
     h.x_amax = dy_amax;
     h.x_namax = n_amax;
     h.w_amax = (const float*)((const char*)packed + body);
+    h.ovf = pcgan::nonfinite_counter();
     h.R = add;
     const dim3 grid((unsigned)((long)d->N * d->H * d->W / 128 * h.nMt));
     pcgan::launch_halo<pcgan::BH_DGRAD>(d, d->W, grid, (hipStream_t)s, h, true);
@@ -1787,6 +1800,7 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     a.xp_bytes = (unsigned)((size_t)d->N * d->C * Hp * Wp * es);
     a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * es);
     a.x_amax = x_amax; a.x_namax = n_xamax; a.dy_amax = dy_amax; a.dy_namax = n_dyamax;
+    a.ovf = half ? nullptr : pcgan::nonfinite_counter();
     const int cw = hsplit_wgrad_cw(d);
     a.ntile = (d->C * d->R * d->S + cw - 1) / cw;
     a.nwg = a.ntile * splits;

@@ -87,6 +87,15 @@ extern "C" int pcgan_timer_read(int kind, float* ms, int cap) {
     return n;
 }
 
+namespace pcgan {
+static std::atomic<unsigned*> g_nonfinite{nullptr};
+unsigned* nonfinite_counter() { return g_nonfinite.load(std::memory_order_relaxed); }
+}  // namespace pcgan
+extern "C" int pcgan_set_nonfinite_counter(unsigned int* dev_word) {
+    pcgan::g_nonfinite.store(dev_word);
+    return 0;
+}
+
 extern "C" const char* pcgan_last_error(void) { return pcgan::g_err; }
 extern "C" int pcgan_version(void) { return 100; }
 

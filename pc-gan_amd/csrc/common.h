@@ -45,6 +45,18 @@ static inline int timer_kind_res(const pcgan_conv_desc* d, int kind) {
     return (d && d->K == 256 && d->C == 256 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad_mode == 1 && d->pad == 1) ? kind : -1;
 }
 
+// ---- non-finite sentinel of the fp16 route --------------------------------------------------------------------------------------------
+// An operand element larger than the maximum its scale was derived from (a stale `_pcgan_amax`: the tensor was rewritten behind the
+// host's back) overflows its fp16 piece to inf, and every product it enters becomes inf / NaN.  The epilogues of the fp16-route kernels
+// therefore count workgroups that produced a non-finite result into ONE device word the host registered (pcgan_set_nonfinite_counter;
+// null = off) and the host raises when it next looks (hip/ops.py: check_nonfinite) -- loud instead of silent.  One class test per
+// result and one ballot per wave: nothing in the K loop.
+unsigned* nonfinite_counter();
+__device__ __forceinline__ bool is_nonfinite(float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ void report_nonfinite(unsigned* counter, bool bad) {
+    if (counter != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(counter, 1u);
+}
+
 static inline int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

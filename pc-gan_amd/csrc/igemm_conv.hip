@@ -174,6 +174,7 @@ struct IgemmArgs {
     const float* x_amax;
     const float* w_amax;
     int x_namax, hsplit;
+    unsigned* ovf;      // non-finite sentinel (common.h); may be null
 };
 
 struct Geom {
@@ -961,22 +962,21 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
             else *reinterpret_cast<usK*>(reinterpret_cast<unsigned short*>(&Bs[buf][0][(ksub >> 1) * BP + pl]) + (ksub & 1) * 4) = v;
             return;
         }
+        // the weights arrive PRE-SPLIT (pcgan_conv2d_hgemm_pack: they only change once per optimizer step while every net runs 2-4
+        // times in between): the 16 bytes a thread loaded are [4 x fp16 high pieces | 4 x fp16 low pieces] of 4 consecutive k of its
+        // row, scaled by the same power of two the epilogue divides by -- two 8-byte LDS stores, no arithmetic
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int q = tid + 256 * j;
             const int row = q >> 2, kc = (q & 3) * 4;
-            f16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 x, y;
-                split2h(__uint_as_float(r.av[j][e]) * sw, x, y);
-                h[e] = x;
-                l[e] = y;
-            }
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 h, l;
+            h[0] = r.av[j][0]; h[1] = r.av[j][1];
+            l[0] = r.av[j][2]; l[1] = r.av[j][3];
             _Float16* d0 = reinterpret_cast<_Float16*>(&As[buf][0][(kc >> 3) * AH + row]) + (kc & 4);
             _Float16* d1 = reinterpret_cast<_Float16*>(&As[buf][NP - 1][(kc >> 3) * AH + row]) + (kc & 4);
-            *reinterpret_cast<f16x4*>(d0) = h;
-            *reinterpret_cast<f16x4*>(d1) = l;
+            *reinterpret_cast<u32x2*>(d0) = h;
+            *reinterpret_cast<u32x2*>(d1) = l;
         }
         if constexpr (KPT == 8) {
             f16x8 h, l;
@@ -1084,6 +1084,16 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
     // epilogue (as igemm2_kernel): scale back (powers of two: exact), bias + activation or raw partial sum of a K split
     const float isx = 1.f / sx, isw = 1.f / sw;
     const int YhYw = a.Yh * a.Yw;
+    bool bad = false;
+    if constexpr (!HALF) {       // (before the ragged-tile `continue`s below: every lane of the wave takes part in the ballot)
+#pragma unroll
+        for (int j = 0; j < PJ; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bad |= is_nonfinite(acc[i][j][r]);
+        report_nonfinite(a.ovf, bad);
+    }
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
         const int pix = p0 + wp * WPT + j * 32 + lo;
@@ -2701,6 +2711,7 @@ static int conv2d_fwd_impl(const pcgan_conv_desc* d, const void* x, const float*
     a.chunked = chunked_k(d->C, d->K, d->R, d->S) ? 1 : (cg4_k(d->C, d->K, d->R, d->S) ? 2 : 0);
     if (hs) {
         a.hsplit = 1; a.x_amax = hs->x_amax; a.x_namax = hs->n_amax; a.w_amax = hs->w_amax;
+        a.ovf = pcgan::nonfinite_counter();
     }
     PhaseArgs& p = a.ph[0];
     p.A = A; p.Kp = RS * Cgp; p.Hs = d->P; p.Ws = d->Q; p.fy = 0; p.fx = 0;
@@ -2768,6 +2779,7 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const void* dy, const 
     a.rowfold = rowfold;
     if (hs) {
         a.hsplit = 1; a.x_amax = hs->x_amax; a.x_namax = hs->n_amax; a.w_amax = hs->w_amax;
+        a.ovf = pcgan::nonfinite_counter();
     }
     a.x_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * esz(d));
 
@@ -2920,6 +2932,44 @@ extern "C" int pcgan_conv2d_bwd_data_packed_hsplit(const pcgan_conv_desc* d, con
     PCGAN_CHECK(packed && dx && dy_amax && n_amax > 0 && w_amax, "conv2d_bwd_data_packed_hsplit: null pointer");
     const HsplitOpt hs = {dy_amax, n_amax, w_amax};
     return conv2d_bwd_data_impl(d, dy, nullptr, packed, bias, dx, ws, ws_bytes, s, &hs);
+}
+
+// in-place pre-split of a packed fp32 weight image for hgemm_kernel: every aligned group of 4 consecutive floats (what one thread
+// feeds to LDS per stage) becomes [4 fp16 high pieces][4 fp16 low pieces] of the values scaled by pow2_scale(max |w|)
+__global__ void __launch_bounds__(256) hgemm_presplit_kernel(float* __restrict__ A, size_t n4, const float* __restrict__ w_amax) {
+    __shared__ float scratch[16];
+    const float sw = pow2_scale(block_max(threadIdx.x < WEIGHT_AMAX_SLOTS ? w_amax[threadIdx.x] : 0.f, scratch));
+    __shared__ float sws;
+    if (threadIdx.x == 0) sws = sw;
+    __syncthreads();
+    const float s = sws;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(A)[i];
+        f16x4 h, l;
+        _Float16 x, y;
+        split2h(v.x * s, x, y); h[0] = x; l[0] = y;
+        split2h(v.y * s, x, y); h[1] = x; l[1] = y;
+        split2h(v.z * s, x, y); h[2] = x; l[2] = y;
+        split2h(v.w * s, x, y); h[3] = x; l[3] = y;
+        reinterpret_cast<f16x4*>(A)[2 * i] = h;
+        reinterpret_cast<f16x4*>(A)[2 * i + 1] = l;
+    }
+}
+
+extern "C" int pcgan_conv2d_hgemm_pack(const pcgan_conv_desc* d, int pass, const float* w, const float* w_amax, float* packed,
+                                       pcgan_stream_t s) {
+    if (check_desc(d)) return 1;
+    PCGAN_CHECK(pcgan_conv2d_hgemm_supported(d, pass), "conv2d_hgemm_pack: unsupported shape or pass");
+    PCGAN_CHECK(w && w_amax && packed, "conv2d_hgemm_pack: null pointer");
+    if (pcgan_conv2d_pack_weights(d, pass, w, packed, s)) return 1;
+    // the A matrices of all phases lie back to back at the start of the packed buffer: K * RS * round4(C) floats (forward),
+    // C * RS * round4(K) (data gradient: the stride phases partition the taps)
+    const size_t n = pass == PCGAN_PASS_FWD ? (size_t)d->K * d->R * d->S * round4(d->C) : (size_t)d->C * d->R * d->S * round4(d->K);
+    const size_t n4 = n / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(hgemm_presplit_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, packed, n4, w_amax);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" size_t pcgan_conv2d_packed_bytes(const pcgan_conv_desc* d, int pass) {

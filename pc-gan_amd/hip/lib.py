@@ -110,9 +110,11 @@ SIGNATURES = {
     'pcgan_resblock_fwd': (_i, [_rp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcgan_resblock_bwd': (_i, [_rp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _sz, _vp, _vp, _vp]),
+    'pcgan_set_nonfinite_counter': (_i, [_vp]),
     'pcgan_timer_enable': (_i, [_i]),
     'pcgan_timer_read': (_i, [_i, _vp, _i]),
     'pcgan_conv2d_hgemm_supported': (_i, [_dp, _i]),
+    'pcgan_conv2d_hgemm_pack': (_i, [_dp, _i, _vp, _vp, _vp, _vp]),
     'pcgan_conv2d_fwd_packed_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
     'pcgan_conv2d_bwd_data_packed_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pcgan_conv2d_hsplit_wgrad_supported': (_i, [_dp]),

@@ -233,6 +233,8 @@ PASS_FWD_BSPLIT = 100    # cache keys only
 PASS_BWD_BSPLIT = 101
 PASS_FWD_HSPLIT = 102
 PASS_BWD_HSPLIT = 103
+PASS_FWD_HGEMM = 104     # pcgan_conv2d_hgemm_pack: the fp32 packed image with pre-split (two fp16 pieces) weights
+PASS_BWD_HGEMM = 105
 # Which split the fp32 residual convolutions (forward, data gradient) take on the matrix pipe: 'f16' = two scaled fp16 pieces, three
 # products (csrc/bf16x6_conv.hip, "fp16 route"); 'bf16' = three bf16 pieces, six products.  Same measured error, half the MFMAs.
 HSPLIT = os.environ.get('PCGAN_SPLIT', 'f16') == 'f16'
@@ -300,7 +302,8 @@ def _weight_amax(lib, w, cache):
     return out
 
 
-def _packed_weights(lib, d, pass_, w, cache):
+def _packed_weights(lib, d, pass_, w, cache, wmax=None):
+    """wmax: the weights' partial maxima (_weight_amax), needed by the pre-split packs of the hgemm route"""
     key = (pass_, d.stride, d.pad, d.pad_mode, d.dtype)
     stamp = _weight_stamp(w)
     ent = cache.get(key)
@@ -315,6 +318,8 @@ def _packed_weights(lib, d, pass_, w, cache):
         nb = int(lib.pcgan_conv2d_bsplit_packed_bytes(ctypes.byref(d)))
     elif pass_ == PASS_BWD_BSPLIT:
         nb = int(lib.pcgan_conv2d_bsplit_dgrad_packed_bytes(ctypes.byref(d)))
+    elif pass_ in (PASS_FWD_HGEMM, PASS_BWD_HGEMM):
+        nb = int(lib.pcgan_conv2d_packed_bytes(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HGEMM else _L.PASS_BWD_DATA))
     else:
         nb = int(lib.pcgan_conv2d_packed_bytes(ctypes.byref(d), pass_))
     nb = max(nb, 256)
@@ -332,6 +337,9 @@ def _packed_weights(lib, d, pass_, w, cache):
         _L.check(lib.pcgan_conv2d_bsplit_pack(ctypes.byref(d), _p(w), _p(buf), _stream()), 'conv2d_bsplit_pack')
     elif pass_ == PASS_BWD_BSPLIT:
         _L.check(lib.pcgan_conv2d_bsplit_dgrad_pack(ctypes.byref(d), _p(w), _p(buf), _stream()), 'conv2d_bsplit_dgrad_pack')
+    elif pass_ in (PASS_FWD_HGEMM, PASS_BWD_HGEMM):
+        _L.check(lib.pcgan_conv2d_hgemm_pack(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HGEMM else _L.PASS_BWD_DATA, _p(w), _p(wmax),
+                                             _p(buf), _stream()), 'conv2d_hgemm_pack')
     else:
         _L.check(lib.pcgan_conv2d_pack_weights(ctypes.byref(d), pass_, _p(w), _p(buf), _stream()), 'conv2d_pack_weights')
     ev = torch.cuda.Event()
@@ -349,12 +357,48 @@ class _Plan(object):
     __slots__ = ('d', 'dref', 'P', 'Q', 'ws_bytes', 'route', 'pack_pass')
 
 
+# Non-finite sentinel of the fp16 route (include/pcgan_hip.h: pcgan_set_nonfinite_counter): one device word the kernels count
+# inf / NaN-producing waves into.  A stale operand maximum (a tensor rewritten through `.data` or a raw pointer after a norm kernel
+# attached its maxima: `_pcgan_amax` is trusted on the tensor version) overflows fp16 and lands here instead of passing silently.
+NONFINITE_CHECK = os.environ.get('PCGAN_NONFINITE_CHECK', '1') != '0'
+_SENTINEL = {}
+
+
+def _sentinel():
+    if not NONFINITE_CHECK or 'word' in _SENTINEL or not torch.cuda.is_available():
+        return
+    _SENTINEL['word'] = torch.zeros(1, dtype=torch.int32, device='cuda')
+    _L.check(_L.load().pcgan_set_nonfinite_counter(_vp(_SENTINEL['word'].data_ptr())), 'set_nonfinite_counter')
+
+
+def nonfinite_count(reset=True):
+    """waves of fp16-route kernels that produced inf / NaN since the last reset (synchronises)"""
+    w = _SENTINEL.get('word')
+    if w is None:
+        return 0
+    n = int(w.item())
+    if n and reset:
+        w.zero_()
+    return n
+
+
+def check_nonfinite(where=''):
+    """raise if an fp16-route convolution produced non-finite values since the last check.  Called where the host synchronises anyway
+    (BaseModel.get_current_losses, the GPU test suite after every test)."""
+    n = nonfinite_count()
+    if n:
+        raise RuntimeError('pcgan_amd: %d wave(s) of the fp16-route convolutions produced inf / NaN%s -- an operand exceeded the maximum its '
+                           'scale was derived from (a tensor rewritten through .data / a raw pointer after its maxima were attached?) or the '
+                           'inputs were already non-finite' % (n, (' (' + where + ')') if where else ''))
+
+
 def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
     key = (pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias, BF16X6, HSPLIT, HGEMM, BSPLIT_MIN_PIXELS)
     p = _PLANS.get(key)
     if p is not None:
         return p
     lib = _L.load()
+    _sentinel()
     p = _Plan()
     p.d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
     p.dref = ctypes.byref(p.d)
@@ -370,7 +414,7 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
         elif bsplit:
             p.route, p.pack_pass = 'bsplit', PASS_FWD_BSPLIT
         elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_FWD):
-            p.route, p.pack_pass = 'hgemm', _L.PASS_FWD
+            p.route, p.pack_pass = 'hgemm', PASS_FWD_HGEMM
         else:
             p.route, p.pack_pass = 'packed', _L.PASS_FWD
     elif pass_ == _L.PASS_BWD_DATA:
@@ -381,7 +425,7 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
         elif bsplit:
             p.route, p.pack_pass = 'bsplit', PASS_BWD_BSPLIT
         elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_BWD_DATA):
-            p.route, p.pack_pass = 'hgemm', _L.PASS_BWD_DATA
+            p.route, p.pack_pass = 'hgemm', PASS_BWD_HGEMM
         else:
             p.route, p.pack_pass = 'packed', _L.PASS_BWD_DATA
     else:
@@ -419,10 +463,11 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
     y = torch.empty((N, K, pl.P, pl.Q), dtype=x.dtype, device=x.device)
     ws = _ws(pl.ws_bytes, x.device)
     if pack_cache is not None:
-        pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache)
+        wmax = _weight_amax(lib, w, pack_cache) if pl.route == 'hgemm' else None      # (before the pack: it pre-splits with this scale)
+        pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache, wmax)
         _count_route('fwd', pl.route)
         if pl.route == 'hgemm':
-            xmax, wmax = amax_of(x), _weight_amax(lib, w, pack_cache)
+            xmax = amax_of(x)
             _L.check(lib.pcgan_conv2d_fwd_packed_hsplit(d, _p(x), _p(xmax), xmax.numel(), _p(pk), _p(wmax), _p(bias), _p(y), act,
                                                         float(slope), _p(ws), ws.numel(), _stream()), 'conv2d_fwd_packed_hsplit')
         elif pl.route == 'hsplit':
@@ -454,7 +499,8 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
     dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device)
     ws = _ws(pl.ws_bytes, dy.device)
     if pack_cache is not None:
-        pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache)
+        wmax = _weight_amax(lib, w, pack_cache) if pl.route == 'hgemm' else None
+        pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache, wmax)
         _count_route('dgrad', pl.route)
         if pl.route == 'hsplit':
             dmax = amax_of(dy)
@@ -462,7 +508,7 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
         elif pl.route == 'bsplit':
             _L.check(lib.pcgan_conv2d_bwd_data_bsplit(d, _p(dy), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_bsplit')
         elif pl.route == 'hgemm':
-            dmax, wmax = amax_of(dy), _weight_amax(lib, w, pack_cache)
+            dmax = amax_of(dy)
             _L.check(lib.pcgan_conv2d_bwd_data_packed_hsplit(d, _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(wmax), _p(bias), _p(dx),
                                                              _p(ws), ws.numel(), _stream()), 'conv2d_bwd_data_packed_hsplit')
         else:

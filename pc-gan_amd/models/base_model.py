@@ -17,6 +17,7 @@ from collections import OrderedDict
 import torch
 
 from . import networks
+from ..hip import ops as hip_ops
 from ..hip import parallel
 
 _STALE_NORM_KEYS = ('running_mean', 'running_var', 'num_batches_tracked')
@@ -145,4 +146,7 @@ class BaseModel(object):
     def get_current_losses(self):
         """float(...) of every loss_<name>: the only device->host synchronisation of the loop (train.py reads it every
         print_freq iterations)."""
-        return OrderedDict((name, float(getattr(self, 'loss_' + name))) for name in self.loss_names if isinstance(name, str))
+        out = OrderedDict((name, float(getattr(self, 'loss_' + name).detach() if isinstance(getattr(self, 'loss_' + name), torch.Tensor)
+                                        else getattr(self, 'loss_' + name))) for name in self.loss_names if isinstance(name, str))
+        hip_ops.check_nonfinite('get_current_losses')      # the fp16 route's overflow sentinel: the device is in sync here anyway
+        return out

@@ -344,3 +344,45 @@ def test_hsplit_weight_gradient_general(dev, N, C, H, W, K, k, stride, pad, mode
     finally:
         ops.BSPLIT_MIN_PIXELS = old
     assert torch.equal(dw2, dw) or float((dw2.double().cpu() - ref).norm() / ref.norm()) < 3e-6
+
+
+@pytest.mark.allow_nonfinite
+def test_stale_operand_maximum_is_caught_loudly(dev, monkeypatch):
+    """The fp16 route trusts `tensor._pcgan_amax` on the tensor VERSION.  A write through `.data` (or a raw-pointer kernel) after a
+    norm kernel attached the maxima does not bump the version: the stale (too small) maximum makes the scaled operand overflow fp16
+    and every product it enters becomes inf / NaN.  That must not pass silently: the kernels' non-finite sentinel counts it and the
+    host raises at its next synchronisation point (ops.check_nonfinite, called by BaseModel.get_current_losses and after every GPU
+    test).  Rewriting the tensor the honest way (an op that bumps the version) drops the stale maxima and the result is right."""
+    from pcgan_amd.hip import ops
+    monkeypatch.setattr(ops, 'BSPLIT_MIN_PIXELS', 0)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 256, 32, 32, generator=g).to(dev)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.05).to(dev)
+    h, _, _ = ops.instnorm_fwd(x, None, 1e-5, 0, 0.0)             # a norm kernel attaches the plane maxima of its output
+    assert '_pcgan_amax' in h.__dict__
+    assert ops.nonfinite_count() == 0
+    cache = {}
+    y0 = ops.conv2d_fwd(h, w, None, 1, 1, 1, pack_cache=cache)
+    assert torch.isfinite(y0).all() and ops.nonfinite_count() == 0
+    h.data.mul_(1.0e4)                                              # behind autograd's back: same version, 10^4 x larger values
+    y1 = ops.conv2d_fwd(h, w, None, 1, 1, 1, pack_cache=cache)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(y1).all(), 'the stale maximum should have overflowed the fp16 pieces'
+    with pytest.raises(RuntimeError, match='inf / NaN'):
+        ops.check_nonfinite('test')
+    assert ops.nonfinite_count() == 0, 'the check resets the counter'
+    # the same values written by an op that bumps the version: the stale maxima are ignored, an absmax pass takes their place
+    h2 = h.clone()
+    h2.mul_(1.0)
+    assert h2.__dict__.get('_pcgan_amax') is None or h2.__dict__['_pcgan_amax'][0] != h2._version
+    y2 = ops.conv2d_fwd(h2, w, None, 1, 1, 1, pack_cache=cache)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(h2.double().cpu(), (1, 1, 1, 1), mode='reflect'), w.double().cpu())
+    err = float((y2.double().cpu() - ref).norm() / ref.norm())
+    assert err < 3e-6 and ops.nonfinite_count() == 0, err
+    # the weight-gradient and data-gradient kernels carry the sentinel too
+    dy = torch.randn(2, 256, 32, 32, generator=g).to(dev)
+    ops._attach_amax(dy, torch.full((4,), 1e-3, device=dev))       # a maximum that is far too small
+    ops.conv2d_bwd_data(dy, w, (32, 32), 1, 1, 1, pack_cache=cache)
+    assert ops.nonfinite_count() > 0
+    ops.conv2d_bwd_weight(h2, dy, (256, 256, 3, 3), 1, 1, 1)
+    assert ops.nonfinite_count() > 0
