@@ -290,7 +290,7 @@ int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const void* x, cons
  * hands over (pcgan_instnorm_* pmax outputs).  It must be a true bound: a larger element would overflow.
  * pass = PCGAN_PASS_FWD | PCGAN_PASS_BWD_DATA; image width 32 or 64, 128 / width rows dividing the height, gathered channels a
  * multiple of 32, produced channels a multiple of 256.  packed: pcgan_conv2d_hsplit_packed_bytes(d, pass) bytes, valid for any
- * batch size; the pack call also stores the weights' largest magnitude in it. */
+ * batch size; the pack call also stores the largest magnitude of every weight row in it (one power-of-two scale per row). */
 /* out[0 .. slots) = partial maxima of |x| (one per workgroup, 1 <= slots <= 1024; no atomics, nothing to clear beforehand);
  * pcgan_absmax_slots(n) = the count that keeps the pass bandwidth-bound.  Weight tensors use exactly 64 slots. */
 int pcgan_absmax_slots(size_t n);
@@ -310,13 +310,16 @@ int pcgan_conv2d_bwd_data_hsplit_add(const pcgan_conv_desc* d, const void* dy, c
  * stride; forward with zero / reflection padding, data gradient with zero padding -- incl. nn.ConvTranspose2d forward,
  * models/networks.py:584-602, 734-763; models/resnet.py): the fp16 two-piece form of pcgan_conv2d_fwd_packed /
  * pcgan_conv2d_bwd_data_packed.  Same workspace and semantics; packed weights from pcgan_conv2d_hgemm_pack (desc.dtype = PCGAN_BF16:
- * from pcgan_conv2d_pack_weights); w_amax[0 .. 64) = partial maxima of |weight| (pcgan_absmax over w with 64 slots). */
+ * from pcgan_conv2d_pack_weights, w_amax unused); w_amax = the row maxima pcgan_conv2d_hgemm_pack wrote. */
 int pcgan_conv2d_hgemm_supported(const pcgan_conv_desc* d, int pass);
-/* packed weights of the two calls below: pcgan_conv2d_pack_weights' image with every group of 4 consecutive k PRE-SPLIT into
- * [4 fp16 high pieces | 4 fp16 low pieces] of the weights scaled by the power of two that w_amax (64 partial maxima, device) implies --
- * the weights change once per optimizer step while each net runs 2-4 times in between, so the kernel's weight path is a plain copy.
- * The SAME w_amax must be given to the convolution calls (their epilogue divides by that scale).  Size: pcgan_conv2d_packed_bytes. */
-int pcgan_conv2d_hgemm_pack(const pcgan_conv_desc* d, int pass, const float* w, const float* w_amax, float* packed, pcgan_stream_t s);
+/* packed weights of the two calls below: pcgan_conv2d_pack_weights' image with every group of 4 consecutive k of a row PRE-SPLIT into
+ * [4 fp16 high pieces | 4 fp16 low pieces] of the weights scaled by ONE POWER OF TWO PER ROW of the pass's weight matrix (forward: per
+ * output channel; data gradient: per input channel) -- the weights change once per optimizer step while each net runs 2-4 times in
+ * between, so the kernel's weight path is a plain copy, and a filter row far below the tensor's largest weight keeps its 22 bits.
+ * w_rowmax (K floats for PCGAN_PASS_FWD, C for PCGAN_PASS_BWD_DATA) is WRITTEN by the pack call -- the largest magnitude of every row --
+ * and must be handed to the convolution calls as `w_amax` (their epilogue divides row m by pow2(w_rowmax[m])).
+ * Size of packed: pcgan_conv2d_packed_bytes. */
+int pcgan_conv2d_hgemm_pack(const pcgan_conv_desc* d, int pass, const float* w, float* w_rowmax, float* packed, pcgan_stream_t s);
 int pcgan_conv2d_fwd_packed_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_amax, const float* packed,
                                    const float* w_amax, const float* bias, void* y, int act, float slope, void* ws, size_t ws_bytes,
                                    pcgan_stream_t s);

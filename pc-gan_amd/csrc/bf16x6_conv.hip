@@ -94,15 +94,10 @@ __device__ __forceinline__ void pack_store8(__bf16* __restrict__ A, size_t e, si
 
 // weights w[M][C][R][S] -> [piece][mt][stage][half][BM][8] bf16 (BM = 128 << bm_shift), stage = chunk * T + tap, k in stage =
 // channel in chunk
-// np = 2: two fp16 pieces of w * pow2_scale(*amax) (the fp16 route)
+// np = 2: two fp16 pieces of w[m][..] * pow2_scale(rowmax[m]) (the fp16 route: ONE power of two per output row, so that a filter
+// row far below the tensor's largest weight keeps its 22 bits -- the epilogue divides row m by the same power)
 __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int M, int C, int T, int nMt, int nst,
-                                   int bm_shift, int np, const float* __restrict__ amax = nullptr) {
-    __shared__ float wscale_s;      // the scale of the fp16 route: one thread reduces the partial maxima for its workgroup
-    if (np == 2) {
-        if (threadIdx.x == 0) wscale_s = pow2_scale(max_of_partials(amax, WEIGHT_AMAX_SLOTS));
-        __syncthreads();
-    }
-    const float wscale = np == 2 ? wscale_s : 1.f;
+                                   int bm_shift, int np, const float* __restrict__ rowmax = nullptr) {
     const int BM = 128 << bm_shift;
     const size_t per_piece = (size_t)nMt * nst * 16 * BM;
     // a thread builds one 16-byte entry (8 consecutive channels of a row and tap) of every piece: 8 loads in flight, one store per piece
@@ -114,6 +109,7 @@ __global__ void bsplit_pack_kernel(const float* __restrict__ w, __bf16* __restri
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = m < M ? w[((size_t)m * C + c0 + j) * T + tap] : 0.f;
+        const float wscale = (np == 2 && m < M) ? pow2_scale(rowmax[m]) : 1.f;
         pack_store8(A, e, per_piece, np, wscale, v);
     }
 }
@@ -144,6 +140,25 @@ __global__ void __launch_bounds__(256) absmax_kernel(const TA* __restrict__ x, s
     __shared__ float red[16];
     m = block_max(m, red);
     if (threadIdx.x == 0) out[blockIdx.x] = m;
+}
+
+// largest magnitude of every ROW of a convolution's weight matrix, w[K][C][T]: by_c = 0 the rows of the forward GEMM (output channel k:
+// C * T contiguous values), by_c = 1 the rows of the data gradient (input channel c: K runs of T values).  One workgroup per row.
+__global__ void __launch_bounds__(256) weight_row_absmax_kernel(const float* __restrict__ w, int K, int C, int T, int by_c, float* __restrict__ out) {
+    const int row = blockIdx.x;
+    float m = 0.f;
+    if (!by_c) {
+        const float* p = w + (size_t)row * C * T;
+        for (int i = threadIdx.x; i < C * T; i += 256) m = fmaxf(m, fabsf(p[i]));
+    } else {
+        for (int i = threadIdx.x; i < K * T; i += 256) {
+            const int k = i / T, t = i - k * T;
+            m = fmaxf(m, fabsf(w[((size_t)k * C + row) * T + t]));
+        }
+    }
+    __shared__ float red[16];
+    m = block_max(m, red);
+    if (threadIdx.x == 0) out[row] = m;
 }
 
 // ---- weight gradient as the same GEMM with the roles turned: rows = output channels k (operand A = dy, re-split per call), columns
@@ -268,14 +283,8 @@ __global__ void bsplit_wgrad_reduce_kernel(const float* __restrict__ part, float
 // row class 2 (row H-2): wf'[2] = wf[2] + wf[0].
 // nphase = 1: only row class 0, the plain flipped weights (all the window kernel reads)
 __global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ A, int K, int C, int nMt, int nst, int bm_shift,
-                                         int np, const float* __restrict__ amax = nullptr, int nphase = 3) {
-    __shared__ float wscale_s;      // the scale of the fp16 route: one thread reduces the partial maxima for its workgroup
-    if (np == 2) {
-        if (threadIdx.x == 0) wscale_s = pow2_scale(max_of_partials(amax, WEIGHT_AMAX_SLOTS));
-        __syncthreads();
-    }
-    const float wscale = np == 2 ? wscale_s : 1.f;
-    const int BM = 128 << bm_shift;
+                                         int np, const float* __restrict__ rowmax = nullptr, int nphase = 3) {
+    const int BM = 128 << bm_shift;      // (rowmax: per INPUT channel c -- the rows of the data gradient -- as in bsplit_pack_kernel)
     const size_t per_piece = (size_t)nMt * nst * 16 * BM, per_phase = (size_t)np * per_piece;
     // (nphase row classes x per_piece / 8 entries of 8 values; each entry writes its np pieces.  A folded row-class weight is at most
     // twice the largest weight: still far inside the fp16 range)
@@ -299,6 +308,7 @@ __global__ void bsplit_pack_dgrad_kernel(const float* __restrict__ w, __bf16* __
                 if (fold) v[j] += wk[rp * 3 + (2 - sp)];   // + wf[2 - rp][sp]
             }
         }
+        const float wscale = (np == 2 && c < C) ? pow2_scale(rowmax[c]) : 1.f;
         pack_store8(A + (size_t)phase * per_phase, e, per_piece, np, wscale, v);
     }
 }
@@ -587,8 +597,8 @@ struct HaloArgs {
     int N, C, H, M, nMt, nch, act;
     float slope;
     unsigned x_bytes, a_bytes;
-    const float* x_amax;   // PK_F16X2: x_namax partial maxima of |X| (device), and the weights' largest magnitude (pack kernel)
-    const float* w_amax;
+    const float* x_amax;   // PK_F16X2: x_namax partial maxima of |X| (device), and the largest magnitude of every weight ROW [M]
+    const float* w_amax;   //           (the pack call scaled row m by pow2_scale(w_amax[m]); the epilogue divides by it)
     int x_namax;
     unsigned* ovf;         // non-finite sentinel (common.h), PK_F16X2 only; may be null
     const void* R;         // optional [N][M][H][W] tensor added to the result (after bias / activation): the skip connection's gradient
@@ -731,11 +741,10 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     // write 4 consecutive channels of one window entry (8 bytes per piece)
     typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
     typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
-    float sx = 1.f, sw = 1.f;
+    float sx = 1.f;
     if constexpr (PK == PK_F16X2) {      // largest of the partial maxima the producer left (one per plane, or a single value)
         const float m = thread_max_of_partials(a.x_amax, a.x_namax, tid, NT);
         sx = pow2_scale(block_max(m, red_scratch));
-        sw = pow2_scale(block_max(tid < WEIGHT_AMAX_SLOTS ? a.w_amax[tid] : 0.f, red_scratch));
         __syncthreads();
     }
     auto put_split = [&](unsigned lds, int buf, const float (&v)[4]) {
@@ -971,7 +980,17 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
     }
 
     // epilogue: acc[i][j][r] = Y[m0 + wave*32 + (r/4)*8 + hi*4 + r%4][pixel j*32 + lo]; a tile is RT full rows of image n
-    const float isx = 1.f / sx, isw = 1.f / sw;    // powers of two: exact
+    const float isx = 1.f / sx;    // powers of two: exact
+    float iswr[NI][16];            // ... and one per weight ROW (the pack call scaled row m by pow2_scale(w_amax[m]))
+    if constexpr (PK == PK_F16X2) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * BM + wave * 32 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+                iswr[i][r] = m < a.M ? 1.f / pow2_scale(a.w_amax[m]) : 1.f;
+            }
+    }
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -982,7 +1001,7 @@ __global__ void __launch_bounds__(512) bsplit_halo_kernel(HaloArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int m = mt * BM + wave * 32 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
                 if (m < a.M) {
-                    const float av = PK == PK_F16X2 ? (acc[i][j][r] * isx) * isw : acc[i][j][r];
+                    const float av = PK == PK_F16X2 ? (acc[i][j][r] * isx) * iswr[i][r] : acc[i][j][r];
                     if constexpr (PK == PK_F16X2) bad |= is_nonfinite(av);
                     float v = act_apply(av + (a.bias ? a.bias[m] : 0.f), a.act, a.slope);
                     if (a.R) v += ld1((const TA*)a.R + yo + (size_t)m * HW);
@@ -1351,6 +1370,12 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     if constexpr (!HALF) report_nonfinite(a.ovf, bad);
 }
 
+int launch_weight_row_absmax(const float* w, int K, int C, int T, int by_c, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(weight_row_absmax_kernel, dim3((unsigned)(by_c ? C : K)), dim3(256), 0, st, w, K, C, T, by_c, out);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
 static int bsplit_check(const pcgan_conv_desc* d) {
     PCGAN_CHECK(d, "conv2d_bsplit: null descriptor");
     PCGAN_CHECK(d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16, "conv2d_bsplit: dtype %d", d->dtype);
@@ -1624,7 +1649,8 @@ extern "C" int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const vo
 
 // ---- fp16 two-piece route of the reflection-padded 3x3 convolution (forward + data gradient), fp32 tensors -------------------------
 // packed buffer: [2 pieces][M tile][stage][k half][256 rows][8 fp16] (data gradient: the plain flipped weights -- the window kernel
-// has no row classes) followed by 256 bytes: 64 partial maxima of |w|
+// has no row classes) followed by the largest magnitude of every weight ROW (one float per produced channel, padded to 256 bytes):
+// row m is scaled by its own power of two, pow2_scale(rowmax[m]), which the epilogue divides out again -- exactly
 static size_t hsplit_body_bytes(const pcgan_conv_desc* d, int pass) {
     const int rows = pass == PCGAN_PASS_FWD ? d->K : d->C, chan = pass == PCGAN_PASS_FWD ? d->C : d->K;
     const size_t nMt = (rows + 255) / 256, nst = (size_t)(chan / 16) * 9;
@@ -1639,8 +1665,11 @@ extern "C" int pcgan_conv2d_hsplit_supported(const pcgan_conv_desc* d, int pass)
     return 0;
 }
 
+static size_t hsplit_tail_bytes(const pcgan_conv_desc* d, int pass) {
+    return pcgan::align_up((size_t)(pass == PCGAN_PASS_FWD ? d->K : d->C) * 4, 256);
+}
 extern "C" size_t pcgan_conv2d_hsplit_packed_bytes(const pcgan_conv_desc* d, int pass) {
-    return pcgan_conv2d_hsplit_supported(d, pass) ? hsplit_body_bytes(d, pass) + 256 : 0;
+    return pcgan_conv2d_hsplit_supported(d, pass) ? hsplit_body_bytes(d, pass) + hsplit_tail_bytes(d, pass) : 0;
 }
 
 extern "C" int pcgan_absmax_slots(size_t n) {
@@ -1664,8 +1693,9 @@ extern "C" int pcgan_conv2d_hsplit_pack(const pcgan_conv_desc* d, int pass, cons
     PCGAN_CHECK(w && packed, "conv2d_hsplit_pack: null pointer");
     hipStream_t st = (hipStream_t)s;
     const size_t body = hsplit_body_bytes(d, pass);
-    float* amax = (float*)((char*)packed + body);     // the 256-byte tail: WEIGHT_AMAX_SLOTS partial maxima
-    hipLaunchKernelGGL(pcgan::absmax_kernel<float>, dim3(pcgan::WEIGHT_AMAX_SLOTS), dim3(256), 0, st, w, (size_t)d->K * d->C * 9, amax);
+    float* amax = (float*)((char*)packed + body);     // the tail: the largest magnitude of every row of this pass's weight matrix
+    hipLaunchKernelGGL(pcgan::weight_row_absmax_kernel, dim3((unsigned)(pass == PCGAN_PASS_FWD ? d->K : d->C)), dim3(256), 0, st, w, d->K, d->C, 9,
+                       pass == PCGAN_PASS_FWD ? 0 : 1, amax);
     PCGAN_LAUNCH_CHECK();
     if (pass == PCGAN_PASS_FWD) {
         const int nMt = (d->K + 255) / 256, nst = (d->C / 16) * 9;

@@ -57,6 +57,9 @@ __device__ __forceinline__ void report_nonfinite(unsigned* counter, bool bad) {
     if (counter != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(counter, 1u);
 }
 
+// out[row] = largest |w| of every row of w[K][C][T] seen as the forward GEMM's A (by_c = 0: row = k) or the data gradient's (by_c = 1: row = c)
+int launch_weight_row_absmax(const float* w, int K, int C, int T, int by_c, float* out, hipStream_t st);
+
 static inline int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

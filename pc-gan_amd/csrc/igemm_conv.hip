@@ -851,6 +851,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
     __shared__ __attribute__((aligned(16))) f16x8 Bs[2][NP][2 * BP];     // [buffer][piece][k half * BP + pixel]
     __shared__ unsigned offT[TROWS][BP];
     __shared__ __attribute__((aligned(16))) float biasS[BM];
+    __shared__ __attribute__((aligned(16))) float iswS[BM];     // fp16 route: 1 / (the power of two row m0 + i of the weights was scaled by)
 
     const int nMt = (a.M + BM - 1) / BM;
     const int mt = blockIdx.x % nMt;
@@ -871,12 +872,13 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
     const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(P.A, (unsigned)a.M * (unsigned)Kp * 4u);
 
-    // operand scales (largest of the partial maxima the producer left)
-    float sx = 1.f, sw = 1.f;
+    // operand scales: the largest of the partial maxima the producer of X left; the weights were scaled ROW BY ROW by the pack call
+    // (a.w_amax[m] = largest magnitude of row m), the epilogue divides each row by its own power of two
+    float sx = 1.f;
     if constexpr (!HALF) {
         const float m = thread_max_of_partials(a.x_amax, a.x_namax, tid, 256);
         sx = pow2_scale(block_max(m, biasS));
-        sw = pow2_scale(block_max(tid < WEIGHT_AMAX_SLOTS ? a.w_amax[tid] : 0.f, biasS));
+        if (tid < BM) iswS[tid] = m0 + tid < a.M ? 1.f / pow2_scale(a.w_amax[m0 + tid]) : 1.f;
         __syncthreads();
     }
     // gather-offset table of this workgroup's BP pixels (as in igemm2_kernel)
@@ -1082,7 +1084,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
     }
 
     // epilogue (as igemm2_kernel): scale back (powers of two: exact), bias + activation or raw partial sum of a K split
-    const float isx = 1.f / sx, isw = 1.f / sw;
+    const float isx = 1.f / sx;
     const int YhYw = a.Yh * a.Yw;
     bool bad = false;
     if constexpr (!HALF) {       // (before the ragged-tile `continue`s below: every lane of the wave takes part in the ballot)
@@ -1106,8 +1108,9 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (m < a.M) Yp[(size_t)m * YhYw] = (acc[i][j][r] * isx) * isw;
+                    const int ml = wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int m = m0 + ml;
+                    if (m < a.M) Yp[(size_t)m * YhYw] = (acc[i][j][r] * isx) * (HALF ? 1.f : iswS[ml]);
                 }
             continue;
         }
@@ -1117,7 +1120,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m0 + ml < a.M) st1(Yp + (size_t)(m0 + ml) * YhYw, act_apply((acc[i][j][r] * isx) * isw + biasS[ml], a.act, a.slope));
+                if (m0 + ml < a.M) st1(Yp + (size_t)(m0 + ml) * YhYw, act_apply((acc[i][j][r] * isx) * (HALF ? 1.f : iswS[ml]) + biasS[ml], a.act, a.slope));
             }
     }
 }
@@ -2019,12 +2022,18 @@ __global__ void __launch_bounds__(256) smallm_wgrad_strip_kernel(WgradArgs a) {
 #pragma unroll
                 for (int k = 0; k < NW; ++k) xin[(sj + 1) & 1][k] = ldx<TA>(rX, rowoff[k] + co, 0u);
             }
+            // One v_fmac_f32 per term, written out: left to itself the compiler pairs the accumulators into v_pk_fma_f32 with operand
+            // selects (op_sel:[0,1,0]), and THAT form of this kernel returned different sums from run to run whenever an f16-MFMA kernel
+            // of another stream shared the CUs (encoder / residual-block kernels beside the head's weight gradient: the only
+            // run-to-run difference of a whole optimize_parameters(); alone, or beside fp32-MFMA / copy kernels, it was exact;
+            // scripts/diag_race.py reproduces it 30 / 30, built with -fno-slp-vectorize 0 / 30).  Same arithmetic, same order.
 #pragma unroll
             for (int ri = 0; ri < NT; ++ri)
 #pragma unroll
                 for (int j = 0; j < PX; ++j)
 #pragma unroll
-                    for (int m = 0; m < MO; ++m) acc[sj][ri][m] += dyv[m][j] * xin[sj & 1][j + ri];
+                    for (int m = 0; m < MO; ++m)
+                        asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[sj][ri][m]) : "v"(dyv[m][j]), "v"(xin[sj & 1][j + ri]));
         }
     }
     // workgroup reduction: 6 shuffle steps inside each wave, then the 4 waves through LDS
@@ -2934,16 +2943,13 @@ extern "C" int pcgan_conv2d_bwd_data_packed_hsplit(const pcgan_conv_desc* d, con
     return conv2d_bwd_data_impl(d, dy, nullptr, packed, bias, dx, ws, ws_bytes, s, &hs);
 }
 
-// in-place pre-split of a packed fp32 weight image for hgemm_kernel: every aligned group of 4 consecutive floats (what one thread
-// feeds to LDS per stage) becomes [4 fp16 high pieces][4 fp16 low pieces] of the values scaled by pow2_scale(max |w|)
-__global__ void __launch_bounds__(256) hgemm_presplit_kernel(float* __restrict__ A, size_t n4, const float* __restrict__ w_amax) {
-    __shared__ float scratch[16];
-    const float sw = pow2_scale(block_max(threadIdx.x < WEIGHT_AMAX_SLOTS ? w_amax[threadIdx.x] : 0.f, scratch));
-    __shared__ float sws;
-    if (threadIdx.x == 0) sws = sw;
-    __syncthreads();
-    const float s = sws;
+// in-place pre-split of one packed fp32 weight matrix A[M][Kp] for hgemm_kernel: every aligned group of 4 consecutive floats of row m
+// (what one thread feeds to LDS per stage) becomes [4 fp16 high pieces][4 fp16 low pieces] of the values scaled by
+// pow2_scale(rowmax[m]) -- one power of two per ROW, so a filter row far below the tensor's largest weight keeps its 22 bits
+__global__ void __launch_bounds__(256) hgemm_presplit_kernel(float* __restrict__ A, int M, int Kp4, const float* __restrict__ rowmax) {
+    const size_t n4 = (size_t)M * Kp4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float s = pow2_scale(rowmax[i / Kp4]);
         const float4 v = reinterpret_cast<const float4*>(A)[i];
         f16x4 h, l;
         _Float16 x, y;
@@ -2956,19 +2962,41 @@ __global__ void __launch_bounds__(256) hgemm_presplit_kernel(float* __restrict__
     }
 }
 
-extern "C" int pcgan_conv2d_hgemm_pack(const pcgan_conv_desc* d, int pass, const float* w, const float* w_amax, float* packed,
+extern "C" int pcgan_conv2d_hgemm_pack(const pcgan_conv_desc* d, int pass, const float* w, float* w_rowmax, float* packed,
                                        pcgan_stream_t s) {
     if (check_desc(d)) return 1;
     PCGAN_CHECK(pcgan_conv2d_hgemm_supported(d, pass), "conv2d_hgemm_pack: unsupported shape or pass");
-    PCGAN_CHECK(w && w_amax && packed, "conv2d_hgemm_pack: null pointer");
+    PCGAN_CHECK(w && w_rowmax && packed, "conv2d_hgemm_pack: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    const bool fwd = pass == PCGAN_PASS_FWD;
+    const int M = fwd ? d->K : d->C, RS = d->R * d->S;
+    if (launch_weight_row_absmax(w, d->K, d->C, RS, fwd ? 0 : 1, w_rowmax, st)) return 2;
     if (pcgan_conv2d_pack_weights(d, pass, w, packed, s)) return 1;
-    // the A matrices of all phases lie back to back at the start of the packed buffer: K * RS * round4(C) floats (forward),
-    // C * RS * round4(K) (data gradient: the stride phases partition the taps)
-    const size_t n = pass == PCGAN_PASS_FWD ? (size_t)d->K * d->R * d->S * round4(d->C) : (size_t)d->C * d->R * d->S * round4(d->K);
-    const size_t n4 = n / 4;
-    const unsigned blocks = (unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(hgemm_presplit_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, packed, n4, w_amax);
-    PCGAN_LAUNCH_CHECK();
+    // the A matrices of the phases lie back to back at the start of the packed buffer (conv2d_fwd_impl / conv2d_bwd_data_impl): one
+    // for the forward pass, one per (y mod stride, x mod stride) that owns taps for the data gradient
+    struct Ph { size_t off; int kp; } ph[16];
+    int nph = 0;
+    if (fwd) {
+        ph[nph++] = {0, RS * round4(d->C)};
+    } else {
+        const int stv = d->stride, Kgp = round4(d->K);
+        size_t off = 0;
+        for (int fy = 0; fy < stv; ++fy)
+            for (int fx = 0; fx < stv; ++fx) {
+                const int r0 = (fy + d->pad) % stv, s0 = (fx + d->pad) % stv;
+                const int nR = r0 < d->R ? (d->R - r0 + stv - 1) / stv : 0, nS = s0 < d->S ? (d->S - s0 + stv - 1) / stv : 0;
+                const int Hs = fy < d->H ? (d->H - fy + stv - 1) / stv : 0, Ws = fx < d->W ? (d->W - fx + stv - 1) / stv : 0;
+                if (Hs * Ws == 0 || nR * nS == 0) continue;
+                ph[nph++] = {off, nR * nS * Kgp};
+                off += (size_t)d->C * nR * nS * Kgp;
+            }
+    }
+    for (int i = 0; i < nph; ++i) {
+        const size_t n4 = (size_t)M * (ph[i].kp / 4);
+        const unsigned blocks = (unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+        hipLaunchKernelGGL(hgemm_presplit_kernel, dim3(blocks), dim3(256), 0, st, packed + ph[i].off, M, ph[i].kp / 4, (const float*)w_rowmax);
+        PCGAN_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -166,7 +166,7 @@ class branch(object):
 
     def __init__(self, name, enabled=True):
         self.name = name
-        self.on = enabled and BRANCH_STREAMS and torch.cuda.is_available()
+        self.on = enabled and BRANCH_STREAMS and torch.cuda.is_available() and name not in os.environ.get('PCGAN_BRANCH_OFF', '').split(',')
 
     def __enter__(self):
         if self.on:
@@ -279,38 +279,16 @@ def amax_of(x):
     return out
 
 
-WEIGHT_AMAX_SLOTS = 64     # csrc/common.h
-
-
-def _weight_amax(lib, w, cache):
-    """[64] partial maxima of |w| on the device, kept with the packed weights (same validity stamp)"""
-    stamp = _weight_stamp(w)
-    ent = cache.get('wamax')
-    if ent is not None and ent[0] == stamp:
-        if ent[3] != _raw_stream():
-            torch.cuda.current_stream().wait_event(ent[2])
-        return ent[1]
-    cur = torch.cuda.current_stream()
-    if ent is not None and ent[3] != cur.cuda_stream:
-        for st in list(_side.values()) + list(_branch.values()):
-            cur.wait_stream(st)
-    out = ent[1] if ent is not None else torch.empty(WEIGHT_AMAX_SLOTS, dtype=torch.float32, device=w.device)
-    _L.check(lib.pcgan_absmax(_p(w), w.numel(), F32, _p(out), WEIGHT_AMAX_SLOTS, _stream()), 'absmax')
-    ev = torch.cuda.Event()
-    ev.record(cur)
-    cache['wamax'] = (stamp, out, ev, cur.cuda_stream)
-    return out
-
-
-def _packed_weights(lib, d, pass_, w, cache, wmax=None):
-    """wmax: the weights' partial maxima (_weight_amax), needed by the pre-split packs of the hgemm route"""
+def _packed_weights(lib, d, pass_, w, cache, want_rowmax=False):
+    """the packed copy of w for one pass; want_rowmax (hgemm route): (packed, rowmax) -- the pre-split pack also writes the largest
+    magnitude of every weight row, which the convolution's epilogue needs"""
     key = (pass_, d.stride, d.pad, d.pad_mode, d.dtype)
     stamp = _weight_stamp(w)
     ent = cache.get(key)
     if ent is not None and ent[0] == stamp:
         if ent[3] != _raw_stream():      # packed on another stream (branch streams): order this use after the pack
             torch.cuda.current_stream().wait_event(ent[2])
-        return ent[1]
+        return (ent[1], ent[4]) if want_rowmax else ent[1]
     cur = torch.cuda.current_stream()
     if pass_ in (PASS_FWD_HSPLIT, PASS_BWD_HSPLIT):
         nb = int(lib.pcgan_conv2d_hsplit_packed_bytes(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HSPLIT else _L.PASS_BWD_DATA))
@@ -330,6 +308,11 @@ def _packed_weights(lib, d, pass_, w, cache, wmax=None):
                 cur.wait_stream(st)
     else:
         buf = _ws(nb, w.device)
+    rowmax = None
+    if pass_ in (PASS_FWD_HGEMM, PASS_BWD_HGEMM):
+        rows = d.K if pass_ == PASS_FWD_HGEMM else d.C
+        rowmax = ent[4] if (ent is not None and len(ent) > 4 and ent[4] is not None and ent[4].numel() == rows and buf is ent[1]) else \
+            torch.empty(rows, dtype=torch.float32, device=w.device)
     if pass_ in (PASS_FWD_HSPLIT, PASS_BWD_HSPLIT):
         _L.check(lib.pcgan_conv2d_hsplit_pack(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HSPLIT else _L.PASS_BWD_DATA, _p(w), _p(buf),
                                               _stream()), 'conv2d_hsplit_pack')
@@ -338,14 +321,14 @@ def _packed_weights(lib, d, pass_, w, cache, wmax=None):
     elif pass_ == PASS_BWD_BSPLIT:
         _L.check(lib.pcgan_conv2d_bsplit_dgrad_pack(ctypes.byref(d), _p(w), _p(buf), _stream()), 'conv2d_bsplit_dgrad_pack')
     elif pass_ in (PASS_FWD_HGEMM, PASS_BWD_HGEMM):
-        _L.check(lib.pcgan_conv2d_hgemm_pack(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HGEMM else _L.PASS_BWD_DATA, _p(w), _p(wmax),
+        _L.check(lib.pcgan_conv2d_hgemm_pack(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HGEMM else _L.PASS_BWD_DATA, _p(w), _p(rowmax),
                                              _p(buf), _stream()), 'conv2d_hgemm_pack')
     else:
         _L.check(lib.pcgan_conv2d_pack_weights(ctypes.byref(d), pass_, _p(w), _p(buf), _stream()), 'conv2d_pack_weights')
     ev = torch.cuda.Event()
     ev.record(cur)
-    cache[key] = (stamp, buf, ev, cur.cuda_stream)
-    return buf
+    cache[key] = (stamp, buf, ev, cur.cuda_stream, rowmax)
+    return (buf, rowmax) if want_rowmax else buf
 
 
 # Per-shape launch plans: descriptor, workspace size and route of a convolution call are functions of the shape and of the
@@ -463,8 +446,10 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
     y = torch.empty((N, K, pl.P, pl.Q), dtype=x.dtype, device=x.device)
     ws = _ws(pl.ws_bytes, x.device)
     if pack_cache is not None:
-        wmax = _weight_amax(lib, w, pack_cache) if pl.route == 'hgemm' else None      # (before the pack: it pre-splits with this scale)
-        pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache, wmax)
+        if pl.route == 'hgemm':
+            pk, wmax = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache, True)
+        else:
+            pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache)
         _count_route('fwd', pl.route)
         if pl.route == 'hgemm':
             xmax = amax_of(x)
@@ -499,8 +484,10 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
     dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device)
     ws = _ws(pl.ws_bytes, dy.device)
     if pack_cache is not None:
-        wmax = _weight_amax(lib, w, pack_cache) if pl.route == 'hgemm' else None
-        pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache, wmax)
+        if pl.route == 'hgemm':
+            pk, wmax = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache, True)
+        else:
+            pk = _packed_weights(lib, pl.d, pl.pack_pass, w, pack_cache)
         _count_route('dgrad', pl.route)
         if pl.route == 'hsplit':
             dmax = amax_of(dy)

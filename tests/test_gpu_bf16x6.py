@@ -386,3 +386,64 @@ def test_stale_operand_maximum_is_caught_loudly(dev, monkeypatch):
     assert ops.nonfinite_count() > 0
     ops.conv2d_bwd_weight(h2, dy, (256, 256, 3, 3), 1, 1, 1)
     assert ops.nonfinite_count() > 0
+
+
+@pytest.mark.parametrize('case', [
+    ('res fwd (window kernel)', 2, 256, 32, 256, 3, 1, 1, 1, False),
+    ('res dgrad (window kernel)', 2, 256, 32, 256, 3, 1, 1, 1, True),
+    ('G.down2 fwd (hgemm, stride 2)', 2, 128, 64, 256, 3, 2, 1, 0, False),
+    ('G.up1 = dgrad of a stride-2 conv (hgemm, 4 phases)', 2, 128, 64, 256, 3, 2, 1, 0, True),
+    ('D.c3 fwd (hgemm, 4x4)', 2, 256, 16, 512, 4, 1, 1, 0, False),
+], ids=lambda c: c[0])
+def test_per_channel_weight_scales(dev, monkeypatch, case):
+    """fp16-route robustness PER CHANNEL (round-2 verdict): the weights are scaled by ONE POWER OF TWO PER ROW of the pass's weight
+    matrix (per output channel in the forward pass, per input channel in the data gradient), not per tensor -- so an output channel
+    whose filter is 2^-20 of the tensor's largest weight is still computed with 22 significand bits (an affine-less InstanceNorm
+    behind it rescales that channel to O(1)).  Filters whose per-row magnitudes span 2^-20 .. 2^20; asserted: the relative L2 error
+    of EVERY output channel against float64 is at the fp32 MFMA kernel's own level (4 x its worst channel + 5e-7).  With one scale
+    per tensor the small channels came out at ~1e-5 .. 1e-3."""
+    from pcgan_amd.hip import ops
+    name, N, C, H, K, k, stride, pad, pm, dgrad = case
+    if name.startswith('res'):       # (the batch of 2 is below the host's routing threshold for the window kernel)
+        monkeypatch.setattr(ops, 'BSPLIT_MIN_PIXELS', 0)
+    g = torch.Generator().manual_seed(len(name))
+    w = torch.randn(K, C, k, k, generator=g)
+    rows = C if dgrad else K                       # the channels this pass produces
+    mag = torch.pow(2.0, torch.randint(-20, 21, (rows,), generator=g).float())
+    mag[0], mag[1] = 2.0 ** 20, 2.0 ** -20
+    w = w * (mag.view(1, C, 1, 1) if dgrad else mag.view(K, 1, 1, 1))
+    P = (H + 2 * pad - k) // stride + 1
+    if dgrad:
+        src = torch.randn(N, K, P, P, generator=g)
+        xz = torch.zeros(N, C, H, H, dtype=torch.float64, requires_grad=True)
+        R.conv2d(xz, w.double(), None, stride, pad, pm).backward(src.double())
+        ref = xz.grad
+    else:
+        src = torch.randn(N, C, H, H, generator=g).relu_()
+        ref = R.conv2d(src.double(), w.double(), None, stride, pad, pm)
+
+    def run():
+        sd, wd = src.to(dev), w.to(dev)
+        cache = {}
+        if dgrad:
+            out = ops.conv2d_bwd_data(sd, wd, (H, H), stride, pad, pm, pack_cache=cache)
+        else:
+            out = ops.conv2d_fwd(sd, wd, None, stride, pad, pm, pack_cache=cache)
+        return out.double().cpu()
+
+    def per_channel_err(out):
+        d = (out - ref).transpose(0, 1).reshape(rows, -1).norm(dim=1)
+        n = ref.transpose(0, 1).reshape(rows, -1).norm(dim=1)
+        return d / n
+
+    r0 = dict(ops.ROUTE_STATS)
+    e16 = per_channel_err(run())
+    key = ('dgrad' if dgrad else 'fwd', 'hsplit' if name.startswith('res') else 'hgemm')
+    assert ops.ROUTE_STATS.get(key, 0) == r0.get(key, 0) + 1, (key, ops.ROUTE_STATS)
+    monkeypatch.setattr(ops, 'HSPLIT', False)
+    monkeypatch.setattr(ops, 'BF16X6', False)      # the fp32 MFMA kernels (round 1's route) on the same data
+    e32 = per_channel_err(run())
+    worst16, worst32 = float(e16.max()), float(e32.max())
+    assert worst16 <= 4 * worst32 + 5e-7, '%s: worst channel %.3e (fp32 MFMA %.3e); channel magnitudes 2^%d: %.3e, 2^%d: %.3e' % (
+        name, worst16, worst32, 20, float(e16[0]), -20, float(e16[1]))
+    assert worst16 < 3e-6

@@ -1,0 +1,84 @@
+"""Kernels must return the same bits whether they run alone or beside other kernels.
+
+Round 3 found one that did not: the weight gradient of the generator's head convolution (64 -> 3, 7x7: smallm_wgrad_strip_kernel)
+returned slightly different sums (1e-4 relative, ~15 % of its elements) from run to run whenever an f16-MFMA kernel of ANOTHER stream --
+the Elo encoder's backward pass on its branch stream, a residual-block convolution -- shared the compute units; alone, or beside
+fp32-MFMA or copy kernels, it was exact.  The compiler had paired its accumulators into `v_pk_fma_f32 ... op_sel:[0,1,0]`; with one
+`v_fmac_f32` per term (same arithmetic, same order) the kernel is exact in every company (csrc/igemm_conv.hip, scripts/diag_race.py).
+It was the only run-to-run difference of a whole optimize_parameters() at the benchmark's size.  This test keeps every vector-ALU
+heavy kernel of the step honest the same way: alone == beside a stream of f16-MFMA convolutions, bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N = 32
+
+
+def _victims(dev, g):
+    from pcgan_amd.hip import ops
+    x64 = torch.randn(N, 64, 128, 128, generator=g).relu_().to(dev)
+    dy3 = torch.randn(N, 3, 128, 128, generator=g).to(dev)
+    w_head = (torch.randn(3, 64, 7, 7, generator=g) * 0.05).to(dev)
+    x3 = torch.randn(N, 3, 224, 224, generator=g).to(dev)
+    w_e1 = (torch.randn(64, 3, 7, 7, generator=g) * 0.05).to(dev)
+    dy_e1 = torch.randn(N, 64, 112, 112, generator=g).to(dev)
+    x4 = torch.randn(N, 4, 128, 128, generator=g).to(dev)
+    w_stem = (torch.randn(64, 4, 7, 7, generator=g) * 0.05).to(dev)
+    dy_stem = torch.randn(N, 64, 128, 128, generator=g).to(dev)
+    xr = torch.randn(N, 256, 32, 32, generator=g).to(dev)
+    dyr = torch.randn(N, 256, 32, 32, generator=g).to(dev)
+    d512 = torch.randn(N, 1, 14, 14, generator=g).to(dev)
+    x512 = torch.randn(N, 512, 15, 15, generator=g).to(dev)
+    w_d4 = (torch.randn(1, 512, 4, 4, generator=g) * 0.05).to(dev)
+    mean, m2 = ops.plane_stats(xr)
+    c1, c2, c3 = {}, {}, {}
+    return {
+        'head wgrad (smallm_wgrad_strip 7x7)': lambda: ops.conv2d_bwd_weight(x64, dy3, (3, 64, 7, 7), 1, 3, 1),
+        'head forward (smallm_strip)': lambda: ops.conv2d_fwd(x64, w_head, None, 1, 3, 1, pack_cache=c1),
+        'head dgrad (cg4 igemm2 + reflect fold)': lambda: ops.conv2d_bwd_data(dy3, w_head, (128, 128), 1, 3, 1, pack_cache=c1),
+        'E.conv1 dgrad (small-M, stride 2)': lambda: ops.conv2d_bwd_data(dy_e1, w_e1, (224, 224), 2, 3, 0, pack_cache=c2),
+        'E.conv1 wgrad (3-channel input)': lambda: ops.conv2d_bwd_weight(x3, dy_e1, (64, 3, 7, 7), 2, 3, 0),
+        'G.stem wgrad (4-channel input)': lambda: ops.conv2d_bwd_weight(x4, dy_stem, (64, 4, 7, 7), 1, 3, 1),
+        'D.c4 wgrad (512 -> 1, 4x4: smallm_wgrad)': lambda: ops.conv2d_bwd_weight(x512, d512, (1, 512, 4, 4), 1, 1, 0),
+        'D.c4 forward': lambda: ops.conv2d_fwd(x512, w_d4, None, 1, 1, 0, pack_cache=c3),
+        'instance norm forward (wave kernel)': lambda: ops.instnorm_fwd(xr, None, 1e-5, 1, 0.0)[0],
+        'instance norm backward (wave kernel)': lambda: ops.instnorm_bwd(dyr, xr, xr, mean, m2, 1e-5, 1, 0.0),
+        'channel sum': lambda: ops.channel_sum(dyr),
+        'bilinear backward': lambda: ops.bilinear_bwd(x3, (128, 128)),
+    }
+
+
+def test_kernels_are_bit_stable_beside_f16_mfma_kernels(dev):
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(4)
+    victims = _victims(dev, g)
+    # the company: residual-block convolutions (window kernel + its weight gradient) and encoder-like data gradients, on another stream
+    xr = torch.randn(N, 256, 32, 32, generator=g).to(dev)
+    wr = (torch.randn(256, 256, 3, 3, generator=g) * 0.05).to(dev)
+    we = (torch.randn(128, 128, 3, 3, generator=g) * 0.05).to(dev)
+    de = torch.randn(N, 128, 28, 28, generator=g).to(dev)
+    cr, ce = {}, {}
+
+    def company():
+        for _ in range(3):
+            ops.conv2d_fwd(xr, wr, None, 1, 1, 1, pack_cache=cr)
+            ops.conv2d_bwd_data(de, we, (28, 28), 1, 1, 0, pack_cache=ce)
+            ops.conv2d_bwd_weight(xr, xr, (256, 256, 3, 3), 1, 1, 1)
+    company()
+    torch.cuda.synchronize()
+    other = torch.cuda.Stream()
+    failures = []
+    for name, fn in victims.items():
+        ref = fn().clone()
+        torch.cuda.synchronize()
+        bad = 0
+        for _ in range(8):
+            other.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(other):
+                company()
+            out = fn()
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(out, ref))
+        if bad:
+            failures.append('%s: %d / 8 runs differ from the kernel running alone' % (name, bad))
+    assert not failures, failures
