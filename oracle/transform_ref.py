@@ -29,3 +29,52 @@ def transform(img, load_size, fine_size, x0, y0, flip, resize=True):
 def to_gray(t):
     """data/wsgan_emb_dataset.py:46-49"""
     return (t[0, ...] * 0.299 + t[1, ...] * 0.587 + t[2, ...] * 0.114).unsqueeze(0)
+
+
+def scale_width(img, target_width):
+    """reference data/base_dataset.py:87-104 (__scale_width), on Pillow itself"""
+    ow, oh = img.size
+    mult = 4
+    assert target_width % mult == 0, "the target width needs to be multiple of %d." % mult
+    if ow == target_width and oh % mult == 0:
+        return img
+    w = target_width
+    target_height = int(target_width * oh / ow)
+    m = (target_height - 1) // mult
+    h = (m + 1) * mult
+    return img.resize((w, h), Image.BICUBIC)
+
+
+def adjust(img):
+    """reference data/base_dataset.py:66-84 (__adjust): width and height up to multiples of 4"""
+    ow, oh = img.size
+    mult = 4
+    if ow % mult == 0 and oh % mult == 0:
+        return img
+    w = ((ow - 1) // mult + 1) * mult
+    h = ((oh - 1) // mult + 1) * mult
+    return img.resize((w, h), Image.BICUBIC)
+
+
+def transform_mode(img, mode, load_size, fine_size, x0=0, y0=0, flip=False):
+    """the non-affine `--transforms` modes of get_transform (reference data/base_dataset.py:24-40, 54-64) with the random draws as
+    arguments: PIL RGB image -> float32 (3, H, W) in [-1, 1]"""
+    crop = True
+    if mode == 'resize_and_crop':
+        img = img.resize((load_size, load_size), Image.BICUBIC)
+    elif mode == 'crop':
+        pass
+    elif mode == 'scale_width':
+        img, crop = scale_width(img, fine_size), False
+    elif mode == 'scale_width_and_crop':
+        img = scale_width(img, load_size)
+    elif mode == 'none':
+        img, crop = adjust(img), False
+    else:
+        raise ValueError(mode)
+    if crop:
+        img = img.crop((x0, y0, x0 + fine_size, y0 + fine_size))
+    if flip:
+        img = img.transpose(Image.FLIP_LEFT_RIGHT)
+    t = torch.from_numpy(np.array(img, np.uint8, copy=True)).permute(2, 0, 1).contiguous().to(dtype=torch.float32).div(255)
+    return t.sub_(torch.tensor([0.5, 0.5, 0.5]).view(3, 1, 1)).div_(torch.tensor([0.5, 0.5, 0.5]).view(3, 1, 1))

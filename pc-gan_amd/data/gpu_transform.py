@@ -70,9 +70,10 @@ def resample_table(in_size, out_size):
 
 
 def draw_augmentation(w, h, fine, flip_enabled):
-    """crop offsets and flip of ONE image, drawn from `random` in the order the PIL path draws them"""
-    x0 = random.randint(0, w - fine) if w > fine else 0
-    y0 = random.randint(0, h - fine) if h > fine else 0
+    """crop offsets and flip of ONE image, drawn from `random` in the order the PIL path draws them (fine = None: no crop,
+    nothing drawn for it)"""
+    x0 = random.randint(0, w - fine) if (fine is not None and w > fine) else 0
+    y0 = random.randint(0, h - fine) if (fine is not None and h > fine) else 0
     flip = 1 if (flip_enabled and random.random() < 0.5) else 0
     return x0, y0, flip
 
@@ -80,10 +81,11 @@ def draw_augmentation(w, h, fine, flip_enabled):
 class _Geometry(object):
     """device-resident tables of one (source size -> resized size -> crop size)"""
 
-    def __init__(self, H, W, RH, RW, fine, out_channels, device):
+    def __init__(self, H, W, RH, RW, FH, FW, out_channels, device):
         kh, bh, ksh = resample_table(W, RW)
         kv, bv, ksv = resample_table(H, RH)
-        self.desc = _L.ImageDesc(H, W, RH, RW, fine, fine, ksh, ksv, out_channels)
+        self.RH, self.RW, self.FH, self.FW = RH, RW, FH, FW
+        self.desc = _L.ImageDesc(H, W, RH, RW, FH, FW, ksh, ksv, out_channels)
         band, rows = ctypes.c_int(0), ctypes.c_int(0)
         bv = np.ascontiguousarray(bv)
         _L.check(_L.load().pcgan_image_transform_band(ctypes.byref(self.desc), bv.ctypes.data_as(ctypes.c_void_p),
@@ -96,9 +98,10 @@ class GpuTransform(object):
     """callable: list of uint8 (H, W, 3) tensors + per-image (x0, y0, flip) -> float (n, C, fine, fine) on `device`"""
 
     def __init__(self, opt, device):
-        if opt.transforms not in ('resize_and_crop', 'crop'):
-            raise NotImplementedError('pcgan_amd: --transforms %s is outside the hot path' % opt.transforms)
-        self.load = opt.loadSize if opt.transforms == 'resize_and_crop' else None
+        if opt.transforms not in ('resize_and_crop', 'crop', 'scale_width', 'scale_width_and_crop', 'none'):
+            raise NotImplementedError('pcgan_amd: the GPU image pipeline does not cover --transforms %s (the affine modes run on the '
+                                      'loader\'s PIL path: drop --gpu_transform)' % opt.transforms)
+        self.opt = opt
         self.fine = opt.fineSize
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -106,16 +109,17 @@ class GpuTransform(object):
         self._geo = {}
         self._stage = {}        # (H, W) -> reusable host buffer uint8 (cap, H, W, 3)
 
-    def resized(self, h, w):
-        return (self.load, self.load) if self.load else (h, w)
-
     def geometry(self, H, W, out_channels):
+        """resized size and output size of an H x W source under the loader's --transforms mode (base_dataset.resize_plan)"""
         key = (H, W, out_channels)
         if key not in self._geo:
-            RH, RW = self.resized(H, W)
-            if RH < self.fine or RW < self.fine:
+            from .base_dataset import resize_plan
+            resized, fs, _ = resize_plan(self.opt, W, H)
+            RW, RH = resized if resized is not None else (W, H)
+            FH, FW = (fs, fs) if fs is not None else (RH, RW)
+            if RH < FH or RW < FW:
                 raise ValueError('image %dx%d (resized %dx%d) is smaller than --fineSize %d' % (H, W, RH, RW, self.fine))
-            self._geo[key] = _Geometry(H, W, RH, RW, self.fine, out_channels, self.device)
+            self._geo[key] = _Geometry(H, W, RH, RW, FH, FW, out_channels, self.device)
         return self._geo[key]
 
     def _upload(self, images, H, W):
@@ -133,22 +137,28 @@ class GpuTransform(object):
     def __call__(self, images, aug, out_channels=3):
         n = len(images)
         aug = torch.as_tensor(aug, dtype=torch.int32).reshape(n, 3)
-        out = torch.empty((n, out_channels, self.fine, self.fine), dtype=torch.float32, device=self.device)
         groups = {}
         for i, im in enumerate(images):
             if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
                 raise ValueError('GpuTransform: image %d is not a uint8 (H, W, 3) tensor' % i)
             groups.setdefault((int(im.shape[0]), int(im.shape[1])), []).append(i)
+        # one output size per batch: the crop size, or (scale_width / none: no crop) the common size of the resized images
+        sizes = {(g.FH, g.FW) for g in (self.geometry(H, W, out_channels) for (H, W) in groups)}
+        if len(sizes) != 1:
+            raise ValueError('GpuTransform: --transforms %s leaves images of different sizes %s in one batch (the reference\'s '
+                             'DataLoader cannot stack them either)' % (self.opt.transforms, sorted(sizes)))
+        FH, FW = next(iter(sizes))
+        out = torch.empty((n, out_channels, FH, FW), dtype=torch.float32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         for (H, W), idx in groups.items():
             g = self.geometry(H, W, out_channels)
-            RH, RW = self.resized(H, W)
+            RH, RW = g.RH, g.RW
             a = torch.empty((len(idx), 4), dtype=torch.int32)
             a[:, :3] = aug[idx]
             a[:, 3] = torch.as_tensor(idx, dtype=torch.int32)
             # the kernel trusts the offsets: check them where they are still host data
-            if int(a[:, 0].min()) < 0 or int(a[:, 0].max()) > RW - self.fine or int(a[:, 1].min()) < 0 \
-                    or int(a[:, 1].max()) > RH - self.fine:
+            if int(a[:, 0].min()) < 0 or int(a[:, 0].max()) > RW - FW or int(a[:, 1].min()) < 0 \
+                    or int(a[:, 1].max()) > RH - FH:
                 raise ValueError('GpuTransform: crop offset outside the resized image')
             src = self._upload([images[i] for i in idx], H, W)
             a_dev = a.to(self.device, non_blocking=True)

@@ -73,6 +73,7 @@ def build_parser():
     add('--bnn_dropout', type=float, default=0.)
     add('--M', type=int, default=1, help='number of reparameterization samples')
     add('--T_train', type=int, default=1, help='MC-dropout passes per iteration (--bayesian)')
+    add('--T', type=int, default=10, help='number of Bayesian samples (--mode embedding)')
     add('--lr_sigma', type=float, default=0.0000002, help='learning rate of the log-variance head (--noisy)')
     add('--noisy_sigma_updating_epochs', nargs='*', type=int, default=[0, 1], help='starts ends (-1: --num_epochs)')
     add('--rsample', type=str2bool, default=True)
@@ -271,8 +272,152 @@ def train(opt):
     return history
 
 
+class SingleImageDataset(torch.utils.data.Dataset):
+    """lines "<image> [<attribute>]" of --datafile under --dataroot, or the directory listing (reference siamese.py:182-199);
+    yields (image, line).  `--dataroot synthetic`: seeded images named "<brightness>_<i>.png" (the hidden rating as the label)."""
+
+    def __init__(self, opt, root, listing):
+        self.opt, self.root = opt, root
+        self.synthetic = root == 'synthetic'
+        if self.synthetic:
+            self.lines = ['%.4f_%d.png' % (0.1 + 0.8 * ((i * 37) % 100) / 100.0, i) for i in range(min(opt.max_dataset_size, 64))]
+        elif listing:
+            with open(listing) as f:
+                self.lines = [line.strip('\n') for line in f.readlines() if line.strip()][:opt.max_dataset_size]
+        else:
+            self.lines = sorted(os.listdir(root))[:opt.max_dataset_size]
+        if not self.synthetic:
+            self.transform = get_transform(opt)
+
+    def __len__(self):
+        return len(self.lines)
+
+    def __getitem__(self, i):
+        if self.synthetic:
+            level = float(self.lines[i].split('_')[0])
+            g = torch.Generator().manual_seed(7000 + i)
+            s = self.opt.fineSize
+            return torch.rand(3, s, s, generator=g) * 0.5 + level - 0.75, self.lines[i]
+        from PIL import Image
+        return self.transform(Image.open(os.path.join(self.root, self.lines[i].split()[0])).convert('RGB')), self.lines[i]
+
+
+def get_attr_value(fname):
+    """reference siamese.py:299-303: the second token of a listing line, else the file name up to its first underscore"""
+    return float(fname.split()[1]) if len(fname.split()) > 1 else float(fname.split('_')[0])
+
+
+def _device(opt):
+    gpu = int(opt.gpu_ids.split(',')[0])
+    if gpu < 0 or not torch.cuda.is_available():
+        raise RuntimeError('pcgan_amd: siamese.py needs an MI355X (no CPU fallback)')
+    device = torch.device('cuda', gpu)
+    torch.cuda.set_device(device)
+    return device
+
+
+def build_feature_net(opt, device, state_dict=None):
+    """the single-image rating net of `--mode embedding` (reference get_model, siamese.py:450-476): SiameseFeature loaded from
+    <checkpoint_dir>/<name>/<which_epoch>_net.pth with strict=False (the trainer's comparison head `cxn` / `fc` is not part of it),
+    parameters frozen.  Like the reference it is NOT switched to eval(): BatchNorm normalises with the statistics of the (single)
+    image and Dropout2d stays active for the MC passes."""
+    if 'resnet' not in opt.which_model:
+        raise NotImplementedError('pcgan_amd: rating trunk [%s] is outside the MI355X hot path' % opt.which_model)
+    base = networks.ResNetFeature(input_nc=3, which_model=opt.which_model, dropout=opt.bnn_dropout)
+    net = networks.SiameseFeature(base, pooling=opt.pooling, cnn_dim=[] if opt.no_cnn else opt.cnn_dim, cnn_pad=opt.cnn_pad,
+                                  cnn_relu_slope=opt.cnn_relu_slope, noisy=opt.noisy,
+                                  drop_layer=networks.get_dropout_layer(dropout=opt.bnn_dropout))
+    if state_dict is None:
+        state_dict = torch.load(os.path.join(opt.checkpoint_dir, opt.name, '%s_net.pth' % opt.which_epoch), map_location='cpu')
+    net.load_state_dict(state_dict, strict=False)
+    for p in net.parameters():
+        p.requires_grad = False
+    return net.to(device)
+
+
+def embedding(opt, net=None, which_epoch=None):
+    """`--mode embedding` (reference siamese.py:791-852): the rating of every image of --datafile, one image per forward pass, written
+    as features_<epoch>.npy / labels_<epoch>.npy (+ stds_ with --noisy: exp(logvar / 2); + vars_ with --bayesian: the variance over
+    --T MC-dropout passes, the feature being their mean) under <checkpoint_dir>/<name>/ -- the ratings from which the GAN's
+    --embedding_mean / --embedding_std / --embedding_bins are derived.  Returns (features, labels)."""
+    device = _device(opt)
+    opt.isTrain = False if opt.no_flip else True      # (get_transform flips only in train mode; the reference passes its own opt)
+    if net is None:
+        net = build_feature_net(opt, device)
+    which_epoch = which_epoch or opt.which_epoch
+    data = SingleImageDataset(opt, opt.dataroot, opt.datafile)
+    loader = torch.utils.data.DataLoader(data, shuffle=False, num_workers=0, batch_size=1)
+    features, labels, stds, variances = [], [], [], []
+    fd = net.feature_dim
+    with torch.no_grad():
+        for img0, path0 in loader:
+            img0 = img0.to(device)
+            if opt.bayesian:
+                feats, std2 = [], 0.0
+                for _ in range(opt.T):
+                    out = net(img0)
+                    f, logvar = out if opt.noisy else (out, None)
+                    feats.append(f.detach().cpu().numpy().reshape(1, fd))
+                    if logvar is not None:
+                        s_ = torch.exp(0.5 * logvar).detach().cpu().numpy()
+                        std2 = std2 + 1.0 / opt.T * s_ * s_
+                feats = np.concatenate(feats, axis=0)
+                feature = np.mean(feats, axis=0)
+                variances.append(np.var(feats, axis=0).reshape(1, fd))
+                if opt.noisy:
+                    stds.append(np.sqrt(std2).reshape(1, fd))
+            elif opt.noisy:
+                f, logvar = net(img0)
+                feature = f.detach().cpu().numpy()
+                stds.append(torch.exp(0.5 * logvar).detach().cpu().numpy().reshape(1, fd))
+            else:
+                feature = net(img0).detach().cpu().numpy()
+            features.append(np.asarray(feature).reshape(1, fd))
+            labels.append(get_attr_value(path0[0]))
+    X, L = np.concatenate(features, axis=0), np.array(labels)
+    out_dir = os.path.join(opt.checkpoint_dir, opt.name)
+    os.makedirs(out_dir, exist_ok=True)
+    np.save(os.path.join(out_dir, 'features_%s.npy' % which_epoch), X)
+    np.save(os.path.join(out_dir, 'labels_%s.npy' % which_epoch), L)
+    if opt.noisy:
+        np.save(os.path.join(out_dir, 'stds_%s.npy' % which_epoch), np.concatenate(stds, axis=0))
+    if opt.bayesian:
+        np.save(os.path.join(out_dir, 'vars_%s.npy' % which_epoch), np.concatenate(variances, axis=0))
+    return X, L
+
+
+def test(opt):
+    """`--mode test` (reference siamese.py:771-789): accuracy of the pair predictions (0: first < second, 1: draw, 2: first > second)
+    over --datafile.  The reference builds a SiameseFeature for this mode and then calls it on pairs (get_model, :450), which cannot
+    run; what its `test` evidently means -- the trained SiameseNetwork's P(first > second) against the labels with the draw band
+    --draw_prob_thresh -- is what runs here.  Returns the accuracy in percent."""
+    device = _device(opt)
+    opt.continue_train = True                  # build_net then loads <which_epoch>_net.pth
+    net = build_net(opt, device)
+    data = PairDataset(opt, opt.dataroot, opt.datafile)
+    loader = torch.utils.data.DataLoader(data, shuffle=False, batch_size=opt.batch_size, num_workers=0 if data.synthetic else opt.num_workers)
+    wrong = seen = 0
+    with torch.no_grad():
+        for i, (img0, img1, label) in enumerate(loader):
+            out = net(img0.to(device), img1.to(device))
+            prob = torch.sigmoid(out[0] - out[1])          # P(first > second) from the two ratings (every head variant returns them first)
+            wrong += int((predictions(prob, opt.draw_prob_thresh).cpu() != label.reshape(-1)).sum())
+            seen += int(label.numel())
+            print('--> batch #%d' % (i + 1))
+    acc = 100.0 * (1.0 - wrong / max(seen, 1))
+    print('================================================================================')
+    print('accuracy: %.6f' % acc)
+    return acc
+
+
 if __name__ == '__main__':
     options = build_parser().parse_args()
-    if options.mode != 'train':
-        raise NotImplementedError('pcgan_amd: siamese.py --mode %s is outside the MI355X hot path (train only)' % options.mode)
-    train(options)
+    if options.mode == 'train':
+        train(options)
+    elif options.mode == 'embedding':
+        embedding(options)
+    elif options.mode == 'test':
+        test(options)
+    else:
+        raise NotImplementedError('pcgan_amd: siamese.py --mode %s is outside the MI355X hot path (train | embedding | test; the '
+                                  'optimize / attention modes need visdom / Grad-CAM tooling)' % options.mode)

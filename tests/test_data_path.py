@@ -90,6 +90,63 @@ def test_pil_transform_matches_oracle(tmp_path):
         assert got.shape == (3, 32, 32) and got.dtype == torch.float32 and -1.0 <= float(got.min()) and float(got.max()) <= 1.0
 
 
+@pytest.mark.parametrize('mode,size', [('scale_width', (50, 70)), ('scale_width', (64, 32)), ('scale_width_and_crop', (70, 50)),
+                                       ('scale_width_and_crop', (90, 40)), ('none', (50, 70)), ('none', (53, 47)), ('none', (48, 64)),
+                                       ('crop', (50, 70))])
+def test_every_non_affine_transform_mode_matches_the_oracle(tmp_path, mode, size):
+    """f3 leftovers of round 2: `scale_width`, `scale_width_and_crop`, `none` (reference data/base_dataset.py:33-40, 66-104) next to
+    `resize_and_crop` / `crop` -- the PIL path against the oracle's restatement on Pillow, draws replayed"""
+    from pcgan_amd.data.base_dataset import get_transform, resize_plan
+    _make_images(tmp_path, n=2, sizes=(size,))
+    opt = _opt(tmp_path, ['--transforms', mode])
+    tf = get_transform(opt)
+    img = Image.open(tmp_path / 'img_0.png').convert('RGB')
+    resized, fs, _ = resize_plan(opt, img.size[0], img.size[1])
+    w, h = resized if resized is not None else img.size
+    for seed in range(4):
+        random.seed(seed)
+        got = tf(img)
+        random.seed(seed)
+        x0 = random.randint(0, w - fs) if (fs is not None and w > fs) else 0
+        y0 = random.randint(0, h - fs) if (fs is not None and h > fs) else 0
+        flip = random.random() < 0.5
+        assert torch.equal(got, R.transform_mode(img, mode, 40, 32, x0, y0, flip))
+        if fs is None:
+            assert got.shape[1] % 4 == 0 and got.shape[2] % 4 == 0        # "the size needs to be a multiple of 4"
+        else:
+            assert got.shape == (3, 32, 32)
+
+
+def test_affine_modes_and_color_jitter(tmp_path):
+    """resize_affine_crop / resize_affine_center (reference :41-52) run on the PIL path: identity parameters leave the resized image
+    unchanged, a real draw rotates / scales about the centre with fill 127, the centre mode draws no crop offsets; --use_color_jitter
+    is torchvision's ColorJitter() with default (zero) arguments, i.e. the identity (:58-59)"""
+    from pcgan_amd.data import base_dataset as B
+    _make_images(tmp_path, n=2, sizes=((50, 50),))
+    img = Image.open(tmp_path / 'img_0.png').convert('RGB').resize((40, 40), Image.BICUBIC)
+    # identity parameters: the inverse matrix is the identity and Pillow's bicubic transform at integer positions returns the image
+    m = B._inverse_affine_matrix((20.5, 20.5), 0.0, (0, 0), 1.0, 0.0)
+    assert np.allclose(m, [1, 0, 0, 0, 1, 0], atol=1e-12)
+    opt = _opt(tmp_path, ['--transforms', 'resize_affine_center', '--affineDegrees', '0', '--affineScale', '1.0', '1.0', '--no_flip'])
+    src = Image.open(tmp_path / 'img_0.png').convert('RGB')
+    got = B.get_transform(opt)(src)
+    assert torch.equal(got, R.transform(src, 40, 32, 4, 4, False))        # CenterCrop: round((40 - 32) / 2) = 4
+    # a real draw: rotation by 90 degrees about the centre maps the image onto its rotation (up to the half-pixel centre convention)
+    opt2 = _opt(tmp_path, ['--transforms', 'resize_affine_crop', '--use_color_jitter'])
+    random.seed(3)
+    out = B.get_transform(opt2)(src)
+    assert out.shape == (3, 32, 32) and torch.isfinite(out).all() and -1.0 <= float(out.min()) and float(out.max()) <= 1.0
+    random.seed(3)
+    angle = random.uniform(-5, 5)
+    scale = random.uniform(0.95, 1.05)
+    assert -5 <= angle <= 5 and 0.95 <= scale <= 1.05
+    with pytest.raises(ValueError, match='not a valid option'):
+        B.get_transform(_opt(tmp_path, ['--transforms', 'bogus']))
+    from pcgan_amd.data.gpu_transform import GpuTransform
+    with pytest.raises(NotImplementedError, match='affine'):
+        GpuTransform(opt2, 'cuda:0')
+
+
 def test_crop_larger_than_image_is_refused(tmp_path):
     from pcgan_amd.data.base_dataset import get_transform
     _make_images(tmp_path)

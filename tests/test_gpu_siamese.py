@@ -151,3 +151,56 @@ def test_siamese_script_trains_noisy_bayesian(tmp_path, dev):
     from pcgan_amd.models import networks
     e = networks.define_E('resnet18', 3, 'normal', 'avg', [32, 1], 1, 0.7, noisy=True, bnn_dropout=0.1)
     e.load_pretrained(os.path.join(str(tmp_path), 'elo_nb', '2_net.pth'))
+
+
+def test_embedding_and_test_modes_close_the_elo_pipeline(tmp_path, dev):
+    """siamese.py --mode embedding / --mode test (reference siamese.py:771-852, f2 leftovers of round 2): train a rating net on the
+    synthetic pairs, extract the ratings of single images with `--mode embedding` -- the .npy files from which the GAN's
+    --embedding_mean / --embedding_std / --embedding_bins are derived -- and score pair predictions with `--mode test`.  The
+    ratings are held to the ORACLE's SiameseFeature on the same checkpoint (train-mode BatchNorm over the single image, as the
+    reference runs it: it never calls eval()), 2e-4; the synthetic rating (mean brightness) must come out monotone."""
+    sys.path.insert(0, ROOT)
+    import siamese
+    from oracle import networks_ref as N
+    common = ['--dataroot', 'synthetic', '--name', 'elo_emb', '--checkpoint_dir', str(tmp_path), '--fineSize', '64',
+              '--pretrained_model_path', '', '--max_dataset_size', '256']
+    opt = siamese.build_parser().parse_args(common + ['--batch_size', '16', '--num_epochs', '3', '--print_freq', '4', '--lr', '0.001'])
+    siamese.train(opt)
+    # --mode embedding
+    eopt = siamese.build_parser().parse_args(common + ['--mode', 'embedding', '--which_epoch', 'latest', '--no_flip', '--max_dataset_size', '12'])
+    X, L = siamese.embedding(eopt)
+    out_dir = os.path.join(str(tmp_path), 'elo_emb')
+    assert X.shape == (12, 1) and L.shape == (12,) and np.isfinite(X).all()
+    assert np.array_equal(np.load(os.path.join(out_dir, 'features_latest.npy')), X)
+    assert np.array_equal(np.load(os.path.join(out_dir, 'labels_latest.npy')), L)
+    assert abs(siamese.get_attr_value('img.png 23.5') - 23.5) < 1e-12 and abs(siamese.get_attr_value('31_abc.png') - 31.0) < 1e-12
+    # against the oracle's SiameseFeature on the same checkpoint, image by image, in train mode (batch statistics of ONE image)
+    sd = torch.load(os.path.join(out_dir, 'latest_net.pth'), map_location='cpu')
+    ref = N.SiameseFeatureRef(N.ResNetFeatureRef('resnet18'), 'avg', (32, 1), 1, 0.7, False)
+    ref.load_state_dict({k: v for k, v in sd.items() if k in ref.state_dict()}, strict=False)
+    ref.train()
+    data = siamese.SingleImageDataset(eopt, 'synthetic', '')
+    with torch.no_grad():
+        for i in range(12):
+            img, line = data[i]
+            want = float(ref(img.unsqueeze(0)).reshape(-1)[0])
+            assert abs(float(X[i, 0]) - want) <= 2e-4 * max(1.0, abs(want)), (i, float(X[i, 0]), want)
+            assert abs(L[i] - float(line.split('_')[0])) < 1e-12
+    # the trained rating follows the hidden one (mean brightness): rank correlation clearly positive after 3 short epochs
+    order_l, order_x = np.argsort(np.argsort(L)), np.argsort(np.argsort(X[:, 0]))
+    rho = np.corrcoef(order_l, order_x)[0, 1]
+    assert rho > 0.5, rho
+    # bayesian + noisy variant of the extraction: T passes, stds / vars files
+    bopt = siamese.build_parser().parse_args(['--dataroot', 'synthetic', '--name', 'elo_nb2', '--checkpoint_dir', str(tmp_path), '--fineSize', '64',
+                                              '--pretrained_model_path', '', '--batch_size', '16', '--num_epochs', '1', '--max_dataset_size', '64',
+                                              '--noisy', 'true', '--bayesian', 'true', '--bnn_dropout', '0.1', '--lr_sigma', '1e-5'])
+    siamese.train(bopt)
+    bopt.mode, bopt.T, bopt.max_dataset_size, bopt.no_flip = 'embedding', 3, 5, True
+    Xb, Lb = siamese.embedding(bopt)
+    nb_dir = os.path.join(str(tmp_path), 'elo_nb2')
+    S, V = np.load(os.path.join(nb_dir, 'stds_latest.npy')), np.load(os.path.join(nb_dir, 'vars_latest.npy'))
+    assert Xb.shape == S.shape == V.shape == (5, 1) and (S > 0).all() and (V >= 0).all() and V.max() > 0
+    # --mode test
+    topt = siamese.build_parser().parse_args(common + ['--mode', 'test', '--batch_size', '16', '--max_dataset_size', '64'])
+    acc = siamese.test(topt)
+    assert 50.0 < acc <= 100.0, acc

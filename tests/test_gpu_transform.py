@@ -59,6 +59,27 @@ def test_kernel_matches_pillow_path(dev, src, load, fine):
     assert torch.equal(_run(dev, imgs, load, fine, aug), _want(imgs, load, fine, aug))
 
 
+@pytest.mark.parametrize('mode,src,load,fine', [('scale_width', (70, 50), 40, 32), ('scale_width', (120, 200), 160, 128),
+                                                ('scale_width_and_crop', (70, 50), 40, 32), ('scale_width_and_crop', (200, 150), 160, 128),
+                                                ('none', (70, 50), 40, 32), ('none', (53, 47), 40, 32), ('none', (48, 64), 40, 32)])
+def test_scale_width_and_none_modes_match_pillow(dev, mode, src, load, fine):
+    """the loader modes round 2 left out (reference data/base_dataset.py:33-40, 66-104) through the same integer resampler: bit-exact
+    against the oracle on Pillow; `scale_width` / `none` have no crop (the output is the resized image, sides multiples of 4)"""
+    from pcgan_amd.data.base_dataset import resize_plan
+    o = _O(load, fine, mode)
+    resized, fs, _ = resize_plan(o, src[1], src[0])
+    w, h = resized if resized is not None else (src[1], src[0])
+    random.seed(load + fine + len(mode))
+    imgs = _images([src] * 4, seed=load + len(mode))
+    mx, my = (w - fs, h - fs) if fs is not None else (0, 0)
+    aug = [(0, 0, 0), (mx, my, 1), (random.randint(0, mx), random.randint(0, my), 0), (random.randint(0, mx), random.randint(0, my), 1)]
+    got = _run(dev, imgs, load, fine, aug, transforms=mode)
+    want = torch.stack([R.transform_mode(Image.fromarray(a), mode, load, fine, x0, y0, bool(fl)) for a, (x0, y0, fl) in zip(imgs, aug)])
+    assert got.shape == want.shape and torch.equal(got, want)
+    if fs is None:
+        assert got.shape[2] % 4 == 0 and got.shape[3] % 4 == 0
+
+
 def test_crop_only_and_gray(dev):
     imgs = _images([(40, 52)] * 4, seed=1)
     aug = [(0, 0, 0), (20, 8, 1), (5, 3, 0), (20, 8, 0)]
