@@ -100,3 +100,49 @@ def test_compute_fid_score_alexnet_features(dev, tmp_path):
         return float(re.search(r': ([-0-9.e]+)\s*$', p.stdout.strip()).group(1))
     same, diff = run(tmp_path / 'a', tmp_path / 'a'), run(tmp_path / 'a', tmp_path / 'b')
     assert abs(same) < 1e-3 * max(1.0, abs(diff)) and diff > 0
+
+
+def test_generate_images_feeds_the_frechet_script(dev, tmp_path):
+    """generate_images.py (the sampler eval_emb.py of the reference calls but does not ship, eval_emb.py:70-93): `--how_to_sample label`
+    over a single-image listing writes <label>_<index>_<stem>.png, one per source image, with the classes of --sample_label_file;
+    the images equal model.sample_from_label on the same input; compute_fid_score.py takes the output directory as it stands."""
+    import re
+    import torch
+    from PIL import Image
+    from pcgan_amd.models import networks
+    rng = np.random.default_rng(11)
+    os.makedirs(tmp_path / 'src')
+    for i in range(6):
+        Image.fromarray(rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)).save(tmp_path / 'src' / ('face_%d.png' % i))
+    with open(tmp_path / 'list.txt', 'w') as f:
+        f.writelines('face_%d.png\n' % i for i in range(6))
+    with open(tmp_path / 'labels.txt', 'w') as f:
+        f.writelines('%d\n' % l for l in (2, 0, 1))
+    torch.manual_seed(2)
+    E = networks.define_E('resnet18', 3, 'normal', 'avg', [32, 1], 1, 0.7)
+    IP = networks.define_IP('alexnet', 3)
+    G = networks.define_G(3, 3, 1, 8, 'resnet_2blocks', 'instance', 'relu', 0, 'normal')
+    os.makedirs(tmp_path / 'ck' / 'gen')
+    torch.save(E.state_dict(), tmp_path / 'ck' / 'gen' / 'latest_net_E.pth')
+    torch.save(G.state_dict(), tmp_path / 'ck' / 'gen' / 'latest_net_G.pth')
+    torch.save(IP.state_dict(), tmp_path / 'IP.pth')
+    torch.save(E.state_dict(), tmp_path / 'E.pth')
+    out = tmp_path / 'samples'
+    cmd = [sys.executable, os.path.join(ROOT, 'generate_images.py'), '--model', 'wsgan_emb', '--how_to_sample', 'label', '--sample_label_file',
+           str(tmp_path / 'labels.txt'), '--dataset_mode', 'single', '--sourcefile_A', str(tmp_path / 'list.txt'), '--dataroot', str(tmp_path / 'src'),
+           '--embedding_bins', '[-1.0, 0.0, 1.5]', '--embedding_mean', '0.1', '--embedding_std', '0.8', '--name', 'gen', '--checkpoints_dir',
+           str(tmp_path / 'ck'), '--which_epoch', 'latest', '--which_model_netG', 'resnet_2blocks', '--ngf', '8', '--loadSize', '32', '--fineSize', '32',
+           '--fineSize_E', '64', '--output_dir', str(out), '--how_many', '5', '--gpu_ids', '0', '--pretrained_model_path_E', str(tmp_path / 'E.pth')]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    names = sorted(os.listdir(out))
+    # classes cycle through the label file (2, 0, 1); --how_many 5 of the 6 sources
+    assert names == sorted(['2_00000_face_0.png', '0_00001_face_1.png', '1_00002_face_2.png', '2_00003_face_3.png', '0_00004_face_4.png']), names
+    img = np.asarray(Image.open(out / '2_00000_face_0.png'))
+    assert img.shape == (32, 32, 3) and img.std() > 0
+    # the directory goes straight into the Frechet script
+    cmd = [sys.executable, os.path.join(ROOT, 'compute_fid_score.py'), str(out), str(tmp_path / 'src'), '--features', 'alexnet', '--batch-size', '4',
+           '--pretrained_model_path_IP', str(tmp_path / 'IP.pth')]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert np.isfinite(float(re.search(r': ([-0-9.e]+)\s*$', p.stdout.strip()).group(1)))
