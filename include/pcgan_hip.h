@@ -155,6 +155,20 @@ int pcgan_norm_bwd_apply(const void* dy, const void* x, const void* y, const flo
                          int act, float slope, int dtype, pcgan_stream_t s);
 int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, float* s2_c, int N, int C,
                         pcgan_stream_t s);
+/* The two-launch pairs above as ONE launch each, for train-mode BatchNorm2d on tensors too large for the fused kernels below
+ * (the Elo encoder's 112^2 / 56^2 / 28^2 maps, the PatchGAN's 32^2 map at batch 32: models/resnet.py:47-71, models/networks.py:756-761).
+ * pcgan_bn_stats_merged = pcgan_plane_stats + pcgan_bn_merge (+ num_batches_tracked += 1 when `batches` != NULL);
+ * pcgan_bn_bwd_stats_reduced = pcgan_norm_bwd_stats(per_plane = 0) + pcgan_bn_bwd_reduce.  The workgroup whose plane completes a
+ * channel ("last arriver", counted on ticket[c]) finishes that channel with the stand-alone kernels' arithmetic in their order, so the
+ * results are the same bits.  ticket: C unsigned words owned by the caller, zeroed ONCE when the layer is created and never cleared
+ * (arrival k is the last of its call iff (k + 1) % N == 0); forward and backward use separate arrays; calls sharing an array must be
+ * ordered (one stream, or stream dependencies) -- a BatchNorm layer's passes are ordered anyway for its running statistics. */
+int pcgan_bn_stats_merged(const void* x, float* mean_nc, float* m2_nc, float* mean_c, float* var_c, float* running_mean,
+                          float* running_var, long long* batches, unsigned int* ticket, int N, int C, int HW, float momentum, int dtype,
+                          pcgan_stream_t s);
+int pcgan_bn_bwd_stats_reduced(const void* dy, const void* x, const void* y, const float* mean_c, const float* var_c, float* s1_nc,
+                               float* s2_nc, float* s1_c, float* s2_c, unsigned int* ticket, int N, int C, int HW, float eps, int act,
+                               float slope, int dtype, pcgan_stream_t s);
 /* BatchNorm2d in training mode for small tensors (used up to N * HW = 8192 per channel), ONE launch per pass: batch statistics,
  * running-statistics update (+ num_batches_tracked when `batches` != NULL), normalise + affine (+ residual) + activation
  * -- replaces nn.BatchNorm2d (+ the following ReLU / LeakyReLU) of the PatchGAN and of the Elo encoder's late stages

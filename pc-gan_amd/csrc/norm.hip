@@ -12,10 +12,65 @@
 
 namespace pcgan {
 
+// ---- "last arriver finishes the channel": the batch-norm reductions over the N planes of a channel without a second launch ----------
+// The per-plane kernels below (one workgroup per (n, c) plane) can be given a ticket word per channel.  Every workgroup publishes its
+// plane's partial result with WRITE-THROUGH stores (agent-scope relaxed atomic stores = `global_store ... sc1`), waits for them
+// (s_waitcnt vmcnt(0)) and makes one returning agent-scope atomicAdd on ticket[c]; the workgroup whose add completes the channel's N
+// arrivals reads the partials with sc1 loads (they bypass the non-coherent caches) and finishes the channel with the arithmetic of the
+// stand-alone merge kernels (same order: the result does not depend on which workgroup is last).  No fences: a release fence per
+// workgroup writes back the whole L2 of its XCD (MI355X_MICROARCH.md: 1.7 - 6.5 us each) -- the first version of this kernel with
+// __threadfence() made the step 2.7 ms SLOWER than the three-launch form it replaces.  Tickets only ever grow -- arrival k is the last of its call iff (k + 1) % N == 0 -- so
+// nothing is cleared between calls and a captured hipGraph replays correctly; the calls that share a ticket array run in stream order
+// (a BatchNorm net never runs two passes at once: its running statistics must stay ordered anyway).
+struct BnTicket {
+    unsigned* ticket;       // [C] arrival counters of this layer and pass direction, or null: no merge in this launch
+    int N, C;
+};
+// true in every thread of the workgroup that completed channel c (call after the plane's partials were stored by thread 0)
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// call with the plane's partials already stored by thread 0 through st_wt
+__device__ __forceinline__ bool bn_last_arriver(const BnTicket& t, int c, int* flag_lds) {
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through stores have left before the ticket moves
+        const unsigned old = __hip_atomic_fetch_add(&t.ticket[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag_lds = ((old + 1u) % (unsigned)t.N) == 0u;
+    }
+    __syncthreads();
+    return *flag_lds != 0;
+}
+// Chan merge of the N plane statistics of channel c by ONE wave (lane = threadIdx.x < 64): the arithmetic of bn_merge_kernel
+template <bool WT>      // WT: the partials were published by other workgroups of THIS launch (sc1 loads); else by an earlier launch
+__device__ __forceinline__ void bn_merge_channel(const float* mean_nc, const float* m2_nc, float* __restrict__ mean_c,
+                                                 float* __restrict__ var_c, float* running_mean, float* running_var, int N, int C, int HW,
+                                                 float momentum, int c, int lane) {
+    float msum = 0.f;
+    for (int n = lane; n < N; n += 64) msum += WT ? ld_wt(mean_nc + n * C + c) : mean_nc[n * C + c];
+    const float mean = wave_sum(msum) / (float)N;
+    float m2 = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        const float d = (WT ? ld_wt(mean_nc + n * C + c) : mean_nc[n * C + c]) - mean;
+        m2 += (WT ? ld_wt(m2_nc + n * C + c) : m2_nc[n * C + c]) + d * d * (float)HW;
+    }
+    m2 = wave_sum(m2);
+    if (lane != 0) return;
+    const float cnt = (float)N * (float)HW;
+    if (mean_c) mean_c[c] = mean;
+    if (var_c) var_c[c] = m2 / cnt;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (cnt - 1.f));
+}
+struct BnMergeOut {
+    float *mean_c, *var_c, *running_mean, *running_var;
+    long long* batches;
+    float momentum;
+};
+
 // one workgroup per plane; mean and M2 = sum (x - mean)^2 by an exact two-pass
 template <typename T>
 __global__ void __launch_bounds__(256) plane_stats_kernel(const T* __restrict__ x, float* __restrict__ mean_nc,
-                                                          float* __restrict__ m2_nc, int HW) {
+                                                          float* __restrict__ m2_nc, int HW, BnTicket tk = BnTicket{nullptr, 0, 0},
+                                                          BnMergeOut mo = BnMergeOut{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f}) {
     __shared__ float scratch[16];
     const size_t plane = blockIdx.x;
     const T* xp = x + plane * (size_t)HW;
@@ -44,8 +99,21 @@ __global__ void __launch_bounds__(256) plane_stats_kernel(const T* __restrict__ 
     }
     const float m2 = block_sum(q, scratch);
     if (threadIdx.x == 0) {
-        mean_nc[plane] = mean;
-        m2_nc[plane] = m2;
+        if (tk.ticket != nullptr) {
+            st_wt(mean_nc + plane, mean);
+            st_wt(m2_nc + plane, m2);
+        } else {
+            mean_nc[plane] = mean;
+            m2_nc[plane] = m2;
+        }
+    }
+    if (tk.ticket != nullptr) {      // batch norm: the workgroup that completes its channel merges the N plane statistics (bn_merge_kernel)
+        __shared__ int last_flag;
+        const int c = (int)(plane % (size_t)tk.C);
+        if (bn_last_arriver(tk, c, &last_flag) && threadIdx.x < 64) {
+            bn_merge_channel<true>(mean_nc, m2_nc, mo.mean_c, mo.var_c, mo.running_mean, mo.running_var, tk.N, tk.C, HW, mo.momentum, c, threadIdx.x);
+            if (c == 0 && threadIdx.x == 0 && mo.batches) mo.batches[0] += 1;       // num_batches_tracked: once per call
+        }
     }
 }
 
@@ -56,22 +124,7 @@ __global__ void bn_merge_kernel(const float* __restrict__ mean_nc, const float* 
                                 float* running_var, int N, int C, int HW, float momentum) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
-    const int lane = threadIdx.x & 63;
-    float msum = 0.f;
-    for (int n = lane; n < N; n += 64) msum += mean_nc[n * C + c];
-    const float mean = wave_sum(msum) / (float)N;
-    float m2 = 0.f;
-    for (int n = lane; n < N; n += 64) {
-        const float d = mean_nc[n * C + c] - mean;
-        m2 += m2_nc[n * C + c] + d * d * (float)HW;
-    }
-    m2 = wave_sum(m2);
-    if (lane != 0) return;
-    const float cnt = (float)N * (float)HW;
-    if (mean_c) mean_c[c] = mean;
-    if (var_c) var_c[c] = m2 / cnt;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (cnt - 1.f));
+    bn_merge_channel<false>(mean_nc, m2_nc, mean_c, var_c, running_mean, running_var, N, C, HW, momentum, c, threadIdx.x & 63);
 }
 
 __global__ void in_running_kernel(const float* __restrict__ mean_nc, const float* __restrict__ m2_nc,
@@ -165,7 +218,8 @@ __global__ void __launch_bounds__(256) norm_act_fwd_kernel(NormArgs a) {
 
 // s1[plane] = sum g, s2[plane] = sum g * xhat, g = dy * act'(y)
 template <typename T>
-__global__ void __launch_bounds__(256) norm_bwd_stats_kernel(NormArgs a) {
+__global__ void __launch_bounds__(256) norm_bwd_stats_kernel(NormArgs a, BnTicket tk = BnTicket{nullptr, 0, 0}, float* s1_c = nullptr,
+                                                             float* s2_c = nullptr) {
     __shared__ float scratch[16];
     const size_t plane = blockIdx.x;
     float mean, rstd, g_, b_;
@@ -183,8 +237,33 @@ __global__ void __launch_bounds__(256) norm_bwd_stats_kernel(NormArgs a) {
     s1 = block_sum(s1, scratch);
     s2 = block_sum(s2, scratch);
     if (threadIdx.x == 0) {
-        ((float*)a.out)[plane] = s1;
-        ((float*)a.out2)[plane] = s2;
+        if (tk.ticket != nullptr) {
+            st_wt((float*)a.out + plane, s1);
+            st_wt((float*)a.out2 + plane, s2);
+        } else {
+            ((float*)a.out)[plane] = s1;
+            ((float*)a.out2)[plane] = s2;
+        }
+    }
+    if (tk.ticket != nullptr) {      // batch norm: the last arriver sums the channel's N plane sums (bn_bwd_reduce_kernel)
+        __shared__ int last_flag;
+        const int c = (int)(plane % (size_t)tk.C);
+        if (bn_last_arriver(tk, c, &last_flag) && threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const float* s1_nc = (const float*)a.out;
+            const float* s2_nc = (const float*)a.out2;
+            float u = 0.f, v = 0.f;
+            for (int n = lane; n < tk.N; n += 64) {
+                u += ld_wt(s1_nc + n * tk.C + c);
+                v += ld_wt(s2_nc + n * tk.C + c);
+            }
+            u = wave_sum(u);
+            v = wave_sum(v);
+            if (lane == 0) {
+                s1_c[c] = u;
+                s2_c[c] = v;
+            }
+        }
     }
 }
 
@@ -657,6 +736,33 @@ extern "C" int pcgan_plane_stats(const void* x, float* mean_nc, float* m2_nc, in
     PCGAN_CHECK(x && mean_nc && m2_nc && NC > 0 && HW > 0, "plane_stats: bad arguments");
     PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(plane_stats_kernel<T>, dim3(NC), dim3(plane_threads(HW)), 0, (hipStream_t)s,
                                                     (const T*)x, mean_nc, m2_nc, HW));
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_bn_stats_merged(const void* x, float* mean_nc, float* m2_nc, float* mean_c, float* var_c, float* running_mean,
+                                     float* running_var, long long* batches, unsigned int* ticket, int N, int C, int HW, float momentum,
+                                     int dtype, pcgan_stream_t s) {
+    PCGAN_CHECK(x && mean_nc && m2_nc && mean_c && var_c && ticket && N > 0 && C > 0 && HW > 0 && (long long)N * HW > 1, "bn_stats_merged: bad arguments");
+    const BnTicket tk{ticket, N, C};
+    const BnMergeOut mo{mean_c, var_c, running_mean, running_var, batches, momentum};
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(plane_stats_kernel<T>, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s,
+                                                    (const T*)x, mean_nc, m2_nc, HW, tk, mo));
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_bn_bwd_stats_reduced(const void* dy, const void* x, const void* y, const float* mean_c, const float* var_c, float* s1_nc,
+                                          float* s2_nc, float* s1_c, float* s2_c, unsigned int* ticket, int N, int C, int HW, float eps, int act,
+                                          float slope, int dtype, pcgan_stream_t s) {
+    PCGAN_CHECK(dy && x && mean_c && var_c && s1_nc && s2_nc && s1_c && s2_c && ticket && N > 0 && C > 0 && HW > 0, "bn_bwd_stats_reduced: bad arguments");
+    PCGAN_CHECK(act == PCGAN_ACT_NONE || y, "bn_bwd_stats_reduced: activation mask needs y");
+    NormArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y; a.dy = dy; a.mean = mean_c; a.var = var_c; a.out = s1_nc; a.out2 = s2_nc;
+    a.N = N; a.C = C; a.HW = HW; a.per_plane = 0; a.eps = eps; a.act = act; a.slope = slope;
+    const BnTicket tk{ticket, N, C};
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(norm_bwd_stats_kernel<T>, dim3(N * C), dim3(plane_threads(HW)), 0, (hipStream_t)s, a, tk, s1_c, s2_c));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

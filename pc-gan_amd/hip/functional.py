@@ -251,7 +251,7 @@ def instance_norm_act(x, running_mean=None, running_var=None, momentum=0.1, eps=
 
 class _BatchNormActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope, training, batches):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope, training, batches, tickets=None):
         x, residual = _c(x), _c(residual)
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
@@ -259,7 +259,10 @@ class _BatchNormActFn(torch.autograd.Function):
         if fused:      # one launch: statistics + running update + batch counter + normalise / activation
             y, mean, var = ops.bn_fwd_fused(x, gamma, beta, residual, running_mean, running_var, batches, momentum, eps, act, slope)
         else:
-            if training:
+            if training and tickets is not None and N * HW > 1:
+                # statistics + Chan merge + running statistics + batch counter in one launch (last-arriver merge, csrc/norm.hip)
+                mean, var = ops.bn_stats_merged(x, running_mean, running_var, batches, tickets[0], momentum)
+            elif training:
                 mean_nc, m2_nc = ops.plane_stats(x)
                 mean, var = ops.bn_merge(mean_nc, m2_nc, N, C, HW, running_mean, running_var, momentum)
                 if batches is not None:
@@ -268,6 +271,7 @@ class _BatchNormActFn(torch.autograd.Function):
                 mean, var = running_mean, running_var
             y = ops.norm_act_fwd(x, mean, var, gamma, beta, residual, False, eps, act, slope)
         ctx.cfg = (eps, act, slope, training, residual is not None, fused)
+        ctx.tickets = tickets
         ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, var, gamma)
         return y
 
@@ -286,8 +290,11 @@ class _BatchNormActFn(torch.autograd.Function):
             dx, dres, s1, s2 = ops.bn_bwd_fused(dy, x, y, mean, var, gamma, eps, act, slope, want_dx,
                                                 want_res and act != ACT_NONE)
         else:
-            s1n, s2n = ops.norm_bwd_stats(dy, x, y, mean, var, False, eps, act, slope)
-            s1, s2 = ops.bn_bwd_reduce(s1n, s2n, N, C)
+            if ctx.tickets is not None:
+                s1, s2 = ops.bn_bwd_stats_reduced(dy, x, y, mean, var, eps, act, slope, ctx.tickets[1])
+            else:
+                s1n, s2n = ops.norm_bwd_stats(dy, x, y, mean, var, False, eps, act, slope)
+                s1, s2 = ops.bn_bwd_reduce(s1n, s2n, N, C)
             if want_dx or (want_res and act != ACT_NONE):
                 dx, dres = ops.norm_bwd_apply(dy, x, y, mean, var, gamma, s1, s2, False, eps, act, slope,
                                               want_res and act != ACT_NONE)
@@ -295,15 +302,15 @@ class _BatchNormActFn(torch.autograd.Function):
             dres = dy
         dgamma = s2 if ctx.needs_input_grad[1] else None
         dbeta = s1 if ctx.needs_input_grad[2] else None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
-                   residual=None, training=True, batches=None):
+                   residual=None, training=True, batches=None, tickets=None):
     """act( BatchNorm2d(affine=True)(x) + residual ) with batch statistics in train mode; `batches` = the module's
     num_batches_tracked counter (incremented on the device, inside the fused kernel when the tensor is small)."""
     return _BatchNormActFn.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope,
-                                 training, batches)
+                                 training, batches, tickets)
 
 
 # ---------------------------------------------------------------------------- pointwise

@@ -11,7 +11,7 @@ makes that possible: no hidden allocation, no host synchronisation, device-side 
 Dropout2d inside a captured net: the keep flags of every site are slices of ONE static buffer that is refilled by a single
 `bernoulli_` launch in front of each replay (independent draws per pass, as in eager mode).
 
-Not used while autograd is recording, while a parity test injects masks (`Dropout2d.mask_source`), under torch.distributed, or with
+Not used while autograd would record the call (an input or a parameter requires gradients), while a parity test injects masks (`Dropout2d.mask_source`), under torch.distributed, or with
 PCGAN_GRAPH_NOGRAD=0.
 A capture is tied to the packed-weight epoch, to the train / eval mode of every sub-module and to the versions of the parameters and
 buffers it reads: anything that re-packs every weight (load_networks, broadcast), `net.eval()` / `net.train()`, or a direct
@@ -80,10 +80,23 @@ class GraphedNoGrad(object):
         self.warm = warm
         self.state = {}
 
+    def _records_nothing(self, x):
+        """no autograd graph would be built for this call: grad mode off, or neither the input nor any parameter asks for gradients
+        (the frozen encoder on real images inside backward_G: config 4's ten MC-dropout passes of the z_rec term)"""
+        if not torch.is_grad_enabled():
+            return True
+        if x.requires_grad:
+            return False
+        return not (isinstance(self.fn, torch.nn.Module) and any(p.requires_grad for p in self.fn.parameters()))
+
     def __call__(self, x):
-        if (not ENABLED or torch.is_grad_enabled() or not (isinstance(x, torch.Tensor) and x.is_cuda)
+        if (not ENABLED or not (isinstance(x, torch.Tensor) and x.is_cuda) or not self._records_nothing(x)
                 or hnn.Dropout2d.mask_source is not None or torch.cuda.is_current_stream_capturing() or parallel.is_distributed()):
             return self.fn(x)      # (under torch.distributed: RCCL's watchdog thread and stream capture do not mix; eager there)
+        with torch.no_grad():
+            return self._call_no_grad(x)
+
+    def _call_no_grad(self, x):
         key = (tuple(x.shape), x.dtype, ops._PACK_EPOCH[0], ops.BF16X6, ops.HSPLIT, ops.HGEMM, ops.BSPLIT_MIN_PIXELS, _module_stamp(self.fn))
         ent = self.state.get(key)
         if ent is None:

@@ -12,8 +12,13 @@ the reference's (same indices => same state_dict keys) with the obvious fusions:
 import torch
 import torch.nn as tnn
 
+import os
+
 from . import functional as F
 from .lib import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID
+
+
+BN_TICKETS = os.environ.get('PCGAN_BN_TICKETS', '1') != '0'      # one-launch statistics for the large BatchNorm tensors (A/B switch)
 
 
 class Conv2d(tnn.Conv2d):
@@ -53,11 +58,20 @@ class BatchNorm2d(tnn.BatchNorm2d):
     """BatchNorm2d(affine=True); train mode uses batch statistics (the reference never calls
     .eval() while training)."""
 
+    def _tickets(self, device):
+        """arrival counters of the one-launch statistics kernels (forward / backward), zeroed once (csrc/norm.hip: last arriver)"""
+        t = self.__dict__.get('_pcgan_tickets')
+        if t is None or t[0].device != device:
+            buf = torch.zeros(2 * self.num_features, dtype=torch.int32, device=device)
+            t = self.__dict__['_pcgan_tickets'] = (buf[:self.num_features], buf[self.num_features:])
+        return t
+
     def forward(self, x, act=ACT_NONE, slope=0.0, residual=None):
         training = self.training or self.running_mean is None
+        tickets = self._tickets(x.device) if (training and x.is_cuda and self.running_mean is not None and BN_TICKETS) else None
         return F.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
                                 self.eps, act, slope, residual, training,
-                                self.num_batches_tracked if training else None)
+                                self.num_batches_tracked if training else None, tickets)
 
 
 class Dropout2d(tnn.Dropout2d):

@@ -743,6 +743,39 @@ def bn_merge(mean_nc, m2_nc, N, C, HW, running_mean, running_var, momentum):
     return mean_c, var_c
 
 
+def bn_stats_merged(x, running_mean, running_var, batches, ticket, momentum):
+    """batch statistics of a train-mode BatchNorm2d in ONE launch (plane_stats + bn_merge + batch counter: the last-arriving
+    workgroup of every channel merges its N plane statistics); returns mean_c, var_c (biased)"""
+    _chk(running_mean, running_var)
+    dt = _act(x)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    assert ticket.dtype == torch.int32 and ticket.numel() >= C and ticket.is_cuda
+    if batches is not None:
+        assert batches.dtype == torch.int64 and batches.is_cuda
+    part = torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
+    mc = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().pcgan_bn_stats_merged(_p(x), _p(part), _vp(part.data_ptr() + 4 * N * C), _p(mc), _vp(mc.data_ptr() + 4 * C),
+                                             _p(running_mean), _p(running_var), _p(batches), _p(ticket), N, C, HW, float(momentum), dt,
+                                             _stream()), 'bn_stats_merged')
+    return mc[:C], mc[C:]
+
+
+def bn_bwd_stats_reduced(dy, x, y, mean, var, eps, act, slope, ticket):
+    """s1_c = sum g, s2_c = sum g * xhat over N, H, W in ONE launch (norm_bwd_stats + bn_bwd_reduce)"""
+    _chk(mean, var)
+    dt = _act(dy, x, y)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    assert ticket.dtype == torch.int32 and ticket.numel() >= C and ticket.is_cuda
+    part = torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
+    sc = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().pcgan_bn_bwd_stats_reduced(_p(dy), _p(x), _p(y), _p(mean), _p(var), _p(part), _vp(part.data_ptr() + 4 * N * C), _p(sc),
+                                                  _vp(sc.data_ptr() + 4 * C), _p(ticket), N, C, HW, float(eps), act, float(slope), dt,
+                                                  _stream()), 'bn_bwd_stats_reduced')
+    return sc[:C], sc[C:]
+
+
 def in_running_update(mean_nc, m2_nc, running_mean, running_var, N, C, HW, momentum):
     _chk(mean_nc, m2_nc, running_mean, running_var)
     _L.check(_L.load().pcgan_in_running_update(_p(mean_nc), _p(m2_nc), _p(running_mean), _p(running_var), N, C, HW,

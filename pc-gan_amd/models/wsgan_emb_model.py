@@ -218,7 +218,7 @@ class WSGANEmbModel(BaseModel):
         o = self.opt
         x = self.transform_E(x_E)
         # the frozen encoder on a real image set (no autograd graph): hipGraph replay of the same launches (hip/graphs.py)
-        E = self._graphed('E', self.netE) if not torch.is_grad_enabled() else self.netE
+        E = self._graphed('E', self.netE)      # (replays only when the call records no autograd graph; eager otherwise)
         if not o.bayesian and not o.noisy:
             return E(x), None
         if not o.bayesian and o.noisy:
@@ -371,7 +371,9 @@ class WSGANEmbModel(BaseModel):
         else:
             # reference quirk kept: the prediction comes from real_A_E, so this term
             # carries no gradient to G
-            pred_y, y_var_, y_s2_ = compute_mu_and_var(self.netE, self.transform_E(self.real_A_E), o.bnn_T, True)
+            # (real images, frozen encoder: nothing to differentiate -- the ten MC-dropout passes replay the captured forward)
+            pred_y, y_var_, y_s2_ = compute_mu_and_var(self._graphed('E', self.netE) if o.lr_E <= 0.0 else self.netE,
+                                                       self.transform_E(self.real_A_E), o.bnn_T, True)
             y_var = torch.zeros_like(pred_y)
             if 'a' in o.noisy_var_type:
                 y_var = y_var + y_s2_
