@@ -1034,6 +1034,8 @@ struct HWgradArgs {
     int x_namax, dy_namax;
     int ntile, nwg;        // column tiles, workgroups that have work (the grid is padded to a multiple of 8)
     unsigned* ovf;         // non-finite sentinel (common.h), fp32 tensors only; may be null
+    int reflect_inline;    // fp32, stride 1, 3x3, reflection padding 1: XP is the UNPADDED input (Hp = H, Wp = W) and the mirror is applied
+                           // in the gather -- a per-stage row select and one register move at the two image edges -- instead of by a padded copy
 };
 
 // NC = column tiles of 128 per workgroup (2 with the 256-row tile: the dy tile is loaded and split once for 256 columns)
@@ -1083,9 +1085,17 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     const int bcol = tid / BT, bq = tid % BT;
     const int col = bx * CW + bcol;
     unsigned bvo = BS_OOB;
+    int tr = 1, fixl = 0, fixr = 0;      // inline reflection: this thread's tap row; whether its first / last element can fall on column -1 / W
     if (col < CT) {
         const int c = col / T, tap = col - c * T, r = tap / a.S, s = tap - r * a.S;
-        bvo = (unsigned)((c * a.Hp + r) * a.Wp + s + bq * KB * STRIDE) * ES;
+        if (a.reflect_inline) {      // row term chosen per stage (ro0 / ro1 / ro2 below); a left-edge lane's run starts at column -1
+            bvo = (unsigned)((c * a.Hp) * a.Wp + s - 1 + bq * KB) * ES;      // (may be "-4": the per-stage sum below is not)
+            tr = r;
+            fixl = (s == 0 && bq == 0);
+            fixr = (s == 2 && bq == BT - 1);
+        } else {
+            bvo = (unsigned)((c * a.Hp + r) * a.Wp + s + bq * KB * STRIDE) * ES;
+        }
     }
     const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.DY), 0, (int)a.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.XP), 0, (int)a.xp_bytes, 0x00020000);
@@ -1104,6 +1114,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     struct Stage {
         unsigned a[HALF ? 4 : 8];     // 8 consecutive dy values of this thread's row (bf16: packed pairs)
         unsigned b[KB];               // KB consecutive output pixels of this thread's column
+        int fix;                      // inline reflection: 1 = the run starts at column -1, loaded from column 0 instead (rotate), 2 = the last is column W
     };
     int lcount = 0;
 #ifndef WG_ABL
@@ -1112,8 +1123,23 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     auto load = [&](Stage& r) {
         const bool live = WG_ABL == 1 ? false : lcount < nst_here;
         const unsigned aso = (unsigned)(ln * a.K * PQ + ly * a.Q + lx) * ES;
-        const unsigned bso = (unsigned)(((ln * a.C) * a.Hp + ly * STRIDE) * a.Wp + lx * STRIDE) * ES;
-        const unsigned av = live ? avo : BS_OOB, bv = live ? bvo : BS_OOB;
+        unsigned bso = (unsigned)(((ln * a.C) * a.Hp + ly * STRIDE) * a.Wp + lx * STRIDE) * ES;
+        unsigned bvt = bvo;
+        r.fix = 0;
+        if constexpr (!HALF && STRIDE == 1) {
+            if (a.reflect_inline) {      // source row of tap row tr under reflection padding 1 (scalars per stage), selected by the lane's tap row
+                const int y0 = ly == 0 ? 1 : ly - 1, y2 = ly == a.Hp - 1 ? a.Hp - 2 : ly + 1;
+                const unsigned base = (unsigned)((ln * a.C) * a.Hp * a.Wp + lx) * ES;
+                const unsigned ro0 = base + (unsigned)(y0 * a.Wp) * ES, ro1 = base + (unsigned)(ly * a.Wp) * ES, ro2 = base + (unsigned)(y2 * a.Wp) * ES;
+                r.fix = (lx == 0 && fixl) ? 1 : ((lx + 16 == a.Q && fixr) ? 2 : 0);
+                // a run that would start at column -1 is loaded from column 0 and rotated when it is split (the first row of the tensor
+                // has nothing in front of it, and an offset of "-4" does not wrap in the hardware's range check: the whole load would
+                // return 0); a run that ends at column W reads one element of the next row -- in range, or zero at the very end
+                bvt = bvo + (tr == 0 ? ro0 : (tr == 1 ? ro1 : ro2)) + (r.fix == 1 ? ES : 0u);
+                bso = 0;
+            }
+        }
+        const unsigned av = live ? avo : BS_OOB, bv = live ? bvt : BS_OOB;
         if constexpr (HALF) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso, 0);
             r.a[0] = v.x; r.a[1] = v.y; r.a[2] = v.z; r.a[3] = v.w;
@@ -1165,8 +1191,12 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
             }
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
+            unsigned bj = r.b[j];
+            if (j == 0) bj = r.fix == 1 ? r.b[1] : bj;                     // run loaded from column 0: wanted (col 1, col 0, col 1, col 2, ...)
+            else bj = r.fix == 1 ? r.b[j - 1] : bj;
+            if (j == KB - 1) bj = r.fix == 2 ? r.b[KB - 3] : bj;           // column W mirrors to column W - 2
             _Float16 x, y;
-            split2h(__uint_as_float(r.b[j]) * sx, x, y);
+            split2h(__uint_as_float(bj) * sx, x, y);
             q.bh[j] = x;
             q.bl[j] = y;
         }
@@ -1817,17 +1847,25 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     void* xpad = ws;
     float* part = (float*)((char*)ws + xpad_bytes);
     const void* xin = x;
-    if (d->pad > 0) {
+    // the residual-block shape (fp32, 3x3, stride 1, reflection padding 1): the mirror is applied inside the gather, no padded copy
+    const bool inline_reflect = !half && d->stride == 1 && d->pad_mode == 1 && d->pad == 1 && d->R == 3 && d->S == 3 && d->H >= 2 && d->W >= 16 &&
+                                d->P == d->H && d->Q == d->W && getenv("PCGAN_WGRAD_PADCOPY") == nullptr;
+    int Hx = Hp, Wx = Wp;
+    if (inline_reflect) {
+        Hx = d->H;
+        Wx = d->W;
+    } else if (d->pad > 0) {
         pcgan::launch_pad(x, xpad, d->N * d->C, d->H, d->W, d->pad, d->pad_mode, half, st);
         PCGAN_LAUNCH_CHECK();
         xin = xpad;
     }
     pcgan::HWgradArgs a;
     a.XP = xin; a.DY = dy; a.part = part;
-    a.N = d->N; a.C = d->C; a.K = d->K; a.P = d->P; a.Q = d->Q; a.Hp = Hp; a.Wp = Wp; a.R = d->R; a.S = d->S;
+    a.N = d->N; a.C = d->C; a.K = d->K; a.P = d->P; a.Q = d->Q; a.Hp = Hx; a.Wp = Wx; a.R = d->R; a.S = d->S;
+    a.reflect_inline = inline_reflect ? 1 : 0;
     a.nst = d->N * d->P * d->Q / 16;
     a.nst_split = per;
-    a.xp_bytes = (unsigned)((size_t)d->N * d->C * Hp * Wp * es);
+    a.xp_bytes = (unsigned)((size_t)d->N * d->C * Hx * Wx * es);
     a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * es);
     a.x_amax = x_amax; a.x_namax = n_xamax; a.dy_amax = dy_amax; a.dy_namax = n_dyamax;
     a.ovf = half ? nullptr : pcgan::nonfinite_counter();
