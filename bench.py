@@ -252,8 +252,8 @@ def main():
         names = {'res_fwd': 'bsplit_halo_kernel<BH_FWD,PK_F16X2,float,32> (two scaled fp16 pieces per operand, 3 x v_mfma_f32_32x32x16_f16 per '
                             'K=16 step, 256 x 128 tile, input window split once per 16-channel chunk)',
                  'res_dgrad': 'bsplit_halo_kernel<BH_DGRAD,PK_F16X2,float,32> (the same window kernel on dy with its sum rows / columns)',
-                 'res_wgrad': 'bsplit_pad_wave_kernel + hsplit_wgrad_kernel<256,1,float,1> + bsplit_wgrad_reduce_kernel (padded copy of x, '
-                              '14 splits of the pixel reduction, fixed-order reduce into the gradient buffer)'}
+                 'res_wgrad': 'hsplit_wgrad_kernel<256,1,float,1> + bsplit_wgrad_reduce_kernel (x gathered with the reflection applied in '
+                              'the loads, 14 splits of the pixel reduction, fixed-order reduce into the gradient buffer)'}
     elif split:
         route, peak = 'bf16x3', BF16_MFMA_PEAK_TFLOPS / BF16_SPLIT_PRODUCTS
         basis = 'dense bf16 MFMA %.0f TFLOP/s / %d piece products per fp32 product' % (BF16_MFMA_PEAK_TFLOPS, BF16_SPLIT_PRODUCTS)
