@@ -386,6 +386,26 @@ int pcgan_resblock_bwd(const pcgan_resblock_desc* d, const void* dout, const voi
                        float* dw1, float* db1, float* dw2, float* db2, void* dy2, void* dh, void* dy1, void* dx, float* scratch,
                        void* wgrad_ws, size_t wgrad_ws_bytes, pcgan_stream_t s, pcgan_stream_t side, pcgan_event_t fork_event);
 
+/* ---- convolutions that gather <= 4 channels, on the same fp16 two-piece route (csrc/thin_conv.hip) --------------------------------------
+ * pass = PCGAN_PASS_FWD: C <= 4 input channels, K a multiple of 64 (<= 256), 7x7 stride 1 / 2 or 4x4 stride 2, zero padding or (stride 1)
+ * reflection padding -- ReflectionPad2d(3) + Conv2d(input_nc + nz, ngf, 7) of the generator (models/networks.py:578-581), conv1 of the Elo
+ * encoder's ResNet-18 (models/resnet.py:108-111), the first PatchGAN layer (models/networks.py:753-755).
+ * pass = PCGAN_PASS_BWD_DATA: K <= 4 output channels of the convolution, C a multiple of 64, 7x7 stride 1 -- autograd's data gradient of
+ * the generator's head ReflectionPad2d(3) + Conv2d(ngf, output_nc, 7) (models/networks.py:603-605), computed as a forward-form
+ * convolution of dy with flipped weights; with reflection padding on the padded grid (ws: pcgan_conv2d_thin_workspace_bytes) and folded.
+ * One workgroup = 8 x 32 output pixels x 64 channels; its input window is loaded, scaled and split ONCE into LDS as [position][4 channels],
+ * and with k = 4 tap + channel an MFMA lane's 8 consecutive k are two adjacent taps = two 8-byte LDS reads.  packed
+ * (pcgan_conv2d_thin_packed_bytes): the weights pre-scaled per output row, pre-split, in MFMA fragment order + the row maxima; x_amax /
+ * n_amax as for the other fp16-route calls (partial maxima of |x| on the device).  fp32 tensors only. */
+int pcgan_conv2d_thin_supported(const pcgan_conv_desc* d, int pass);
+size_t pcgan_conv2d_thin_packed_bytes(const pcgan_conv_desc* d, int pass);
+size_t pcgan_conv2d_thin_workspace_bytes(const pcgan_conv_desc* d, int pass);
+int pcgan_conv2d_thin_pack(const pcgan_conv_desc* d, int pass, const float* w, void* packed, pcgan_stream_t s);
+int pcgan_conv2d_fwd_thin(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_amax, const void* packed, const float* bias,
+                          void* y, int act, float slope, pcgan_stream_t s);
+int pcgan_conv2d_bwd_data_thin(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed, void* dx,
+                               void* ws, size_t ws_bytes, pcgan_stream_t s);
+
 /* ---- kernel timer (measurement only) -----------------------------------------------------------------------------------------------
  * bench.py's roofline block: HIP events on the launch stream around every launch of the three residual-block convolution kernels
  * (kind 0 forward, 1 data gradient, 2 weight gradient incl. its padded copy and reduce, 3 the weight gradient's main kernel),

@@ -60,6 +60,9 @@ __device__ __forceinline__ void report_nonfinite(unsigned* counter, bool bad) {
 // out[row] = largest |w| of every row of w[K][C][T] seen as the forward GEMM's A (by_c = 0: row = k) or the data gradient's (by_c = 1: row = c)
 int launch_weight_row_absmax(const float* w, int K, int C, int T, int by_c, float* out, hipStream_t st);
 
+// igemm_conv.hip: fold of the padded-grid gradient of a ReflectionPad2d input (also the last step of thin_conv.hip's head data gradient)
+int launch_reflect_fold(const void* padded, void* dx, int NC, int H, int W, int pad, int dtype, hipStream_t st);
+
 static inline int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

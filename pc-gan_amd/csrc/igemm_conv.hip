@@ -2749,6 +2749,22 @@ extern "C" int pcgan_conv2d_fwd_packed(const pcgan_conv_desc* d, const void* x, 
     return conv2d_fwd_impl(d, x, nullptr, packed, bias, y, act, slope, ws, ws_bytes, s);
 }
 
+namespace pcgan {
+// dx = the gradient of a reflection-padded tensor `padded` [NC][H + 2 pad][W + 2 pad] folded back onto the unpadded grid
+int launch_reflect_fold(const void* padded, void* dx, int NC, int H, int W, int pad, int dtype, hipStream_t st) {
+    PCGAN_CHECK(NC <= 65535, "conv2d_bwd_data: more than 65535 planes in the reflect fold");
+    const int per_plane = H * ((W + 3) / 4);
+    if (dtype == PCGAN_BF16)
+        hipLaunchKernelGGL(reflect_fold_kernel<bf16>, dim3((per_plane + 255) / 256, NC), dim3(256), 0, st, (const bf16*)padded, (bf16*)dx, NC, H,
+                           W, pad);
+    else
+        hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3((per_plane + 255) / 256, NC), dim3(256), 0, st, (const float*)padded, (float*)dx, NC,
+                           H, W, pad);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace pcgan
+
 static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const void* dy, const float* w, const float* packed,
                                 const float* bias, void* dx, void* ws, size_t ws_bytes, pcgan_stream_t s, const HsplitOpt* hs = nullptr) {
     if (check_desc(d)) return 1;
@@ -2885,17 +2901,7 @@ static int conv2d_bwd_data_impl(const pcgan_conv_desc* d, const void* dy, const 
     float* part = (bwd_part_bytes(d) && !reflect && !need_zero) ? (float*)((char*)ws + a_bytes) : nullptr;
     if (fused ? launch_igemm<MODE_BWD_REFLECT>(a, st, part, bwd_part_bytes(d)) : launch_igemm<MODE_BWD>(a, st, part, bwd_part_bytes(d)))
         return 2;
-    if (reflect) {
-        PCGAN_CHECK(d->N * d->C <= 65535, "conv2d_bwd_data: more than 65535 planes in the reflect fold");
-        const int per_plane = d->H * ((d->W + 3) / 4);
-        if (d->dtype == PCGAN_BF16)
-            hipLaunchKernelGGL(reflect_fold_kernel<bf16>, dim3((per_plane + 255) / 256, d->N * d->C), dim3(256), 0, st, (const bf16*)out,
-                               (bf16*)dx, d->N * d->C, d->H, d->W, d->pad);
-        else
-            hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3((per_plane + 255) / 256, d->N * d->C), dim3(256), 0, st, (const float*)out,
-                               (float*)dx, d->N * d->C, d->H, d->W, d->pad);
-        PCGAN_LAUNCH_CHECK();
-    }
+    if (reflect) return pcgan::launch_reflect_fold(out, dx, d->N * d->C, d->H, d->W, d->pad, d->dtype, st);
     return 0;
 }
 

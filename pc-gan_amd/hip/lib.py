@@ -119,6 +119,12 @@ SIGNATURES = {
     'pcgan_conv2d_hgemm_pack': (_i, [_dp, _i, _vp, _vp, _vp, _vp]),
     'pcgan_conv2d_fwd_packed_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
     'pcgan_conv2d_bwd_data_packed_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'pcgan_conv2d_thin_supported': (_i, [_dp, _i]),
+    'pcgan_conv2d_thin_packed_bytes': (_sz, [_dp, _i]),
+    'pcgan_conv2d_thin_workspace_bytes': (_sz, [_dp, _i]),
+    'pcgan_conv2d_thin_pack': (_i, [_dp, _i, _vp, _vp, _vp]),
+    'pcgan_conv2d_fwd_thin': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp]),
+    'pcgan_conv2d_bwd_data_thin': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     'pcgan_conv2d_hsplit_wgrad_supported': (_i, [_dp]),
     'pcgan_conv2d_hsplit_wgrad_workspace_bytes': (_sz, [_dp]),
     'pcgan_conv2d_bwd_weight_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),

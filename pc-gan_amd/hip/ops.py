@@ -235,12 +235,16 @@ PASS_FWD_HSPLIT = 102
 PASS_BWD_HSPLIT = 103
 PASS_FWD_HGEMM = 104     # pcgan_conv2d_hgemm_pack: the fp32 packed image with pre-split (two fp16 pieces) weights
 PASS_BWD_HGEMM = 105
+PASS_FWD_THIN = 106      # pcgan_conv2d_thin_pack: <= 4 gathered channels (7x7 stems, first PatchGAN layer; data gradient of the 64 -> 3 head)
+PASS_BWD_THIN = 107
 # Which split the fp32 residual convolutions (forward, data gradient) take on the matrix pipe: 'f16' = two scaled fp16 pieces, three
 # products (csrc/bf16x6_conv.hip, "fp16 route"); 'bf16' = three bf16 pieces, six products.  Same measured error, half the MFMAs.
 HSPLIT = os.environ.get('PCGAN_SPLIT', 'f16') == 'f16'
 # ... and whether every other convolution with a multiple of 16 gathered channels runs the fp16 two-piece form of the packed
 # implicit GEMM (csrc/igemm_conv.hip hgemm_kernel) instead of the fp32 MFMA one
 HGEMM = os.environ.get('PCGAN_HGEMM', '1') == '1'
+# ... and the convolutions that gather <= 4 channels the window kernel of csrc/thin_conv.hip instead of igemm2_kernel<.., 4> on fp32 MFMA
+THIN = os.environ.get('PCGAN_THIN', '1') == '1'
 
 
 AMAX_STATS = {'attached': 0, 'computed': 0}     # operand maxima handed over by the producing kernel / taken by an absmax pass
@@ -298,6 +302,8 @@ def _packed_weights(lib, d, pass_, w, cache, want_rowmax=False):
         nb = int(lib.pcgan_conv2d_bsplit_dgrad_packed_bytes(ctypes.byref(d)))
     elif pass_ in (PASS_FWD_HGEMM, PASS_BWD_HGEMM):
         nb = int(lib.pcgan_conv2d_packed_bytes(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HGEMM else _L.PASS_BWD_DATA))
+    elif pass_ in (PASS_FWD_THIN, PASS_BWD_THIN):
+        nb = int(lib.pcgan_conv2d_thin_packed_bytes(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_THIN else _L.PASS_BWD_DATA))
     else:
         nb = int(lib.pcgan_conv2d_packed_bytes(ctypes.byref(d), pass_))
     nb = max(nb, 256)
@@ -320,6 +326,9 @@ def _packed_weights(lib, d, pass_, w, cache, want_rowmax=False):
         _L.check(lib.pcgan_conv2d_bsplit_pack(ctypes.byref(d), _p(w), _p(buf), _stream()), 'conv2d_bsplit_pack')
     elif pass_ == PASS_BWD_BSPLIT:
         _L.check(lib.pcgan_conv2d_bsplit_dgrad_pack(ctypes.byref(d), _p(w), _p(buf), _stream()), 'conv2d_bsplit_dgrad_pack')
+    elif pass_ in (PASS_FWD_THIN, PASS_BWD_THIN):
+        _L.check(lib.pcgan_conv2d_thin_pack(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_THIN else _L.PASS_BWD_DATA, _p(w), _p(buf),
+                                            _stream()), 'conv2d_thin_pack')
     elif pass_ in (PASS_FWD_HGEMM, PASS_BWD_HGEMM):
         _L.check(lib.pcgan_conv2d_hgemm_pack(ctypes.byref(d), _L.PASS_FWD if pass_ == PASS_FWD_HGEMM else _L.PASS_BWD_DATA, _p(w), _p(rowmax),
                                              _p(buf), _stream()), 'conv2d_hgemm_pack')
@@ -376,7 +385,7 @@ def check_nonfinite(where=''):
 
 
 def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
-    key = (pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias, BF16X6, HSPLIT, HGEMM, BSPLIT_MIN_PIXELS)
+    key = (pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias, BF16X6, HSPLIT, HGEMM, THIN, BSPLIT_MIN_PIXELS)
     p = _PLANS.get(key)
     if p is not None:
         return p
@@ -398,6 +407,8 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
             p.route, p.pack_pass = 'bsplit', PASS_FWD_BSPLIT
         elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_FWD):
             p.route, p.pack_pass = 'hgemm', PASS_FWD_HGEMM
+        elif f16 and THIN and lib.pcgan_conv2d_thin_supported(p.dref, _L.PASS_FWD):
+            p.route, p.pack_pass = 'thin', PASS_FWD_THIN
         else:
             p.route, p.pack_pass = 'packed', _L.PASS_FWD
     elif pass_ == _L.PASS_BWD_DATA:
@@ -409,6 +420,9 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
             p.route, p.pack_pass = 'bsplit', PASS_BWD_BSPLIT
         elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_BWD_DATA):
             p.route, p.pack_pass = 'hgemm', PASS_BWD_HGEMM
+        elif f16 and THIN and no_bias and lib.pcgan_conv2d_thin_supported(p.dref, _L.PASS_BWD_DATA):
+            p.route, p.pack_pass = 'thin', PASS_BWD_THIN
+            p.ws_bytes = int(lib.pcgan_conv2d_thin_workspace_bytes(p.dref, _L.PASS_BWD_DATA))
         else:
             p.route, p.pack_pass = 'packed', _L.PASS_BWD_DATA
     else:
@@ -461,6 +475,10 @@ def conv2d_fwd(x, w, bias, stride, pad, pad_mode=0, act=ACT_NONE, slope=0.0, pac
                      'conv2d_fwd_hsplit')
         elif pl.route == 'bsplit':
             _L.check(lib.pcgan_conv2d_fwd_bsplit(d, _p(x), _p(pk), _p(bias), _p(y), act, float(slope), _stream()), 'conv2d_fwd_bsplit')
+        elif pl.route == 'thin':
+            xmax = amax_of(x)
+            _L.check(lib.pcgan_conv2d_fwd_thin(d, _p(x), _p(xmax), xmax.numel(), _p(pk), _p(bias), _p(y), act, float(slope), _stream()),
+                     'conv2d_fwd_thin')
         else:
             _L.check(lib.pcgan_conv2d_fwd_packed(d, _p(x), _p(pk), _p(bias), _p(y), act, float(slope), _p(ws), ws.numel(), _stream()),
                      'conv2d_fwd_packed')
@@ -494,6 +512,10 @@ def conv2d_bwd_data(dy, w, in_hw, stride, pad, pad_mode=0, bias=None, pack_cache
             _L.check(lib.pcgan_conv2d_bwd_data_hsplit(d, _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_hsplit')
         elif pl.route == 'bsplit':
             _L.check(lib.pcgan_conv2d_bwd_data_bsplit(d, _p(dy), _p(pk), _p(dx), _stream()), 'conv2d_bwd_data_bsplit')
+        elif pl.route == 'thin':
+            dmax = amax_of(dy)
+            _L.check(lib.pcgan_conv2d_bwd_data_thin(d, _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(dx), _p(ws), ws.numel(), _stream()),
+                     'conv2d_bwd_data_thin')
         elif pl.route == 'hgemm':
             dmax = amax_of(dy)
             _L.check(lib.pcgan_conv2d_bwd_data_packed_hsplit(d, _p(dy), _p(dmax), dmax.numel(), _p(pk), _p(wmax), _p(bias), _p(dx),
