@@ -245,6 +245,7 @@ HSPLIT = os.environ.get('PCGAN_SPLIT', 'f16') == 'f16'
 HGEMM = os.environ.get('PCGAN_HGEMM', '1') == '1'
 # ... and the convolutions that gather <= 4 channels the window kernel of csrc/thin_conv.hip instead of igemm2_kernel<.., 4> on fp32 MFMA
 THIN = os.environ.get('PCGAN_THIN', '1') == '1'
+THIN_MASK = int(os.environ.get('PCGAN_THIN_MASK', '7'))     # debugging: 1 = stride-1 forward, 2 = stride-2 forward, 4 = data gradient
 
 
 AMAX_STATS = {'attached': 0, 'computed': 0}     # operand maxima handed over by the producing kernel / taken by an absmax pass
@@ -407,7 +408,7 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
             p.route, p.pack_pass = 'bsplit', PASS_FWD_BSPLIT
         elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_FWD):
             p.route, p.pack_pass = 'hgemm', PASS_FWD_HGEMM
-        elif f16 and THIN and lib.pcgan_conv2d_thin_supported(p.dref, _L.PASS_FWD):
+        elif f16 and THIN and (THIN_MASK & (1 if stride == 1 else 2)) and lib.pcgan_conv2d_thin_supported(p.dref, _L.PASS_FWD):
             p.route, p.pack_pass = 'thin', PASS_FWD_THIN
         else:
             p.route, p.pack_pass = 'packed', _L.PASS_FWD
@@ -420,9 +421,9 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
             p.route, p.pack_pass = 'bsplit', PASS_BWD_BSPLIT
         elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_BWD_DATA):
             p.route, p.pack_pass = 'hgemm', PASS_BWD_HGEMM
-        elif f16 and THIN and no_bias and lib.pcgan_conv2d_thin_supported(p.dref, _L.PASS_BWD_DATA):
+        elif f16 and THIN and (THIN_MASK & 4) and no_bias and lib.pcgan_conv2d_thin_supported(p.dref, _L.PASS_BWD_DATA):
             p.route, p.pack_pass = 'thin', PASS_BWD_THIN
-            p.ws_bytes = int(lib.pcgan_conv2d_thin_workspace_bytes(p.dref, _L.PASS_BWD_DATA))
+            p.ws_bytes = max(p.ws_bytes, int(lib.pcgan_conv2d_thin_workspace_bytes(p.dref, _L.PASS_BWD_DATA)))    # (no pack cache: the generic call)
         else:
             p.route, p.pack_pass = 'packed', _L.PASS_BWD_DATA
     else:

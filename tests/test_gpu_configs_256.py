@@ -73,7 +73,13 @@ def _grab(model, tags):
     return grabbed
 
 
-def _check_grads(tag, hip, ref, tol=2e-2):
+def _check_grads(tag, hip, ref, tol=3e-2):
+    """This is the LOOSE band: the oracle differentiates on its OWN ReLU / max-pool decisions, so the distance is that of a handful of
+    flipped decisions (every generator tensor sits at the same 1.6e-2 .. 2.2e-2), not of the kernels; the sharp 5e-4 checks with the
+    decisions replayed are tests/test_gpu_nets.py / test_gpu_step.py.  The band follows the distance between the HIP forward pass and
+    the CPU fp32 forward pass: with the generator stem on the f16 matrix pipe (csrc/thin_conv.hip) its output is CLOSER to float64
+    (1.7e-7 against 2.5e-7 for the fp32-MFMA kernel and for the CPU) but further from the CPU's own rounding (3.0e-7 against 1.4e-7,
+    scripts/acc_thin.py), so a few more decisions flip: 1.58e-2 -> 2.1e-2 on this fixture (PCGAN_THIN_MASK isolates it to the stem)."""
     for k, og in ref.items():
         if og is None:
             continue
@@ -94,6 +100,8 @@ def _check_grads(tag, hip, ref, tol=2e-2):
         # generator head): its fp32 value depends on the summation order on either side; the weights of the same layer are
         # the sharp check
         t = 1e-1 if k.endswith('.bias') else tol
+        if os.environ.get('PCGAN_TEST_VERBOSE'):
+            print('grad%s %-40s rel L2 %.3e' % (tag, k, e))
         assert e <= t, 'grad%s %s: relative L2 against the oracle %.3e > %.1e (max |g| %.3e)' % (tag, k, e, t, scale)
 
 

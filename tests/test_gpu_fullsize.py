@@ -131,6 +131,8 @@ def test_fullsize_step_vs_oracle(tmp_path, dev, route, monkeypatch):
     if route == 'split_kernels' and ops.HSPLIT:
         # the norm kernels hand the operand maxima over (18 residual convolutions x 2 generator passes x (forward, data gradient,
         # 2 operands of the weight gradient) alone are 216); only tensors written by a convolution epilogue or a max-pooling
-        # (the PatchGAN's second layer, AlexNet, the encoder's first block) still cost an absmax pass
+        # (the PatchGAN's second layer, AlexNet, the encoder's first block) still cost an absmax pass -- and, since the 3- / 4-channel
+        # layers run on the same route (csrc/thin_conv.hip), the images themselves: generator input x 2, the encoder's three inputs,
+        # the PatchGAN's four, the head's dy (small tensors: 6-19 MB)
         attached, computed = ops.AMAX_STATS['attached'] - amax0['attached'], ops.AMAX_STATS['computed'] - amax0['computed']
-        assert attached >= 216 and computed <= 24, ops.AMAX_STATS
+        assert attached >= 216 and computed <= 34, ops.AMAX_STATS
