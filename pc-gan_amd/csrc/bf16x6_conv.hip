@@ -1796,7 +1796,7 @@ extern "C" int pcgan_conv2d_hsplit_wgrad_supported(const pcgan_conv_desc* d) {
     if (!d || (d->dtype != PCGAN_F32 && d->dtype != PCGAN_BF16)) return 0;
     if (d->stride != 1 && d->stride != 2) return 0;
     if (d->pad_mode == 1 && (d->stride != 1 || d->pad >= d->H || d->pad >= d->W)) return 0;
-    if (d->K > 256 || d->K < 32 || d->R * d->S > 25 || d->Q % 16 != 0 || d->P < 1) return 0;
+    if (d->K > 256 || d->K < 32 || d->R * d->S > 49 || d->Q % 16 != 0 || d->P < 1) return 0;
     if (d->P != (d->H + 2 * d->pad - d->R) / d->stride + 1 || d->Q != (d->W + 2 * d->pad - d->S) / d->stride + 1) return 0;
     // the gather reads xpad rows up to (P-1) stride + R - 1 and columns up to (Q-1) stride + S - 1: inside the padded plane by the two lines above
     return (size_t)d->N * d->C * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * 4 < 0x80000000ull && (size_t)d->N * d->K * d->P * d->Q * 4 < 0x80000000ull &&

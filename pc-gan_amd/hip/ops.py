@@ -162,10 +162,14 @@ _branch = {}
 
 class branch(object):
     """with branch('E') as b: ... loss = f(...) ; b.join(loss): run the body on the named stream after everything
-    queued so far on the current stream; join() makes the current stream wait and hands the tensors over."""
+    queued so far on the current stream; join() makes the current stream wait and hands the tensors over.
+    after = a list of events / streams: the body only waits for THOSE (the readiness of its inputs, `ready_event`) instead of for the whole
+    current stream -- work that depends on nothing the current stream still has queued (the frozen encoder on the next batch) then
+    runs beside the tail of the previous step."""
 
-    def __init__(self, name, enabled=True):
+    def __init__(self, name, enabled=True, after=None):
         self.name = name
+        self.after = after
         self.on = enabled and BRANCH_STREAMS and torch.cuda.is_available() and name not in os.environ.get('PCGAN_BRANCH_OFF', '').split(',')
 
     def __enter__(self):
@@ -175,7 +179,14 @@ class branch(object):
             st = _branch.get(key)
             if st is None:
                 st = _branch[key] = torch.cuda.Stream(device=self.cur.device)
-            st.wait_stream(self.cur)
+            if self.after is None:
+                st.wait_stream(self.cur)
+            else:
+                for ev in self.after:      # events, or whole streams (another branch whose results the body reads)
+                    if isinstance(ev, torch.cuda.Stream):
+                        st.wait_stream(ev)
+                    else:
+                        st.wait_event(ev)
             self.st = st
             self.ctx = torch.cuda.stream(st)
             self.ctx.__enter__()
@@ -191,6 +202,31 @@ class branch(object):
             for t in tensors:
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(self.cur)
+
+
+_upload = {}
+
+
+def upload_stream(device):
+    """the stream input batches are copied / cast on (base_model.to_act): not ordered behind the step still running on the main stream"""
+    device = torch.device(device)
+    st = _upload.get(device)
+    if st is None:
+        st = _upload[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def ready_event(t):
+    """an event after which the device tensor `t` holds its current contents: attached by whoever produced it on another stream
+    (to_act), else recorded on the current stream the first time the tensor is seen and kept while its version stays the same -- a
+    batch that has been resident for a while is ready without waiting for what the current stream has queued since"""
+    ent = t.__dict__.get('_pcgan_ready')
+    if ent is not None and ent[0] == t._version:
+        return ent[1]
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(t.device))
+    t._pcgan_ready = (t._version, ev)
+    return ev
 
 
 def join_side_stream():
@@ -245,6 +281,7 @@ HSPLIT = os.environ.get('PCGAN_SPLIT', 'f16') == 'f16'
 HGEMM = os.environ.get('PCGAN_HGEMM', '1') == '1'
 # ... and the convolutions that gather <= 4 channels the window kernel of csrc/thin_conv.hip instead of igemm2_kernel<.., 4> on fp32 MFMA
 THIN = os.environ.get('PCGAN_THIN', '1') == '1'
+THIN_WGRAD = os.environ.get('PCGAN_THIN_WGRAD', '1') == '1'     # weight gradients of the 3- / 4-channel layers on the matrix-pipe kernel too
 THIN_MASK = int(os.environ.get('PCGAN_THIN_MASK', '7'))     # debugging: 1 = stride-1 forward, 2 = stride-2 forward, 4 = data gradient
 
 
@@ -281,6 +318,7 @@ def amax_of(x):
     slots = int(lib.pcgan_absmax_slots(x.numel()))
     out = torch.empty(slots, dtype=torch.float32, device=x.device)
     _L.check(lib.pcgan_absmax(_p(x), x.numel(), _DTYPES[x.dtype], _p(out), slots, _stream()), 'absmax')
+    _attach_amax(x, out)      # a second consumer of the same tensor version (forward and weight gradient of one layer) reuses the pass
     return out
 
 
@@ -386,7 +424,7 @@ def check_nonfinite(where=''):
 
 
 def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
-    key = (pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias, BF16X6, HSPLIT, HGEMM, THIN, BSPLIT_MIN_PIXELS)
+    key = (pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias, BF16X6, HSPLIT, HGEMM, THIN, THIN_WGRAD, BSPLIT_MIN_PIXELS)
     p = _PLANS.get(key)
     if p is not None:
         return p
@@ -434,7 +472,10 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
         res_like = K == 256 and R == 3 and S == 3 and stride == 1 and pad_mode == 1
         # (not where the padded copy of x costs more than the matrix pipe saves: measured slower for the 134 MB inputs of the
         # generator's outermost 64-channel layers, 0.235 vs 0.17 ms, and for 3- / 4-channel images)
-        cheap_pad = C % 16 == 0 and N * C * H * W * 4 <= 80 * 1000 * 1000
+        # (3- / 4-channel inputs: only the generator's 7x7 stride-1 stem gains, 0.266 -> 0.215 ms; the PatchGAN's first layer and the
+        # encoder's strided stem are faster on the fp32-MFMA kernels, scripts/time_thin.py)
+        thin_stem = C <= 4 and THIN_WGRAD and R == 7 and S == 7 and stride == 1
+        cheap_pad = (C % 16 == 0 or thin_stem) and N * C * H * W * 4 <= 80 * 1000 * 1000
         if (HSPLIT and BF16X6 and lib.pcgan_conv2d_hsplit_wgrad_supported(p.dref)
                 and (px >= BSPLIT_MIN_PIXELS if (res_like or not HGEMM) else px >= min(BSPLIT_MIN_PIXELS, 4096))
                 and (res_like or (HGEMM and cheap_pad))):

@@ -33,12 +33,31 @@ class BaseModel(object):
         return 'BaseModel'
 
     def to_act(self, image):
-        """a loader image batch on the device in the model's activation storage type (one cast kernel under --dtype bf16)"""
-        image = image.to(self.device, non_blocking=True)
-        if image.dtype != self.act_dtype and image.is_cuda:
-            from ..hip import ops
-            image = ops.cast(image.contiguous(), self.act_dtype)
-        return image
+        """a loader image batch on the device in the model's activation storage type (one cast kernel under --dtype bf16).  Copies and
+        casts run on an upload stream and the result carries its readiness event (hip/ops.py: ready_event), so that consumers which do
+        not depend on the step still in flight (the frozen encoder's passes over the new batch) need not queue behind it."""
+        from ..hip import ops
+        if not (isinstance(image, torch.Tensor) and self.device.type == 'cuda'):
+            return image.to(self.device)
+        if image.is_cuda and image.dtype == self.act_dtype:
+            ops.ready_event(image)
+            return image
+        cur = torch.cuda.current_stream(self.device)
+        up = ops.upload_stream(self.device)
+        src_ev = ops.ready_event(image) if image.is_cuda else None
+        with torch.cuda.stream(up):
+            if src_ev is not None:
+                up.wait_event(src_ev)
+                image.record_stream(up)
+            out = image.to(self.device, non_blocking=True)
+            if out.dtype != self.act_dtype:
+                out = ops.cast(out.contiguous(), self.act_dtype)
+            ev = torch.cuda.Event()
+            ev.record(up)
+        out._pcgan_ready = (out._version, ev)
+        cur.wait_event(ev)
+        out.record_stream(cur)
+        return out
 
     def set_input(self, input):
         self.input = input

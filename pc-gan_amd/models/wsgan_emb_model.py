@@ -26,7 +26,13 @@ from ..hip.optim import FusedAdam
 from ..util.util import upsample2d, str2list, str2bool, resample, compute_mu_and_var
 
 _DDP_OVERLAP = os.environ.get('PCGAN_DDP_OVERLAP', '0') == '1'
-_G2_BRANCH = os.environ.get('PCGAN_G2_BRANCH', '0') == '1'
+_G2_BRANCH = os.environ.get('PCGAN_G2_BRANCH', '1') == '1'
+# the frozen encoder's two passes over the new batch on the encoder's stream, waiting only for the batch itself
+_E_AHEAD = os.environ.get('PCGAN_E_AHEAD', '1') == '1'
+# ... likewise the generator's FIRST pass: it needs the batch, the encoder's rating and the generator's weights as the last
+# optimizer_G.step() left them -- not the discriminator update still queued behind it.  (AlexNet's features of real_A moved ahead the
+# same way cost 1.8 ms per step: that pass is better placed where it is, beside the discriminator branch of backward_G.)
+_G1_AHEAD = os.environ.get('PCGAN_G1_AHEAD', '1') == '1'
 
 MAGIC_EPS = 1e-20
 
@@ -242,30 +248,49 @@ class WSGANEmbModel(BaseModel):
     def forward(self):
         o = self.opt
         self.real_A_IP = upsample2d(self.real_A, o.fineSize_IP)
-        self.real_A_E = upsample2d(self.real_A, o.fineSize_E)
-        self.real_B_E = upsample2d(self.real_B, o.fineSize_E)
         frozen = o.lr_E <= 0.0
-        with torch.set_grad_enabled(not frozen):   # E is frozen: no graph, nothing saved for backward
-            y_A, var_A = self._encode(self.real_A_E)
-            y_B, var_B = self._encode(self.real_B_E)
-            if var_A is not None:       # resample order: A then B, as the reference draws them
-                self.resample_A = self.embedding_normalize(resample(y_A, var_A))
-                self.resample_B = self.embedding_normalize(resample(y_B, var_B))
-        self.y_A, self.y_B = y_A, y_B
-        self.embedding_A = self.embedding_normalize(y_A)
-        self.embedding_B = self.embedding_normalize(y_B)
+        # The frozen encoder's passes over the two real image sets depend on the batch and on the encoder's own state only (weights
+        # that no optimizer touches, BatchNorm running statistics that only encoder passes update -- all of them on this stream, in
+        # the reference's order): they run on the encoder's branch stream and wait for the BATCH (ops.ready_event), not for what the
+        # main stream still has queued, so they fill the tail of the previous step (backward_D, Adam) instead of starting the next.
+        ahead = frozen and _E_AHEAD and self.real_A.is_cuda
+        after = [hip_ops.ready_event(self.real_A), hip_ops.ready_event(self.real_B)] if ahead else None
+        with hip_ops.branch('E', enabled=ahead, after=after) as eb:
+            if eb.on:
+                self.real_A.record_stream(eb.st)
+                self.real_B.record_stream(eb.st)
+            self.real_A_E = upsample2d(self.real_A, o.fineSize_E)
+            self.real_B_E = upsample2d(self.real_B, o.fineSize_E)
+            with torch.set_grad_enabled(not frozen):   # E is frozen: no graph, nothing saved for backward
+                y_A, var_A = self._encode(self.real_A_E)
+                y_B, var_B = self._encode(self.real_B_E)
+                if var_A is not None:       # resample order: A then B, as the reference draws them
+                    self.resample_A = self.embedding_normalize(resample(y_A, var_A))
+                    self.resample_B = self.embedding_normalize(resample(y_B, var_B))
+            self.y_A, self.y_B = y_A, y_B
+            self.embedding_A = self.embedding_normalize(y_A)
+            self.embedding_B = self.embedding_normalize(y_B)
+        eb.join(self.real_A_E, self.real_B_E, self.y_A, self.y_B, self.embedding_A, self.embedding_B,
+                getattr(self, 'resample_A', None), getattr(self, 'resample_B', None))
         if frozen:
             self.y_A, self.y_B = self.y_A.detach(), self.y_B.detach()
             self.embedding_A, self.embedding_B = self.embedding_A.detach(), self.embedding_B.detach()
             if o.noisy_var_type:
                 self.resample_A, self.resample_B = self.resample_A.detach(), self.resample_B.detach()
-        self.fake_B = self.netG(self.real_A, self.embedding_B)
+        g_done = getattr(self, '_g_updated', None)
+        g1 = self.isTrain and _G1_AHEAD and ahead and eb.on and g_done is not None
+        with hip_ops.branch('G1', enabled=g1, after=[hip_ops.ready_event(self.real_A), eb.st, g_done] if g1 else None) as bg:
+            if bg.on:
+                self.real_A.record_stream(bg.st)
+                self.embedding_B.record_stream(bg.st)
+            self.fake_B = self.netG(self.real_A, self.embedding_B)
+        bg.join(self.fake_B)
         self.fake_B_IP = upsample2d(self.fake_B, o.fineSize_IP)
         self.fake_B_E = upsample2d(self.fake_B, o.fineSize_E)
         # the second generator pass only meets the other consumers of fake_B (D / IP / E branches of backward_G) in the
         # loss sum: it runs on its own stream beside them (forward here, its backward nodes on the same stream)
-        # (opt-in, PCGAN_G2_BRANCH=1: -1.3 % step time, but the second pass's kernels then share the GPU with the
-        # branches and per-kernel timings of the generator are no longer those of a kernel running alone)
+        # (default since round 3, PCGAN_G2_BRANCH=0 switches it off: -2 % step time; the second pass's kernels share the GPU with
+        # the branches, so their in-step timings include that overlap -- bench.py reports the alone timings beside them)
         with hip_ops.branch('G2', enabled=_G2_BRANCH) as self._rec_branch:
             self.rec_A = self.netG(self.fake_B.detach() if o.detach_fake_B else self.fake_B, self.embedding_A)
 
@@ -276,6 +301,7 @@ class WSGANEmbModel(BaseModel):
             self._rec_branch = None
 
     def test(self):
+        self._g_updated = None
         if hasattr(self, 'real_B'):
             if 'real_B' not in self.visual_names:
                 self.visual_names += ['real_B', 'fake_B']
@@ -285,11 +311,13 @@ class WSGANEmbModel(BaseModel):
                 self.fake_B = self.netG(self.real_A, self.embedding_B)
 
     def sample_from_prior(self):
+        self._g_updated = None
         y_B, _ = self._encode(upsample2d(self.real_B, self.opt.fineSize_E))
         self.embedding_B = self.embedding_normalize(y_B.detach())
         return self.netG(self.real_A, self.embedding_B)
 
     def sample_from_label(self, label):
+        self._g_updated = None
         emb_B = torch.Tensor([self.embedding_bins[label]]).reshape(1, 1, 1, 1).to(self.device)
         return self.netG(self.real_A, self.embedding_normalize(emb_B))
 
@@ -399,6 +427,13 @@ class WSGANEmbModel(BaseModel):
         self.backward_G()
         parallel.sync_gradients(self.optimizer_G)
         self.optimizer_G.step()
+        self._mark_g_updated()
+
+    def _mark_g_updated(self):
+        """the point in the current stream after which the generator's weights are those of this update (forward(): G1 branch)"""
+        if self.real_A.is_cuda:
+            self._g_updated = torch.cuda.Event()
+            self._g_updated.record(torch.cuda.current_stream(self.real_A.device))
 
     def optimize_parameters(self):
         self.forward()
@@ -419,11 +454,13 @@ class WSGANEmbModel(BaseModel):
         self.backward_D()
         finish_G()
         self.optimizer_G.step()
+        self._mark_g_updated()
         parallel.sync_gradients(self.optimizer_D)
         self.optimizer_D.step()
 
     def get_current_visuals(self):
         self._join_rec()
+        self._g_updated = None      # generator passes outside the step move its running statistics: the next forward() queues behind them
         self.set_requires_grad(self.netG, False)
         ret = OrderedDict()
         for name in self.visual_names:

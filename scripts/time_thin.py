@@ -30,3 +30,29 @@ for name, N, C, H, K, k, st, pad, pm, dgrad in LAYERS:
         torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 20)
     print('%-40s thin %.4f ms (%.0f TFLOP/s)   fp32 MFMA %.4f ms (%.0f)' % (name, res[0], flop / res[0] / 1e9, res[1], flop / res[1] / 1e9), flush=True)
+
+print('weight gradients (hsplit_wgrad_kernel with <= 4 gathered channels / 49 taps against the fp32-MFMA kernels)')
+for name, N, C, H, K, k, st, pad, pm in [('G.stem 4->64 7x7 reflect @128', 32, 4, 128, 64, 7, 1, 3, 1), ('D.c0 4->64 4x4 s2 @128', 32, 4, 128, 64, 4, 2, 1, 0),
+                                         ('E.conv1 3->64 7x7 s2 @224', 32, 3, 224, 64, 7, 2, 3, 0)]:
+    P = (H + 2 * pad - k) // st + 1
+    x = torch.randn(N, C, H, H, device=dev)
+    dy = torch.randn(N, K, P, P, device=dev)
+    flop = 2.0 * N * P * P * K * C * k * k
+    res, outs = [], []
+    for thin in (True, False):
+        ops.THIN_WGRAD = thin
+        f = lambda: ops.conv2d_bwd_weight(x, dy, (K, C, k, k), st, pad, pm)
+        for _ in range(3):
+            o = f()
+        outs.append(o.double())
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 10)
+    print('%-40s matrix pipe %.4f ms (%.0f TFLOP/s)   fp32 MFMA %.4f ms (%.0f)   rel diff %.2e  route %s' % (
+        name, res[0], flop / res[0] / 1e9, res[1], flop / res[1] / 1e9, float((outs[0] - outs[1]).norm() / outs[1].norm()),
+        [k_ for k_ in ops.ROUTE_STATS if k_[0] == 'wgrad']), flush=True)

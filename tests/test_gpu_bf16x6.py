@@ -302,6 +302,8 @@ def test_hsplit_weight_gradient(dev, N, C, H, W, acc, data):
     (8, 128, 16, 16, 64, 3, 1, 1, 0),     # 1024 small planes: the wave-per-plane padded copy, zero padding
     (9, 128, 16, 32, 64, 3, 1, 1, 1),     # ... reflection, a plane count that is no multiple of 4, non-square
     (4, 256, 12, 16, 64, 5, 1, 2, 1),     # ... padding 2
+    (2, 4, 32, 48, 64, 7, 1, 3, 1),       # the generator's stem: 4 channels x 49 taps = 196 columns (two ragged column tiles), reflection 3
+    (2, 3, 20, 32, 64, 7, 1, 3, 0),       # 3 channels, zero padding
 ])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_hsplit_weight_gradient_general(dev, N, C, H, W, K, k, stride, pad, mode, dtype):
