@@ -270,6 +270,7 @@ class WSGANEmbModel(BaseModel):
             self.y_A, self.y_B = y_A, y_B
             self.embedding_A = self.embedding_normalize(y_A)
             self.embedding_B = self.embedding_normalize(y_B)
+        self._e_on_branch = bool(ahead and eb.on)
         eb.join(self.real_A_E, self.real_B_E, self.y_A, self.y_B, self.embedding_A, self.embedding_B,
                 getattr(self, 'resample_A', None), getattr(self, 'resample_B', None))
         if frozen:
@@ -364,7 +365,11 @@ class WSGANEmbModel(BaseModel):
         o = self.opt
         b_e = None
         if o.lambda_z > 0.0:
-            b_e = hip_ops.branch('E')     # the Elo-encoder branch, beside the discriminator / identity branches
+            # the Elo-encoder branch, beside the discriminator / identity branches.  In the bayesian + noisy mode the prediction comes
+            # from real_A_E (reference quirk D10): everything it reads was produced on the encoder's stream by forward(), so the branch
+            # need not wait for the generator passes queued on the main stream
+            d10 = o.bayesian and o.noisy and o.lr_E <= 0.0 and getattr(self, '_e_on_branch', False)
+            b_e = hip_ops.branch('E', after=[] if d10 else None)
             b_e.__enter__()
             try:
                 self._z_rec_loss()
