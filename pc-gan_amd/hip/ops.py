@@ -196,6 +196,14 @@ class branch(object):
         if self.on:
             return self.ctx.__exit__(*exc)
 
+    def reads(self, *tensors):
+        """tensors allocated on other streams that the body reads: the caching allocator must not hand their memory out again (after
+        the owner drops them while the host runs ahead) before this stream is done with them"""
+        if self.on:
+            for t in tensors:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(self.st)
+
     def join(self, *tensors):
         if self.on:
             self.cur.wait_stream(self.st)

@@ -256,9 +256,7 @@ class WSGANEmbModel(BaseModel):
         ahead = frozen and _E_AHEAD and self.real_A.is_cuda
         after = [hip_ops.ready_event(self.real_A), hip_ops.ready_event(self.real_B)] if ahead else None
         with hip_ops.branch('E', enabled=ahead, after=after) as eb:
-            if eb.on:
-                self.real_A.record_stream(eb.st)
-                self.real_B.record_stream(eb.st)
+            eb.reads(self.real_A, self.real_B)
             self.real_A_E = upsample2d(self.real_A, o.fineSize_E)
             self.real_B_E = upsample2d(self.real_B, o.fineSize_E)
             with torch.set_grad_enabled(not frozen):   # E is frozen: no graph, nothing saved for backward
@@ -281,9 +279,7 @@ class WSGANEmbModel(BaseModel):
         g_done = getattr(self, '_g_updated', None)
         g1 = self.isTrain and _G1_AHEAD and ahead and eb.on and g_done is not None
         with hip_ops.branch('G1', enabled=g1, after=[hip_ops.ready_event(self.real_A), eb.st, g_done] if g1 else None) as bg:
-            if bg.on:
-                self.real_A.record_stream(bg.st)
-                self.embedding_B.record_stream(bg.st)
+            bg.reads(self.real_A, self.embedding_B)
             self.fake_B = self.netG(self.real_A, self.embedding_B)
         bg.join(self.fake_B)
         self.fake_B_IP = upsample2d(self.fake_B, o.fineSize_IP)
@@ -293,6 +289,7 @@ class WSGANEmbModel(BaseModel):
         # (default since round 3, PCGAN_G2_BRANCH=0 switches it off: -2 % step time; the second pass's kernels share the GPU with
         # the branches, so their in-step timings include that overlap -- bench.py reports the alone timings beside them)
         with hip_ops.branch('G2', enabled=_G2_BRANCH) as self._rec_branch:
+            self._rec_branch.reads(self.fake_B, self.embedding_A)
             self.rec_A = self.netG(self.fake_B.detach() if o.detach_fake_B else self.fake_B, self.embedding_A)
 
     def _join_rec(self):
@@ -346,6 +343,7 @@ class WSGANEmbModel(BaseModel):
         b_ip = None
         if o.lambda_IP > 0.0:
             with hip_ops.branch('IP') as b_ip:
+                b_ip.reads(self.real_A_IP, self.fake_B_IP)
                 with torch.no_grad():
                     feature_A = self.netIP(self.transform_IP(self.real_A_IP))
                 self.loss_G_IP = self.criterionIP(self.netIP(self.transform_IP(self.fake_B_IP)), feature_A) * o.lambda_IP
@@ -371,6 +369,7 @@ class WSGANEmbModel(BaseModel):
             d10 = o.bayesian and o.noisy and o.lr_E <= 0.0 and getattr(self, '_e_on_branch', False)
             b_e = hip_ops.branch('E', after=[] if d10 else None)
             b_e.__enter__()
+            b_e.reads(self.fake_B_E, self.real_A_E, self.y_B)
             try:
                 self._z_rec_loss()
             finally:

@@ -6,7 +6,7 @@ top = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 groups = collections.OrderedDict([
     ('residual convs (bsplit main)', r'bsplit_conv_fwd_kernel|bsplit_halo_kernel|hsplit_wgrad_kernel'), ('residual wgrad aux (pad / pack / reduce)', r'bsplit_(pad|pack_dy|wgrad_reduce)'),
     ('bsplit weight packs, absmax', r'bsplit_pack|absmax'), ('other MFMA convs fwd+dgrad (igemm2 / igemm)', r'igemm2?_kernel|hgemm_kernel'),
-    ('other MFMA wgrad (wgrad2 / wgrad + reduce)', r'::wgrad2?_kernel|::wgrad_reduce|\d\dwgrad2?_kernelI'), ('<=4-channel convs (smallm)', r'smallm'),
+    ('other MFMA wgrad (wgrad2 / wgrad + reduce)', r'::wgrad2?_kernel|::wgrad_reduce|\d\dwgrad2?_kernelI'), ('<=4-channel convs (smallm, thin_conv)', r'smallm|thin_conv|thin_pack'),
     ('split-K reduce / repack / fold', r'splitk|repack|reflect_fold|transpose4|pack_strip'), ('instance norm', r'instnorm|in_running'),
     ('batch norm / plane stats', r'bn_|norm_|plane_stats'), ('bias sums', r'sum_over_n|plane_sum'),
     ('pointwise / cast', r'act_|add_kernel|scale_kernel|concat_z|channel_scale'), ('pool / resize', r'pool|bilinear'),

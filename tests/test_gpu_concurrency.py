@@ -82,3 +82,41 @@ def test_kernels_are_bit_stable_beside_f16_mfma_kernels(dev):
         if bad:
             failures.append('%s: %d / 8 runs differ from the kernel running alone' % (name, bad))
     assert not failures, failures
+
+
+def test_cross_step_overlap_changes_nothing(tmp_path, dev, monkeypatch):
+    """Round 3's cross-step overlap (models/wsgan_emb_model.py: forward): the frozen encoder's passes over the new batch, the generator's
+    first pass (G1) and its second pass (G2) run on their own streams behind the events of their inputs, beside the previous step's
+    backward_D / Adam.  Same kernels in the same per-net order, so six optimize_parameters() at the benchmark's network sizes (bs 8,
+    resident batches as in bench.py) must end in the SAME BITS with the overlap on (twice: run-to-run) and with every stream switched
+    off: weights of G and D, the encoder's running statistics, the last losses and images."""
+    import bench
+    from pcgan_amd.hip import ops
+    from pcgan_amd.models import wsgan_emb_model as W
+
+    def run(overlap):
+        monkeypatch.setattr(W, '_E_AHEAD', overlap)
+        monkeypatch.setattr(W, '_G1_AHEAD', overlap)
+        monkeypatch.setattr(W, '_G2_BRANCH', overlap)
+        monkeypatch.setattr(ops, 'BRANCH_STREAMS', overlap)
+        torch.manual_seed(7)
+        d = tmp_path / ('o%d_%d' % (overlap, len(list(tmp_path.iterdir()))))
+        d.mkdir()
+        model, opt = bench.build_model(0, 8, 128, str(d))
+        batches = [bench.synthetic_batch(8, 128, 0, it) for it in range(2)]
+        batches = [{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()} for b in batches]
+        for i in range(6):
+            model.set_input(batches[i % 2])
+            model.optimize_parameters()
+        torch.cuda.synchronize()
+        out = {('G.' + k): v.detach().clone() for k, v in model.netG.state_dict().items()}
+        out.update({('D.' + k): v.detach().clone() for k, v in model.netD.state_dict().items()})
+        out.update({('E.' + k): v.detach().clone() for k, v in model.netE.state_dict().items() if 'running' in k or 'num_batches' in k})
+        out['fake_B'], out['rec_A'] = model.fake_B.detach().clone(), model.rec_A.detach().clone()
+        out.update({'loss_' + k: torch.tensor(v) for k, v in model.get_current_losses().items()})
+        return out
+
+    a, b, c = run(True), run(True), run(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), 'run-to-run difference with the overlap on: ' + k
+        assert torch.equal(a[k], c[k]), 'the overlap changed ' + k
