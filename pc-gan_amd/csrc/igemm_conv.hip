@@ -872,15 +872,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
     const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.X, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(P.A, (unsigned)a.M * (unsigned)Kp * 4u);
 
-    // operand scales: the largest of the partial maxima the producer of X left; the weights were scaled ROW BY ROW by the pack call
-    // (a.w_amax[m] = largest magnitude of row m), the epilogue divides each row by its own power of two
     float sx = 1.f;
-    if constexpr (!HALF) {
-        const float m = thread_max_of_partials(a.x_amax, a.x_namax, tid, 256);
-        sx = pow2_scale(block_max(m, biasS));
-        if (tid < BM) iswS[tid] = m0 + tid < a.M ? 1.f / pow2_scale(a.w_amax[m0 + tid]) : 1.f;
-        __syncthreads();
-    }
     // gather-offset table of this workgroup's BP pixels (as in igemm2_kernel)
     const int pl = tid % BP;
     {
@@ -897,7 +889,6 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
             const unsigned x = axis_entry<MODE>(px, px + a.pad, true, sxx, a.Wg, a.sl, a.pad);
             offT[t][pl] = (live && y != 0xffffffffu && x != 0xffffffffu) ? (vbase + y * (unsigned)a.Wg + x) * ES : OOB;
         }
-        if (tid < BM) biasS[tid] = (a.bias != nullptr && m0 + tid < a.M) ? a.bias[m0 + tid] : 0.f;
     }
     const int ksub = __builtin_amdgcn_readfirstlane(tid / BP);
     __syncthreads();
@@ -1055,11 +1046,23 @@ __global__ void __launch_bounds__(256) hgemm_kernel(IgemmArgs a) {
         }
     };
 
-    if (nst_here > 0) {
-        Stage rg[2];
-        Operands op[2];
+    Stage rg[2];
+    if (nst_here > 0) {      // the first two stages' global loads go out before the scale reduction below (their latency covers it)
         load(rg[0]);
         load(rg[1]);
+    }
+    // operand scales: the largest of the partial maxima the producer of X left; the weights were scaled ROW BY ROW by the pack call
+    // (a.w_amax[m] = largest magnitude of row m), the epilogue divides each row by its own power of two
+    if constexpr (!HALF) {
+        const float m = thread_max_of_partials(a.x_amax, a.x_namax, tid, 256);
+        sx = pow2_scale(block_max(m, biasS));
+        if (tid < BM) iswS[tid] = m0 + tid < a.M ? 1.f / pow2_scale(a.w_amax[m0 + tid]) : 1.f;
+        __syncthreads();      // (biasS was the reduction's scratch)
+    }
+    if (tid < BM) biasS[tid] = (a.bias != nullptr && m0 + tid < a.M) ? a.bias[m0 + tid] : 0.f;
+    if (nst_here == 0) __syncthreads();      // (with stages, the barriers below order biasS before the epilogue)
+    if (nst_here > 0) {
+        Operands op[2];
         stash(rg[0], 0);
         __syncthreads();
         load(rg[0]);
@@ -2403,9 +2406,13 @@ static inline bool cg4_k(int Cg, int M, int R, int S) {
 static inline long tile_blocks(int M, int ptot_max, int nphase, int mm, int pp) {
     return (long)((M + mm - 1) / mm) * ((ptot_max + pp - 1) / pp) * nphase;
 }
+static inline long split_below() {     // tiles (BP = 128) below which a long-K layer is cut along K; PCGAN_SPLIT_BELOW: experiments
+    static const long v = getenv("PCGAN_SPLIT_BELOW") ? atol(getenv("PCGAN_SPLIT_BELOW")) : 192;
+    return v;
+}
 static inline bool may_split(int M, int ptot_max, int nphase) {
     const int m = M > 64 ? 128 : (M > 32 ? 64 : 32);
-    return M > 4 && tile_blocks(M, ptot_max, nphase, m, 128) < 192;
+    return M > 4 && tile_blocks(M, ptot_max, nphase, m, 128) < split_below();
 }
 static void choose_tile(int M, int ptot_max, int nphase, int nst, bool allow_split, int* bm, int* bp, int* ks) {
     int m = M > 64 ? 128 : (M > 32 ? 64 : 32);
