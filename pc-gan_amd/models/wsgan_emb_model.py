@@ -34,6 +34,9 @@ _E_AHEAD = os.environ.get('PCGAN_E_AHEAD', '1') == '1'
 # optimizer_G.step() left them -- not the discriminator update still queued behind it.  (AlexNet's features of real_A moved ahead the
 # same way cost 1.8 ms per step: that pass is better placed where it is, beside the discriminator branch of backward_G.)
 _G1_AHEAD = os.environ.get('PCGAN_G1_AHEAD', '1') == '1'
+# the AlexNet identity term on its own stream beside the discriminator branch: round 2's default; with the cross-step overlap four
+# streams then crowd the same phase of backward_G and the step is 4.5 % SLOWER (1093 vs 1143 img/s, same box) -> off
+_IP_BRANCH = os.environ.get('PCGAN_IP_BRANCH', '0') == '1'
 
 MAGIC_EPS = 1e-20
 
@@ -344,7 +347,7 @@ class WSGANEmbModel(BaseModel):
         # the identity branch (AlexNet: no running statistics, order-free) runs beside the discriminator branch
         b_ip = None
         if o.lambda_IP > 0.0:
-            with hip_ops.branch('IP') as b_ip:
+            with hip_ops.branch('IP', enabled=_IP_BRANCH) as b_ip:
                 b_ip.reads(self.real_A_IP, self.fake_B_IP)
                 with torch.no_grad():
                     feature_A = self.netIP(self.transform_IP(self.real_A_IP))
