@@ -12,10 +12,13 @@ Workload (BASELINE.json configs[1]): 9-block ResnetGenerator + 3-layer PatchGAN 
 "pretrained" E/IP weights (no checkpoints ship offline).
 
 One JSON line on rank 0: value = whole-job images/s; `roofline` = the three kernels of the 256->256 3x3 residual
-convolution (forward, data gradient, weight gradient INCLUDING its padded-copy and reduce launches; 36 launches each per step;
+convolution (forward, data gradient, weight gradient INCLUDING its reduce launch; 36 launches each per step;
 fp32 contraction as two scaled fp16 pieces / three products on the f16 matrix pipe by default): every launch inside the timed
 region is bracketed by HIP events on its launch stream inside the library (pcgan_timer_*), the slowest of the three is the
-dominant kernel the top-level fields describe; `cpu_baseline` = the oracle's PyTorch-CPU step on this host's cores, bounded sample.
+dominant kernel the top-level fields describe.  The step runs on several streams (parameter gradients, branches of backward_G, the
+next step's encoder passes and first generator pass beside the previous step's backward_D), so an in-region duration is that of a
+kernel SHARING the GPU; `ms_per_launch_alone` / `frac_alone` are the same launches with those streams off (3 extra steps after the
+region).  `cpu_baseline` = the oracle's PyTorch-CPU step on this host's cores, bounded sample.
 `python bench.py --dtype bf16` is the same line for BASELINE configs[2] per GPU (bf16 activations).
 """
 import argparse
