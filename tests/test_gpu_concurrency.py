@@ -120,3 +120,41 @@ def test_cross_step_overlap_changes_nothing(tmp_path, dev, monkeypatch):
     for k in a:
         assert torch.equal(a[k], b[k]), 'run-to-run difference with the overlap on: ' + k
         assert torch.equal(a[k], c[k]), 'the overlap changed ' + k
+
+
+@pytest.mark.parametrize('act', ['fp32', 'bf16'])
+def test_to_act_uploads_on_its_own_stream_and_says_when_it_is_ready(dev, act):
+    """BaseModel.to_act (round 3): copies / casts of a batch run on the upload stream and the result carries its readiness event
+    (ops.ready_event), which is what lets the frozen encoder start on the new batch without queueing behind the main stream.  Same
+    values as the plain path; a resident tensor of the right type is passed through and gets an event the first time it is seen,
+    kept while its version is unchanged and renewed after an in-place write."""
+    import types
+    from pcgan_amd.hip import ops
+    from pcgan_amd.models.base_model import BaseModel
+    me = types.SimpleNamespace(device=dev, act_dtype=torch.bfloat16 if act == 'bf16' else torch.float32)
+    g = torch.Generator().manual_seed(3)
+    host = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
+    out = BaseModel.to_act(me, host)
+    assert out.is_cuda and out.dtype == me.act_dtype
+    ver, ev = out._pcgan_ready
+    assert ver == out._version and ops.ready_event(out) is ev
+    torch.cuda.current_stream().wait_event(ev)
+    want = host.to(dev)
+    if act == 'bf16':
+        want = ops.cast(want, torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    # resident input of the model's type: passed through, tagged once
+    res = host.to(dev).to(me.act_dtype)
+    same = BaseModel.to_act(me, res)
+    assert same is res
+    e1 = ops.ready_event(res)
+    assert ops.ready_event(res) is e1
+    res.add_(1.0)                      # an in-place write bumps the version: a new event
+    assert ops.ready_event(res) is not e1
+    # resident fp32 input under a bf16 model: cast on the upload stream, behind the input's own event
+    if act == 'bf16':
+        src = host.to(dev)
+        out2 = BaseModel.to_act(me, src)
+        torch.cuda.synchronize()
+        assert out2.dtype == torch.bfloat16 and torch.equal(out2, ops.cast(src, torch.bfloat16))
