@@ -450,10 +450,12 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
         bsplit = split and K % 128 == 0 and N * p.P * p.Q >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_supported(p.dref)
         if bsplit and f16 and lib.pcgan_conv2d_hsplit_supported(p.dref, _L.PASS_FWD):
             p.route, p.pack_pass = 'hsplit', PASS_FWD_HSPLIT
+        elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_FWD):
+            # (before the three-piece kernel below: fp32 tensors whose shape the window kernel does not take -- the encoder's 128-channel
+            # 28x28 layers -- were still on its six products per term, 0.062 ms against 0.047 for the same layer's data gradient)
+            p.route, p.pack_pass = 'hgemm', PASS_FWD_HGEMM
         elif bsplit:
             p.route, p.pack_pass = 'bsplit', PASS_FWD_BSPLIT
-        elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_FWD):
-            p.route, p.pack_pass = 'hgemm', PASS_FWD_HGEMM
         elif f16 and THIN and (THIN_MASK & (1 if stride == 1 else 2)) and lib.pcgan_conv2d_thin_supported(p.dref, _L.PASS_FWD):
             p.route, p.pack_pass = 'thin', PASS_FWD_THIN
         else:
