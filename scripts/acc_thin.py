@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pcgan_amd.hip import ops
 from oracle import ops_ref as R
 dev='cuda:0'

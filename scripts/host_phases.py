@@ -1,7 +1,7 @@
 """where the host spends a steady-state step (wall-clock per call, GPU running behind): set_input / forward / update_G / update_D.  A phase
 that takes about as long as the GPU needs for a step contains a host <-> device synchronisation (or the launch queue's back-pressure)."""
 import sys, time, tempfile, contextlib, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device('cuda', 0)
 with contextlib.redirect_stdout(sys.stderr):

@@ -1,7 +1,7 @@
 """the <= 4-channel convolutions alone (G stem, E conv1, D c0 forward; G head data gradient): thin_conv.hip on the f16 matrix pipe against
 igemm2_kernel<.., 4> on fp32 MFMA (PCGAN_THIN=0's route), HIP events, bs 32"""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pcgan_amd.hip import ops
 dev = 'cuda:0'
 LAYERS = [('G.stem 4->64 7x7 reflect @128', 32, 4, 128, 64, 7, 1, 3, 1, False),
