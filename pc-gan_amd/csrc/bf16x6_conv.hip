@@ -1036,11 +1036,18 @@ struct HWgradArgs {
     unsigned* ovf;         // non-finite sentinel (common.h), fp32 tensors only; may be null
     int reflect_inline;    // fp32, stride 1, 3x3, reflection padding 1: XP is the UNPADDED input (Hp = H, Wp = W) and the mirror is applied
                            // in the gather -- a per-stage row select and one register move at the two image edges -- instead of by a padded copy
+    int splits, nmt;       // splits of the pixel reduction; row tiles of BM output channels (K > 256: the PatchGAN's 512-channel layer)
+    int Qs, pad;           // GEN kernels: Q rounded up to a multiple of 16 (the stages of a row; dy beyond column Q enters as zero) and the
+                           // ZERO padding (0 or 1) applied inside the gather -- XP is the unpadded input (Hp = H, Wp = W), no padded copy
 };
 
 // NC = column tiles of 128 per workgroup (2 with the 256-row tile: the dy tile is loaded and split once for 256 columns)
-template <int BM, int STRIDE, typename TA, int NC>
+// GEN (fp32 tensors, zero padding <= 1): the padding is applied inside the gather (rows outside the image select an out-of-range
+// offset, the at most one column per side is zeroed in registers when the run is split) and the output width may be ragged (stages
+// of 16 columns per output row, the dy values beyond column Q masked to zero: the PatchGAN's 15 x 15 layer)
+template <int BM, int STRIDE, typename TA, int NC, int GEN = 0>
 __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
+    static_assert(!GEN || sizeof(TA) == 4, "the general form takes fp32 tensors");
     constexpr int NT = BM * 2;
     constexpr int CW = 128 * NC;                // columns per workgroup
     constexpr bool HALF = sizeof(TA) == 2;      // bf16 tensors: one piece, one product, no scaling
@@ -1061,7 +1068,8 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     // of one split -- which all read the same dy rows -- share one L2 (dispatch order put them on all eight: dy crossed the fabric 8x)
     const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
     if (wg >= a.nwg) return;
-    const int bx = wg % a.ntile, by = wg / a.ntile;
+    const int bx = wg % a.ntile, byz = wg / a.ntile;
+    const int by = byz % a.splits, m0 = (byz / a.splits) * BM;      // (the column tiles of one (row tile, split) pair are neighbours: same dy rows)
 
     float sx = 1.f, sdy = 1.f;
     if constexpr (!HALF) {
@@ -1080,14 +1088,29 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     constexpr int BT = 16 / KB;
     const int arow = HALF ? tid >> 1 : tid >> 2, aq = HALF ? (tid & 1) * 2 : tid & 3;
     const int ahalf = aq >> 1, asub = (aq & 1) * 4;
-    const unsigned avo = arow < a.K ? (unsigned)(arow * PQ + aq * 4) * ES : BS_OOB;
-    const unsigned avo1 = (!HALF && arow + AR < a.K) ? (unsigned)((arow + AR) * PQ + aq * 4) * ES : BS_OOB;
+    const unsigned avo = m0 + arow < a.K ? (unsigned)((m0 + arow) * PQ + aq * 4) * ES : BS_OOB;
+    const unsigned avo1 = (!HALF && m0 + arow + AR < a.K) ? (unsigned)((m0 + arow + AR) * PQ + aq * 4) * ES : BS_OOB;
     const int bcol = tid / BT, bq = tid % BT;
     const int col = bx * CW + bcol;
     unsigned bvo = BS_OOB;
     int tr = 1, fixl = 0, fixr = 0;      // inline reflection: this thread's tap row; whether its first / last element can fall on column -1 / W
+    int lm = 0, rmk = 0;                 // GEN: elements of the run that lie in the zero padding in the first / last stage of a row (bit j), bit 8 = rotate
     if (col < CT) {
         const int c = col / T, tap = col - c * T, r = tap / a.S, s = tap - r * a.S;
+        if constexpr (GEN) {
+            const int cs = bq * KB * STRIDE + s - a.pad;      // column of the run's first element in the row's first stage (-1 at most)
+            bvo = (unsigned)(((c * a.Hp + r) * a.Wp + cs) * (int)ES);      // (may wrap: its sum with the stage's part below does not)
+            tr = r;
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                lm |= (cs + j * STRIDE < 0) ? 1 << j : 0;
+                rmk |= ((a.Qs - 16) * STRIDE + cs + j * STRIDE >= a.Wp) ? 1 << j : 0;
+            }
+            // a run whose first element is column -1 is loaded one element late and rotated when it is split: in the first row of the
+            // tensor its offset would be "-4", which does not wrap in the hardware's range check (every later element of the run,
+            // reached through the instruction's immediate offset, would read as 0 too)
+            if (cs < 0) lm |= 256;
+        } else
         if (a.reflect_inline) {      // row term chosen per stage (ro0 / ro1 / ro2 below); a left-edge lane's run starts at column -1
             bvo = (unsigned)((c * a.Hp) * a.Wp + s - 1 + bq * KB) * ES;      // (may be "-4": the per-stage sum below is not)
             tr = r;
@@ -1105,16 +1128,19 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     // position of the next stage to LOAD (scalar): image, output row, first output column
     int ln, ly, lx;
     {
+        const int Qrow = GEN ? a.Qs : a.Q;      // stage positions count the (padded) row width
         const int e0 = st0 * 16;
-        ln = e0 / PQ;
-        const int rem = e0 - ln * PQ;
-        ly = rem / a.Q;
-        lx = rem - ly * a.Q;
+        ln = e0 / (a.P * Qrow);
+        const int rem = e0 - ln * (a.P * Qrow);
+        ly = rem / Qrow;
+        lx = rem - ly * Qrow;
     }
     struct Stage {
         unsigned a[HALF ? 4 : 8];     // 8 consecutive dy values of this thread's row (bf16: packed pairs)
         unsigned b[KB];               // KB consecutive output pixels of this thread's column
         int fix;                      // inline reflection: 1 = the run starts at column -1, loaded from column 0 instead (rotate), 2 = the last is column W
+                                      // GEN: bit j = element j of the run lies in the zero padding, bit 8 = the run was loaded from column 0 (rotate)
+        int am;                       // GEN: how many of this thread's 4 consecutive dy values lie inside the row (>= 4: all)
     };
     int lcount = 0;
 #ifndef WG_ABL
@@ -1126,6 +1152,15 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
         unsigned bso = (unsigned)(((ln * a.C) * a.Hp + ly * STRIDE) * a.Wp + lx * STRIDE) * ES;
         unsigned bvt = bvo;
         r.fix = 0;
+        r.am = 4;
+        if constexpr (GEN) {
+            const int yy = ly * STRIDE - a.pad;      // source row of tap row 0 (scalar)
+            const bool rowok = (unsigned)(yy + tr) < (unsigned)a.Hp;
+            r.fix = (lx == 0 ? lm : 0) | (lx == a.Qs - 16 ? rmk : 0);
+            bvt = rowok ? bvo + (unsigned)((((ln * a.C) * a.Hp + yy) * a.Wp + lx * STRIDE) * (int)ES) + ((r.fix & 256) ? STRIDE * ES : 0u) : BS_OOB;
+            bso = 0;
+            r.am = a.Q - lx - aq * 4;
+        } else
         if constexpr (!HALF && STRIDE == 1) {
             if (a.reflect_inline) {      // source row of tap row tr under reflection padding 1 (scalars per stage), selected by the lane's tap row
                 const int y0 = ly == 0 ? 1 : ly - 1, y2 = ly == a.Hp - 1 ? a.Hp - 2 : ly + 1;
@@ -1162,7 +1197,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
         }
         ++lcount;
         lx += 16;
-        if (lx == a.Q) {
+        if (lx == (GEN ? a.Qs : a.Q)) {
             lx = 0;
             if (++ly == a.P) {
                 ly = 0;
@@ -1185,16 +1220,23 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 _Float16 x, y;
-                split2h(__uint_as_float(r.a[(i * 4 + j) % (HALF ? 4 : 8)]) * sdy, x, y);
+                unsigned aj = r.a[(i * 4 + j) % (HALF ? 4 : 8)];
+                if constexpr (GEN) aj = j < r.am ? aj : 0u;                // dy beyond the row's last column
+                split2h(__uint_as_float(aj) * sdy, x, y);
                 q.ah[i][j] = x;
                 q.al[i][j] = y;
             }
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             unsigned bj = r.b[j];
+            if constexpr (GEN) {
+                bj = (r.fix & 256) ? (j == 0 ? 0u : r.b[j == 0 ? 0 : j - 1]) : bj;      // run loaded one element late
+                bj = (r.fix >> j & 1) ? 0u : bj;                            // zero padding
+            } else {
             if (j == 0) bj = r.fix == 1 ? r.b[1] : bj;                     // run loaded from column 0: wanted (col 1, col 0, col 1, col 2, ...)
             else bj = r.fix == 1 ? r.b[j - 1] : bj;
             if (j == KB - 1) bj = r.fix == 2 ? r.b[KB - 3] : bj;           // column W mirrors to column W - 2
+            }
             _Float16 x, y;
             split2h(__uint_as_float(bj) * sx, x, y);
             q.bh[j] = x;
@@ -1389,7 +1431,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+                const int m = m0 + wm * 64 + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
                 const float v = (acc[i][j][r] * isx) * isd;
                 if (m < a.K) {
                     out[(size_t)m * CT] = v;
@@ -1792,11 +1834,29 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit_add(const pcgan_conv_desc* d, const 
 
 // weight gradient on the fp16 route (fp32 tensors) / bf16 route (bf16 tensors): padded copy of x (workspace), the kernel above over
 // splits of the pixel reduction, reduce
+// the general form of the kernel (GEN): fp32 tensors, zero padding of at most 1 applied inside the gather (no padded copy), ragged output
+// width.  PCGAN_WGRAD_GEN=0 keeps the padded copy (A/B measurement; the ragged widths and K > 256 then leave this route)
+static bool hsplit_wgrad_gen(const pcgan_conv_desc* d) {
+    static const bool on = [] { const char* e = getenv("PCGAN_WGRAD_GEN"); return !(e && e[0] == '0'); }();
+    return on && d->dtype == PCGAN_F32 && d->pad_mode == 0 && d->pad <= 1;
+}
+
+extern "C" int pcgan_conv2d_hsplit_wgrad_inline(const pcgan_conv_desc* d) {
+    if (!d || !pcgan_conv2d_hsplit_wgrad_supported(d)) return 0;
+    const bool inline_reflect = d->dtype == PCGAN_F32 && d->stride == 1 && d->pad_mode == 1 && d->pad == 1 && d->R == 3 && d->S == 3 && d->H >= 2 &&
+                                d->W >= 16 && d->P == d->H && d->Q == d->W && getenv("PCGAN_WGRAD_PADCOPY") == nullptr;
+    return (inline_reflect || d->pad == 0 || hsplit_wgrad_gen(d)) ? 1 : 0;
+}
+
 extern "C" int pcgan_conv2d_hsplit_wgrad_supported(const pcgan_conv_desc* d) {
     if (!d || (d->dtype != PCGAN_F32 && d->dtype != PCGAN_BF16)) return 0;
     if (d->stride != 1 && d->stride != 2) return 0;
     if (d->pad_mode == 1 && (d->stride != 1 || d->pad >= d->H || d->pad >= d->W)) return 0;
-    if (d->K > 256 || d->K < 32 || d->R * d->S > 49 || d->Q % 16 != 0 || d->P < 1) return 0;
+    if (d->K < 32 || d->R * d->S > 49 || d->P < 1 || d->Q < 1) return 0;
+    const bool gen = hsplit_wgrad_gen(d);
+    const int Qs = (d->Q + 15) & ~15;
+    if (!gen && (d->Q % 16 != 0 || d->K > 256)) return 0;
+    if ((Qs - d->Q) * 4 > Qs) return 0;           // ragged rows: at least three quarters of every 16-column stage are real columns
     if (d->P != (d->H + 2 * d->pad - d->R) / d->stride + 1 || d->Q != (d->W + 2 * d->pad - d->S) / d->stride + 1) return 0;
     // the gather reads xpad rows up to (P-1) stride + R - 1 and columns up to (Q-1) stride + S - 1: inside the padded plane by the two lines above
     return (size_t)d->N * d->C * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * 4 < 0x80000000ull && (size_t)d->N * d->K * d->P * d->Q * 4 < 0x80000000ull &&
@@ -1812,9 +1872,9 @@ static inline int hsplit_wgrad_cw(const pcgan_conv_desc* d) {
 }
 
 static inline int hsplit_wgrad_splits(const pcgan_conv_desc* d, int* nst_split) {
-    const int nst = d->N * d->P * d->Q / 16;
+    const int nst = d->N * d->P * ((d->Q + 15) / 16);
     const int cw = hsplit_wgrad_cw(d);
-    const long tiles = (d->C * d->R * d->S + cw - 1) / cw;
+    const long tiles = (long)((d->C * d->R * d->S + cw - 1) / cw) * ((d->K + 255) / 256);      // column tiles x row tiles
     long want = (hsplit_wgrad_bm(d) == 256 ? 256 : 512) / tiles;          // one round of resident workgroups
     if (want < 1) want = 1;
     if (want > nst / 8) want = nst / 8 > 0 ? nst / 8 : 1;
@@ -1826,7 +1886,8 @@ extern "C" size_t pcgan_conv2d_hsplit_wgrad_workspace_bytes(const pcgan_conv_des
     if (!pcgan_conv2d_hsplit_wgrad_supported(d)) return 0;
     int per;
     const int splits = hsplit_wgrad_splits(d, &per);
-    return pcgan::align_up((size_t)d->N * d->C * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * 4, 256) + (size_t)splits * d->K * d->C * d->R * d->S * 4;
+    const size_t xpad = hsplit_wgrad_gen(d) ? 0 : pcgan::align_up((size_t)d->N * d->C * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * 4, 256);
+    return xpad + (size_t)splits * d->K * d->C * d->R * d->S * 4;
 }
 
 extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_xamax, const void* dy,
@@ -1843,7 +1904,8 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     const int splits = hsplit_wgrad_splits(d, &per);
     const int Hp = d->H + 2 * d->pad, Wp = d->W + 2 * d->pad;
     const size_t es = half ? 2 : 4;
-    const size_t xpad_bytes = pcgan::align_up((size_t)d->N * d->C * Hp * Wp * 4, 256);
+    const bool gen = hsplit_wgrad_gen(d);
+    const size_t xpad_bytes = gen ? 0 : pcgan::align_up((size_t)d->N * d->C * Hp * Wp * 4, 256);
     void* xpad = ws;
     float* part = (float*)((char*)ws + xpad_bytes);
     const void* xin = x;
@@ -1851,7 +1913,7 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     const bool inline_reflect = !half && d->stride == 1 && d->pad_mode == 1 && d->pad == 1 && d->R == 3 && d->S == 3 && d->H >= 2 && d->W >= 16 &&
                                 d->P == d->H && d->Q == d->W && getenv("PCGAN_WGRAD_PADCOPY") == nullptr;
     int Hx = Hp, Wx = Wp;
-    if (inline_reflect) {
+    if (inline_reflect || gen) {
         Hx = d->H;
         Wx = d->W;
     } else if (d->pad > 0) {
@@ -1863,7 +1925,11 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     a.XP = xin; a.DY = dy; a.part = part;
     a.N = d->N; a.C = d->C; a.K = d->K; a.P = d->P; a.Q = d->Q; a.Hp = Hx; a.Wp = Wx; a.R = d->R; a.S = d->S;
     a.reflect_inline = inline_reflect ? 1 : 0;
-    a.nst = d->N * d->P * d->Q / 16;
+    a.Qs = (d->Q + 15) & ~15;
+    a.pad = d->pad;
+    a.splits = splits;
+    a.nmt = (d->K + 255) / 256;
+    a.nst = d->N * d->P * (a.Qs / 16);
     a.nst_split = per;
     a.xp_bytes = (unsigned)((size_t)d->N * d->C * Hx * Wx * es);
     a.dy_bytes = (unsigned)((size_t)d->N * d->K * d->P * d->Q * es);
@@ -1871,13 +1937,20 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     a.ovf = half ? nullptr : pcgan::nonfinite_counter();
     const int cw = hsplit_wgrad_cw(d);
     a.ntile = (d->C * d->R * d->S + cw - 1) / cw;
-    a.nwg = a.ntile * splits;
+    a.nwg = a.ntile * splits * a.nmt;
     const dim3 grid((unsigned)((a.nwg + 7) & ~7));
     const int bm = hsplit_wgrad_bm(d);
+#define LWG(BMV, SV) hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, float, 1, 1>), grid, dim3(BMV * 2), 0, st, a)
 #define LWH(BMV, SV, NCV) do { if (half) hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, pcgan::bf16, NCV>), grid, dim3(BMV * 2), 0, st, a); \
                                else hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, float, NCV>), grid, dim3(BMV * 2), 0, st, a); } while (0)
     {
     pcgan::TimerScope timer_main(res_like ? pcgan::TIMER_RES_WGRAD_MAIN : -1, st);
+    if (gen) {
+        if (bm == 256 && d->stride == 1) LWG(256, 1);
+        else if (bm == 256) LWG(256, 2);
+        else if (d->stride == 1) LWG(128, 1);
+        else LWG(128, 2);
+    } else
     if (bm == 256 && cw == 256 && d->stride == 1) LWH(256, 1, 2);
     else if (bm == 256 && cw == 256) LWH(256, 2, 2);
     else if (bm == 256 && d->stride == 1) LWH(256, 1, 1);
@@ -1886,6 +1959,7 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     else LWH(128, 2, 1);
     }
 #undef LWH
+#undef LWG
     PCGAN_LAUNCH_CHECK();
     const size_t total = (size_t)d->K * d->C * d->R * d->S;
     hipLaunchKernelGGL(pcgan::bsplit_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, dw, splits, total, accumulate);

@@ -126,6 +126,7 @@ SIGNATURES = {
     'pcgan_conv2d_fwd_thin': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp]),
     'pcgan_conv2d_bwd_data_thin': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     'pcgan_conv2d_hsplit_wgrad_supported': (_i, [_dp]),
+    'pcgan_conv2d_hsplit_wgrad_inline': (_i, [_dp]),
     'pcgan_conv2d_hsplit_wgrad_workspace_bytes': (_sz, [_dp]),
     'pcgan_conv2d_bwd_weight_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     'pcgan_image_transform_band': (_i, [_ip, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),

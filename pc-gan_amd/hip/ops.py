@@ -290,6 +290,7 @@ HGEMM = os.environ.get('PCGAN_HGEMM', '1') == '1'
 # ... and the convolutions that gather <= 4 channels the window kernel of csrc/thin_conv.hip instead of igemm2_kernel<.., 4> on fp32 MFMA
 THIN = os.environ.get('PCGAN_THIN', '1') == '1'
 THIN_WGRAD = os.environ.get('PCGAN_THIN_WGRAD', '1') == '1'     # weight gradients of the 3- / 4-channel layers on the matrix-pipe kernel too
+WGRAD_INLINE_BIG = os.environ.get('PCGAN_WGRAD_INLINE_BIG', '1') != '0'
 THIN_MASK = int(os.environ.get('PCGAN_THIN_MASK', '7'))     # debugging: 1 = stride-1 forward, 2 = stride-2 forward, 4 = data gradient
 
 
@@ -485,7 +486,10 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
         # (3- / 4-channel inputs: only the generator's 7x7 stride-1 stem gains, 0.266 -> 0.215 ms; the PatchGAN's first layer and the
         # encoder's strided stem are faster on the fp32-MFMA kernels, scripts/time_thin.py)
         thin_stem = C <= 4 and THIN_WGRAD and R == 7 and S == 7 and stride == 1
-        cheap_pad = (C % 16 == 0 or thin_stem) and N * C * H * W * 4 <= 80 * 1000 * 1000
+        # (fp32 tensors with zero padding <= 1 need no padded copy at all -- the padding is applied inside the gather: those go there
+        # whatever their size, PCGAN_WGRAD_INLINE_BIG=0 keeps the 80 MB limit for an A/B measurement)
+        no_copy = WGRAD_INLINE_BIG and bool(lib.pcgan_conv2d_hsplit_wgrad_inline(p.dref))
+        cheap_pad = (C % 16 == 0 or thin_stem) and (no_copy or N * C * H * W * 4 <= 80 * 1000 * 1000)
         if (HSPLIT and BF16X6 and lib.pcgan_conv2d_hsplit_wgrad_supported(p.dref)
                 and (px >= BSPLIT_MIN_PIXELS if (res_like or not HGEMM) else px >= min(BSPLIT_MIN_PIXELS, 4096))
                 and (res_like or (HGEMM and cheap_pad))):

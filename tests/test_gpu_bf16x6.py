@@ -348,6 +348,60 @@ def test_hsplit_weight_gradient_general(dev, N, C, H, W, K, k, stride, pad, mode
     assert torch.equal(dw2, dw) or float((dw2.double().cpu() - ref).norm() / ref.norm()) < 3e-6
 
 
+@pytest.mark.parametrize('N,C,H,W,K,k,stride,pad', [
+    (2, 256, 16, 16, 512, 4, 1, 1),      # the PatchGAN's 256 -> 512 layer (networks.py:753-775): two row tiles, output 15 x 15 (one ragged stage per row)
+    (3, 32, 16, 16, 320, 4, 1, 1),       # a ragged second row tile (320 = 256 + 64)
+    (2, 64, 26, 28, 64, 3, 1, 1),        # output width 28: two stages per row, the second ragged
+    (1, 16, 9, 30, 32, 3, 2, 1),         # stride 2, output 5 x 15
+    (2, 32, 14, 14, 64, 3, 1, 1),        # output width 14
+    (2, 48, 15, 30, 96, 4, 2, 1),        # 4x4 stride 2, output 7 x 15: the last tap column falls on column W (zeroed in registers)
+    (4, 64, 128, 128, 128, 3, 2, 1),     # the generator's first down-sampling layer at full size (no padded copy of the 134 MB input)
+])
+def test_hsplit_weight_gradient_inline_zero_padding(dev, N, C, H, W, K, k, stride, pad):
+    """the general form of the matrix-pipe weight gradient (fp32 tensors, zero padding applied inside the gather, ragged output width,
+    more than 256 output channels) against autograd in float64 and against the same call with the padded copy where that form exists"""
+    from pcgan_amd.hip import lib as L, ops
+    g = torch.Generator().manual_seed(N * 100 + C + K + k + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    P, Q = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = torch.randn(N, K, P, Q, generator=g) * 0.01
+    w = torch.zeros(K, C, k, k, dtype=torch.float64, requires_grad=True)
+    R.conv2d(x.double(), w, None, stride, pad, 0).backward(dy.double())
+    ref = w.grad
+    d = ops.make_desc(N, C, H, W, K, k, k, stride, pad, 0)
+    lib = L.load()
+    assert lib.pcgan_conv2d_hsplit_wgrad_supported(ctypes.byref(d)) and lib.pcgan_conv2d_hsplit_wgrad_inline(ctypes.byref(d))
+    xd, dyd = x.to(dev), dy.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(ctypes.byref(d))
+    assert nbytes % (K * C * k * k * 4) == 0 and nbytes // (K * C * k * k * 4) >= 1      # whole partial sums only: no room for a padded copy
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dw = torch.full((K, C, k, k), float('nan'), device=dev)
+    xmax, dmax = ops.amax_of(xd), ops.amax_of(dyd)
+    L.check(lib.pcgan_conv2d_bwd_weight_hsplit(ctypes.byref(d), xd.data_ptr(), xmax.data_ptr(), xmax.numel(), dyd.data_ptr(), dmax.data_ptr(),
+                                               dmax.numel(), dw.data_ptr(), 0, ws.data_ptr(), ws.numel(), st), 'wgrad')
+    old, ops.HSPLIT = ops.HSPLIT, False
+    try:
+        dw32 = ops.conv2d_bwd_weight(xd, dyd, (K, C, k, k), stride, pad, 0)      # the fp32-MFMA kernel
+    finally:
+        ops.HSPLIT = old
+    torch.cuda.synchronize()
+    e = lambda t: float((t.double().cpu() - ref).norm() / ref.norm())
+    assert e(dw) < 3e-6 and e(dw) < 4 * e(dw32) + 5e-7, (e(dw), e(dw32))
+    # every tap separately (a wrong border column or row shows in the border taps only)
+    per_tap = ((dw.double().cpu() - ref) ** 2).sum(dim=(0, 1)).sqrt() / (ref ** 2).sum(dim=(0, 1)).sqrt()
+    assert float(per_tap.max()) < 1e-5, per_tap
+    # the host routes these shapes there
+    old = ops.BSPLIT_MIN_PIXELS
+    ops.BSPLIT_MIN_PIXELS = 0
+    try:
+        assert ops._plan(L.PASS_BWD_WEIGHT, N, C, H, W, K, k, k, stride, pad, 0, L.F32).route == 'hsplit'
+        dw2 = ops.conv2d_bwd_weight(xd, dyd, (K, C, k, k), stride, pad, 0)
+    finally:
+        ops.BSPLIT_MIN_PIXELS = old
+    assert torch.equal(dw2, dw)
+
+
 @pytest.mark.allow_nonfinite
 def test_stale_operand_maximum_is_caught_loudly(dev, monkeypatch):
     """The fp16 route trusts `tensor._pcgan_amax` on the tensor VERSION.  A write through `.data` (or a raw-pointer kernel) after a
