@@ -492,7 +492,10 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
         cheap_pad = (C % 16 == 0 or thin_stem) and (no_copy or N * C * H * W * 4 <= 80 * 1000 * 1000)
         if (HSPLIT and BF16X6 and lib.pcgan_conv2d_hsplit_wgrad_supported(p.dref)
                 and (px >= BSPLIT_MIN_PIXELS if (res_like or not HGEMM) else px >= min(BSPLIT_MIN_PIXELS, 4096))
-                and (res_like or (HGEMM and cheap_pad))):
+                and (res_like or (HGEMM and cheap_pad))
+                # (a ragged output width under a half-empty 128-row tile loses to the fp32 kernel: ResNet-18 layer1, 64 -> 64 at
+                # 56 x 56, 0.092 vs 0.076 ms)
+                and (K >= 128 or p.Q % 16 == 0)):
             p.route, p.ws_bytes = 'hsplit', int(lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(p.dref))
         elif split and K in (128, 256) and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_wgrad_supported(p.dref):
             p.route, p.ws_bytes = 'bsplit', int(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(p.dref))
