@@ -348,7 +348,8 @@ def test_batch_norm_train(shape, act, slope, res, dev):
 
 
 @pytest.mark.parametrize('shape,k,stride,pad', [((2, 4, 16, 16), 3, 2, 1), ((2, 3, 55, 55), 3, 2, 0),
-                                               ((1, 2, 13, 13), 3, 2, 0), ((2, 3, 112, 112), 3, 2, 1)])
+                                               ((1, 2, 13, 13), 3, 2, 0), ((2, 3, 112, 112), 3, 2, 1),
+                                               ((2, 3, 20, 70), 3, 1, 1), ((1, 2, 17, 33), 2, 3, 0)])      # (strides other than 2: the runtime-stride form)
 def test_maxpool(shape, k, stride, pad, dev):
     from pcgan_amd.hip import ops
     g = torch.Generator().manual_seed(6)
