@@ -1863,7 +1863,10 @@ extern "C" int pcgan_conv2d_hsplit_wgrad_supported(const pcgan_conv_desc* d) {
            d->N * d->C <= 65535;
 }
 
-static inline int hsplit_wgrad_bm(const pcgan_conv_desc* d) { return d->K > 128 ? 256 : 128; }
+static inline int hsplit_wgrad_bm(const pcgan_conv_desc* d) {
+    static const int force = [] { const char* e = getenv("PCGAN_WGRAD_BM"); return e ? atoi(e) : 0; }();      // experiments: 128
+    return (d->K > 128 && force != 128) ? 256 : 128;
+}
 
 // 256 columns per workgroup: bf16 tensors with the 256-row tile when that still leaves at least 8 column tiles (26.5 -> 26.0 ms per
 // bf16 step).  The fp16 two-piece form needs 256 VGPRs there and spills: 0.166 -> 0.177 ms per launch, so it keeps 128 columns.
@@ -1874,7 +1877,8 @@ static inline int hsplit_wgrad_cw(const pcgan_conv_desc* d) {
 static inline int hsplit_wgrad_splits(const pcgan_conv_desc* d, int* nst_split) {
     const int nst = d->N * d->P * ((d->Q + 15) / 16);
     const int cw = hsplit_wgrad_cw(d);
-    const long tiles = (long)((d->C * d->R * d->S + cw - 1) / cw) * ((d->K + 255) / 256);      // column tiles x row tiles
+    const int bmr = hsplit_wgrad_bm(d);
+    const long tiles = (long)((d->C * d->R * d->S + cw - 1) / cw) * ((d->K + bmr - 1) / bmr);      // column tiles x row tiles
     long want = (hsplit_wgrad_bm(d) == 256 ? 256 : 512) / tiles;          // one round of resident workgroups
     if (want < 1) want = 1;
     if (want > nst / 8) want = nst / 8 > 0 ? nst / 8 : 1;
@@ -1928,7 +1932,7 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     a.Qs = (d->Q + 15) & ~15;
     a.pad = d->pad;
     a.splits = splits;
-    a.nmt = (d->K + 255) / 256;
+    a.nmt = (d->K + hsplit_wgrad_bm(d) - 1) / hsplit_wgrad_bm(d);
     a.nst = d->N * d->P * (a.Qs / 16);
     a.nst_split = per;
     a.xp_bytes = (unsigned)((size_t)d->N * d->C * Hx * Wx * es);
