@@ -1042,12 +1042,11 @@ struct HWgradArgs {
 };
 
 // NC = column tiles of 128 per workgroup (2 with the 256-row tile: the dy tile is loaded and split once for 256 columns)
-// GEN (fp32 tensors, zero padding <= 1): the padding is applied inside the gather (rows outside the image select an out-of-range
+// GEN (zero padding <= 1; bf16 tensors: output width a multiple of 16): the padding is applied inside the gather (rows outside the image select an out-of-range
 // offset, the at most one column per side is zeroed in registers when the run is split) and the output width may be ragged (stages
 // of 16 columns per output row, the dy values beyond column Q masked to zero: the PatchGAN's 15 x 15 layer)
 template <int BM, int STRIDE, typename TA, int NC, int GEN = 0>
 __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
-    static_assert(!GEN || sizeof(TA) == 4, "the general form takes fp32 tensors");
     constexpr int NT = BM * 2;
     constexpr int CW = 128 * NC;                // columns per workgroup
     constexpr bool HALF = sizeof(TA) == 2;      // bf16 tensors: one piece, one product, no scaling
@@ -1273,7 +1272,14 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
             typedef unsigned short usK __attribute__((ext_vector_type(KB)));
             usK w;
 #pragma unroll
-            for (int j = 0; j < KB; ++j) w[j] = (unsigned short)r.b[j];
+            for (int j = 0; j < KB; ++j) {
+                unsigned bj = r.b[j];
+                if constexpr (GEN) {
+                    bj = (r.fix & 256) ? (j == 0 ? 0u : r.b[j == 0 ? 0 : j - 1]) : bj;      // run loaded one element late
+                    bj = (r.fix >> j & 1) ? 0u : bj;                                         // zero padding
+                }
+                w[j] = (unsigned short)bj;
+            }
             *reinterpret_cast<usK*>(reinterpret_cast<unsigned short*>(&Bs[buf][0][bhalf * BH + bcol]) + bsub) = w;
         }
     };
@@ -1838,7 +1844,9 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit_add(const pcgan_conv_desc* d, const 
 // width.  PCGAN_WGRAD_GEN=0 keeps the padded copy (A/B measurement; the ragged widths and K > 256 then leave this route)
 static bool hsplit_wgrad_gen(const pcgan_conv_desc* d) {
     static const bool on = [] { const char* e = getenv("PCGAN_WGRAD_GEN"); return !(e && e[0] == '0'); }();
-    return on && d->dtype == PCGAN_F32 && d->pad_mode == 0 && d->pad <= 1;
+    if (!on || d->pad_mode != 0 || d->pad > 1) return false;
+    // bf16 tensors: the 16-byte loads of dy need rows of whole stages (a ragged row would start on a 2-byte boundary)
+    return d->dtype == PCGAN_F32 || (d->dtype == PCGAN_BF16 && d->Q % 16 == 0 && d->K <= 256);
 }
 
 extern "C" int pcgan_conv2d_hsplit_wgrad_inline(const pcgan_conv_desc* d) {
@@ -1944,7 +1952,9 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     a.nwg = a.ntile * splits * a.nmt;
     const dim3 grid((unsigned)((a.nwg + 7) & ~7));
     const int bm = hsplit_wgrad_bm(d);
-#define LWG(BMV, SV) hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, float, 1, 1>), grid, dim3(BMV * 2), 0, st, a)
+#define LWG(BMV, SV) do { if (half) { if (cw == 256) hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<256, SV, pcgan::bf16, 2, 1>), grid, dim3(512), 0, st, a); \
+                                      else hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, pcgan::bf16, 1, 1>), grid, dim3(BMV * 2), 0, st, a); } \
+                           else hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, float, 1, 1>), grid, dim3(BMV * 2), 0, st, a); } while (0)
 #define LWH(BMV, SV, NCV) do { if (half) hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, pcgan::bf16, NCV>), grid, dim3(BMV * 2), 0, st, a); \
                                else hipLaunchKernelGGL((pcgan::hsplit_wgrad_kernel<BMV, SV, float, NCV>), grid, dim3(BMV * 2), 0, st, a); } while (0)
     {

@@ -10,61 +10,61 @@
 
 namespace pcgan {
 
-// thread = (output column, output row) of a 64 x 4 tile, blockIdx.z = plane: no division per element (the flat-index form spent its
-// time in `me / Q`: the encoder's 64 x 112 x 112 pooling took 59 us forward and 169 us backward for 154 MB of traffic); STRIDE = 2
-// (every pooling of ResNet-18 / AlexNet) makes the window arithmetic shifts, 0 = the runtime value
-template <typename T, int STRIDE>
-__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int32_t* __restrict__ arg,
-                                                          int H, int W, int k, int stride_rt, int pad, int P, int Q) {
-    const int stride = STRIDE ? STRIDE : stride_rt;
-    const size_t nc = blockIdx.z;
-    const int q = blockIdx.x * 64 + (threadIdx.x & 63), p = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (q >= Q || p >= P) return;
-    const size_t i = nc * (size_t)P * Q + p * Q + q;
-    const T* xp = x + nc * (size_t)H * W;
-    const int y0 = p * stride - pad, x0 = q * stride - pad;
-    float best = -FLT_MAX;
-    int bi = -1;
-    for (int r = 0; r < k; ++r) {
-        const int iy = y0 + r;
-        if (iy < 0 || iy >= H) continue;
-        for (int s = 0; s < k; ++s) {
-            const int ix = x0 + s;
-            if (ix < 0 || ix >= W) continue;
-            const float v = ld1(xp + iy * W + ix);
-            if (bi < 0 || v > best || v != v) {  // first maximum in scan order; NaN propagates
-                best = v;
-                bi = iy * W + ix;
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int32_t* __restrict__ arg,
+                                   int H, int W, int k, int stride, int pad, int P, int Q, size_t total) {
+    const size_t nc = blockIdx.y;   // plane; blockIdx.x = chunk of the output plane (32-bit index math)
+    for (int me = blockIdx.x * blockDim.x + threadIdx.x; me < P * Q; me += gridDim.x * blockDim.x) {
+        const int p = me / Q;
+        const int q = me - p * Q;
+        const size_t i = nc * (size_t)P * Q + me;
+        const T* xp = x + nc * (size_t)H * W;
+        const int y0 = p * stride - pad, x0 = q * stride - pad;
+        float best = -FLT_MAX;
+        int bi = -1;
+        for (int r = 0; r < k; ++r) {
+            const int iy = y0 + r;
+            if (iy < 0 || iy >= H) continue;
+            for (int s = 0; s < k; ++s) {
+                const int ix = x0 + s;
+                if (ix < 0 || ix >= W) continue;
+                const float v = ld1(xp + iy * W + ix);
+                if (bi < 0 || v > best || v != v) {  // first maximum in scan order; NaN propagates
+                    best = v;
+                    bi = iy * W + ix;
+                }
             }
         }
+        st1(y + i, best);        // (a stored bf16 value is exact again in bf16: max of stored values)
+        arg[i] = bi;
     }
-    st1(y + i, best);        // (a stored bf16 value is exact again in bf16: max of stored values)
-    arg[i] = bi;
 }
 
-template <typename T, int STRIDE>
-__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ arg, T* __restrict__ dx,
-                                                          int H, int W, int k, int stride_rt, int pad, int P, int Q) {
-    const int stride = STRIDE ? STRIDE : stride_rt;
-    const size_t nc = blockIdx.z;
-    const int ix = blockIdx.x * 64 + (threadIdx.x & 63), iy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ix >= W || iy >= H) return;
-    const int me = iy * W + ix;
-    // output rows p with p*stride - pad <= iy <= p*stride - pad + k - 1
-    int p_lo = (iy + pad - k + 1 + stride - 1);
-    p_lo = p_lo <= 0 ? 0 : p_lo / stride;
-    int p_hi = (iy + pad) / stride;
-    if (p_hi > P - 1) p_hi = P - 1;
-    int q_lo = (ix + pad - k + 1 + stride - 1);
-    q_lo = q_lo <= 0 ? 0 : q_lo / stride;
-    int q_hi = (ix + pad) / stride;
-    if (q_hi > Q - 1) q_hi = Q - 1;
-    float acc = 0.f;
-    const size_t ob = nc * (size_t)P * Q;
-    for (int p = p_lo; p <= p_hi; ++p)
-        for (int q = q_lo; q <= q_hi; ++q)
-            if (arg[ob + p * Q + q] == me) acc += ld1(dy + ob + p * Q + q);
-    st1(dx + nc * (size_t)H * W + me, acc);
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ arg, T* __restrict__ dx,
+                                   int H, int W, int k, int stride, int pad, int P, int Q, size_t total) {
+    // blockIdx.y = plane, blockIdx.x = 256-element chunk of the plane: no 64-bit divisions per element
+    const size_t nc = blockIdx.y;
+    for (int me = blockIdx.x * blockDim.x + threadIdx.x; me < H * W; me += gridDim.x * blockDim.x) {
+        const int iy = me / W;
+        const int ix = me - iy * W;
+        const size_t i = nc * (size_t)H * W + me;
+        // output rows p with p*stride - pad <= iy <= p*stride - pad + k - 1
+        int p_lo = (iy + pad - k + 1 + stride - 1);
+        p_lo = p_lo <= 0 ? 0 : p_lo / stride;
+        int p_hi = (iy + pad) / stride;
+        if (p_hi > P - 1) p_hi = P - 1;
+        int q_lo = (ix + pad - k + 1 + stride - 1);
+        q_lo = q_lo <= 0 ? 0 : q_lo / stride;
+        int q_hi = (ix + pad) / stride;
+        if (q_hi > Q - 1) q_hi = Q - 1;
+        float acc = 0.f;
+        const size_t ob = nc * (size_t)P * Q;
+        for (int p = p_lo; p <= p_hi; ++p)
+            for (int q = q_lo; q <= q_hi; ++q)
+                if (arg[ob + p * Q + q] == me) acc += ld1(dy + ob + p * Q + q);
+        st1(dx + i, acc);
+    }
 }
 
 // one wave per plane
@@ -197,12 +197,11 @@ extern "C" int pcgan_maxpool_fwd(const void* x, void* y, int32_t* argmax, int NC
     PCGAN_CHECK(x && y && argmax && NC > 0 && H > 0 && W > 0 && k > 0 && stride > 0, "maxpool_fwd: bad arguments");
     PCGAN_CHECK(P == (H + 2 * pad - k) / stride + 1 && Q == (W + 2 * pad - k) / stride + 1,
                 "maxpool_fwd: output dims do not match (floor mode)");
+    const size_t total = (size_t)NC * P * Q;
     PCGAN_CHECK(NC <= 65535, "maxpool_fwd: more than 65535 planes");
-    const dim3 grid((unsigned)((Q + 63) / 64), (unsigned)((P + 3) / 4), (unsigned)NC);
-    if (stride == 2) PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y,
-                                                                       argmax, H, W, k, stride, pad, P, Q));
-    else PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T, 0>), grid, dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, argmax,
-                                                         H, W, k, stride, pad, P, Q));
+    const int bx = (P * Q + 255) / 256;
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s,
+                                                    (const T*)x, (T*)y, argmax, H, W, k, stride, pad, P, Q, total));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
@@ -210,13 +209,11 @@ extern "C" int pcgan_maxpool_fwd(const void* x, void* y, int32_t* argmax, int NC
 extern "C" int pcgan_maxpool_bwd(const void* dy, const int32_t* argmax, void* dx, int NC, int H, int W, int k,
                                  int stride, int pad, int P, int Q, int dtype, pcgan_stream_t s) {
     PCGAN_CHECK(dy && argmax && dx && NC > 0, "maxpool_bwd: bad arguments");
+    const size_t total = (size_t)NC * H * W;
     PCGAN_CHECK(NC <= 65535, "maxpool_bwd: more than 65535 planes");
-    PCGAN_CHECK(stride > 0 && k > 0, "maxpool_bwd: bad window");
-    const dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)NC);
-    if (stride == 2) PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)s, (const T*)dy,
-                                                                       argmax, (T*)dx, H, W, k, stride, pad, P, Q));
-    else PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 0>), grid, dim3(256), 0, (hipStream_t)s, (const T*)dy, argmax,
-                                                         (T*)dx, H, W, k, stride, pad, P, Q));
+    const int bx = (H * W + 255) / 256;
+    PCGAN_DTYPE_SWITCH(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(bx > 1024 ? 1024 : bx, NC), dim3(256), 0, (hipStream_t)s,
+                                                    (const T*)dy, argmax, (T*)dx, H, W, k, stride, pad, P, Q, total));
     PCGAN_LAUNCH_CHECK();
     return 0;
 }
