@@ -344,9 +344,9 @@ int pcgan_conv2d_bwd_data_packed_hsplit(const pcgan_conv_desc* d, const void* dy
  * residual blocks, the generator's down / up-sampling layers, the PatchGAN's layers (models/networks.py:584-648, 753-775).  Both
  * operands are split on their way to LDS, so there is no packed copy of dy; ws (pcgan_conv2d_hsplit_wgrad_workspace_bytes) holds the
  * padded copy of x (when one is made) and the partial sums of the splits of the pixel reduction, which are combined in a fixed order.
- * fp32 tensors with zero padding <= 1: the padding is applied inside the gather (no padded copy), the output width may be ragged
- * (at least 3/4 of its multiple of 16: the PatchGAN's 15 x 15 layer) and K may exceed 256 (row tiles); otherwise the output width
- * is a multiple of 16 and K <= 256.  pcgan_conv2d_hsplit_wgrad_inline: 1 when the call makes no padded copy of x (routing: the
+ * Zero padding <= 1: the padding is applied inside the gather (no padded copy); with fp32 tensors the output width may also be ragged
+ * (at least 3/4 of its multiple of 16: the PatchGAN's 15 x 15 layer) and K may exceed 256 (row tiles); otherwise (bf16 tensors, other
+ * paddings) the output width is a multiple of 16 and K <= 256.  pcgan_conv2d_hsplit_wgrad_inline: 1 when the call makes no padded copy of x (routing: the
  * copy of a 134 MB input costs more than the matrix pipe saves).  accumulate != 0 adds into dw like pcgan_conv2d_bwd_weight.
  * desc.dtype = PCGAN_BF16: the one-product bf16 form (the maxima pointers may be NULL). */
 int pcgan_conv2d_hsplit_wgrad_supported(const pcgan_conv_desc* d);
