@@ -1175,8 +1175,18 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
         }
         const unsigned av = live ? avo : BS_OOB, bv = live ? bvt : BS_OOB;
         if constexpr (HALF) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso, 0);
-            r.a[0] = v.x; r.a[1] = v.y; r.a[2] = v.z; r.a[3] = v.w;
+            if (GEN && a.Qs != a.Q) {      // ragged rows start on 2-byte boundaries: element loads, the values beyond column Q enter as zero
+                const int am = a.Q - lx - aq * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned e0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rD, av, aso + (unsigned)(2 * i) * ES, 0);
+                    const unsigned e1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rD, av, aso + (unsigned)(2 * i + 1) * ES, 0);
+                    r.a[i] = (2 * i < am ? (e0 & 0xffffu) : 0u) | (2 * i + 1 < am ? e1 << 16 : 0u);
+                }
+            } else {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rD, av, aso, 0);
+                r.a[0] = v.x; r.a[1] = v.y; r.a[2] = v.z; r.a[3] = v.w;
+            }
 #pragma unroll
             for (int j = 0; j < KB; ++j) r.b[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rX, bv, bso + (unsigned)(j * STRIDE) * ES, 0);
         } else {
@@ -1845,8 +1855,7 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit_add(const pcgan_conv_desc* d, const 
 static bool hsplit_wgrad_gen(const pcgan_conv_desc* d) {
     static const bool on = [] { const char* e = getenv("PCGAN_WGRAD_GEN"); return !(e && e[0] == '0'); }();
     if (!on || d->pad_mode != 0 || d->pad > 1) return false;
-    // bf16 tensors: the 16-byte loads of dy need rows of whole stages (a ragged row would start on a 2-byte boundary)
-    return d->dtype == PCGAN_F32 || (d->dtype == PCGAN_BF16 && d->Q % 16 == 0 && d->K <= 256);
+    return d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16;      // (bf16 tensors with ragged rows: element loads of dy, rows start on 2-byte boundaries)
 }
 
 extern "C" int pcgan_conv2d_hsplit_wgrad_inline(const pcgan_conv_desc* d) {

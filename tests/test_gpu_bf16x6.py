@@ -361,8 +361,8 @@ def test_hsplit_weight_gradient_general(dev, N, C, H, W, K, k, stride, pad, mode
 ])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_hsplit_weight_gradient_inline_zero_padding(dev, N, C, H, W, K, k, stride, pad, dtype):
-    """the general form of the matrix-pipe weight gradient (zero padding applied inside the gather; fp32 tensors: ragged output width,
-    more than 256 output channels; bf16 tensors: whole 16-column stages) against autograd in float64 and the fp32-MFMA kernel"""
+    """the general form of the matrix-pipe weight gradient (zero padding applied inside the gather, ragged output width, more than 256
+    output channels; fp16 two-piece route / bf16 one-product route) against autograd in float64 and the fp32-MFMA kernel"""
     from pcgan_amd.hip import lib as L, ops
     g = torch.Generator().manual_seed(N * 100 + C + K + k + W)
     x = torch.randn(N, C, H, W, generator=g)
@@ -373,9 +373,6 @@ def test_hsplit_weight_gradient_inline_zero_padding(dev, N, C, H, W, K, k, strid
         x, dy = x.bfloat16().float(), dy.bfloat16().float()       # bf16-valued operands: the products are exact in fp32
     d = ops.make_desc(N, C, H, W, K, k, k, stride, pad, 0, L.BF16 if half else L.F32)
     lib = L.load()
-    if half and (Q % 16 != 0 or K > 256):
-        assert not lib.pcgan_conv2d_hsplit_wgrad_supported(ctypes.byref(d))      # ragged rows / row tiles: fp32 tensors only
-        return
     w = torch.zeros(K, C, k, k, dtype=torch.float64, requires_grad=True)
     R.conv2d(x.double(), w, None, stride, pad, 0).backward(dy.double())
     ref = w.grad
