@@ -1034,7 +1034,7 @@ struct HWgradArgs {
     int x_namax, dy_namax;
     int ntile, nwg;        // column tiles, workgroups that have work (the grid is padded to a multiple of 8)
     unsigned* ovf;         // non-finite sentinel (common.h), fp32 tensors only; may be null
-    int reflect_inline;    // fp32, stride 1, 3x3, reflection padding 1: XP is the UNPADDED input (Hp = H, Wp = W) and the mirror is applied
+    int reflect_inline;    // stride 1, 3x3, reflection padding 1: XP is the UNPADDED input (Hp = H, Wp = W) and the mirror is applied
                            // in the gather -- a per-stage row select and one register move at the two image edges -- instead of by a padded copy
     int splits, nmt;       // splits of the pixel reduction; row tiles of BM output channels (K > 256: the PatchGAN's 512-channel layer)
     int Qs, pad;           // GEN kernels: Q rounded up to a multiple of 16 (the stages of a row; dy beyond column Q enters as zero) and the
@@ -1160,7 +1160,7 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
             bso = 0;
             r.am = a.Q - lx - aq * 4;
         } else
-        if constexpr (!HALF && STRIDE == 1) {
+        if constexpr (STRIDE == 1) {
             if (a.reflect_inline) {      // source row of tap row tr under reflection padding 1 (scalars per stage), selected by the lane's tap row
                 const int y0 = ly == 0 ? 1 : ly - 1, y2 = ly == a.Hp - 1 ? a.Hp - 2 : ly + 1;
                 const unsigned base = (unsigned)((ln * a.C) * a.Hp * a.Wp + lx) * ES;
@@ -1287,6 +1287,10 @@ __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
                 if constexpr (GEN) {
                     bj = (r.fix & 256) ? (j == 0 ? 0u : r.b[j == 0 ? 0 : j - 1]) : bj;      // run loaded one element late
                     bj = (r.fix >> j & 1) ? 0u : bj;                                         // zero padding
+                } else if constexpr (STRIDE == 1) {                                          // inline reflection, as in split() above
+                    if (j == 0) bj = r.fix == 1 ? r.b[1] : bj;
+                    else bj = r.fix == 1 ? r.b[j - 1] : bj;
+                    if (j == KB - 1) bj = r.fix == 2 ? r.b[KB - 3] : bj;
                 }
                 w[j] = (unsigned short)bj;
             }
@@ -1860,7 +1864,7 @@ static bool hsplit_wgrad_gen(const pcgan_conv_desc* d) {
 
 extern "C" int pcgan_conv2d_hsplit_wgrad_inline(const pcgan_conv_desc* d) {
     if (!d || !pcgan_conv2d_hsplit_wgrad_supported(d)) return 0;
-    const bool inline_reflect = d->dtype == PCGAN_F32 && d->stride == 1 && d->pad_mode == 1 && d->pad == 1 && d->R == 3 && d->S == 3 && d->H >= 2 &&
+    const bool inline_reflect = d->stride == 1 && d->pad_mode == 1 && d->pad == 1 && d->R == 3 && d->S == 3 && d->H >= 2 &&
                                 d->W >= 16 && d->P == d->H && d->Q == d->W && getenv("PCGAN_WGRAD_PADCOPY") == nullptr;
     return (inline_reflect || d->pad == 0 || hsplit_wgrad_gen(d)) ? 1 : 0;
 }
@@ -1931,7 +1935,7 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     float* part = (float*)((char*)ws + xpad_bytes);
     const void* xin = x;
     // the residual-block shape (fp32, 3x3, stride 1, reflection padding 1): the mirror is applied inside the gather, no padded copy
-    const bool inline_reflect = !half && d->stride == 1 && d->pad_mode == 1 && d->pad == 1 && d->R == 3 && d->S == 3 && d->H >= 2 && d->W >= 16 &&
+    const bool inline_reflect = d->stride == 1 && d->pad_mode == 1 && d->pad == 1 && d->R == 3 && d->S == 3 && d->H >= 2 && d->W >= 16 &&
                                 d->P == d->H && d->Q == d->W && getenv("PCGAN_WGRAD_PADCOPY") == nullptr;
     int Hx = Hp, Wx = Wp;
     if (inline_reflect || gen) {

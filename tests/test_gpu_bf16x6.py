@@ -301,6 +301,7 @@ def test_hsplit_weight_gradient(dev, N, C, H, W, acc, data):
     (2, 32, 16, 16, 64, 1, 1, 0, 0),      # 1x1, no padding (no padded copy)
     (8, 128, 16, 16, 64, 3, 1, 1, 0),     # 1024 small planes: the wave-per-plane padded copy, zero padding
     (9, 128, 16, 32, 64, 3, 1, 1, 1),     # ... reflection, a plane count that is no multiple of 4, non-square
+    (2, 256, 32, 32, 256, 3, 1, 1, 1),    # the residual block's shape (bf16 tensors: 256-column workgroups, the mirror applied in the gather)
     (4, 256, 12, 16, 64, 5, 1, 2, 1),     # ... padding 2
     (2, 4, 32, 48, 64, 7, 1, 3, 1),       # the generator's stem: 4 channels x 49 taps = 196 columns (two ragged column tiles), reflection 3
     (2, 3, 20, 32, 64, 7, 1, 3, 0),       # 3 channels, zero padding
