@@ -1042,9 +1042,10 @@ struct HWgradArgs {
 };
 
 // NC = column tiles of 128 per workgroup (2 with the 256-row tile: the dy tile is loaded and split once for 256 columns)
-// GEN (zero padding <= 1; bf16 tensors: output width a multiple of 16): the padding is applied inside the gather (rows outside the image select an out-of-range
-// offset, the at most one column per side is zeroed in registers when the run is split) and the output width may be ragged (stages
-// of 16 columns per output row, the dy values beyond column Q masked to zero: the PatchGAN's 15 x 15 layer)
+// GEN (zero padding <= 1, fp32 or bf16 tensors): the padding is applied inside the gather (rows outside the image select an
+// out-of-range offset, the at most one column per side is zeroed in registers when the run is split / stored) and the output width
+// may be ragged (stages of 16 columns per output row, the dy values beyond column Q masked to zero: the PatchGAN's 15 x 15 layer;
+// bf16 tensors then load dy by 2-byte elements, a ragged row starts on a 2-byte boundary)
 template <int BM, int STRIDE, typename TA, int NC, int GEN = 0>
 __global__ void __launch_bounds__(BM * 2) hsplit_wgrad_kernel(HWgradArgs a) {
     constexpr int NT = BM * 2;
@@ -1854,8 +1855,8 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit_add(const pcgan_conv_desc* d, const 
 
 // weight gradient on the fp16 route (fp32 tensors) / bf16 route (bf16 tensors): padded copy of x (workspace), the kernel above over
 // splits of the pixel reduction, reduce
-// the general form of the kernel (GEN): fp32 tensors, zero padding of at most 1 applied inside the gather (no padded copy), ragged output
-// width.  PCGAN_WGRAD_GEN=0 keeps the padded copy (A/B measurement; the ragged widths and K > 256 then leave this route)
+// the general form of the kernel (GEN): zero padding of at most 1 applied inside the gather (no padded copy), ragged output width, row
+// tiles.  PCGAN_WGRAD_GEN=0 keeps the padded copy (A/B measurement; the ragged widths and K > 256 then leave this route)
 static bool hsplit_wgrad_gen(const pcgan_conv_desc* d) {
     static const bool on = [] { const char* e = getenv("PCGAN_WGRAD_GEN"); return !(e && e[0] == '0'); }();
     if (!on || d->pad_mode != 0 || d->pad > 1) return false;
