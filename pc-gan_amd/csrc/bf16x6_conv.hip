@@ -1890,10 +1890,16 @@ static inline int hsplit_wgrad_bm(const pcgan_conv_desc* d) {
     return (d->K > 128 && force != 128) ? 256 : 128;
 }
 
-// 256 columns per workgroup: bf16 tensors with the 256-row tile when that still leaves at least 8 column tiles (26.5 -> 26.0 ms per
-// bf16 step).  The fp16 two-piece form needs 256 VGPRs there and spills: 0.166 -> 0.177 ms per launch, so it keeps 128 columns.
+// 256 columns per workgroup with the 256-row tile when that still leaves at least 8 column tiles: the dy tile is loaded, split and
+// written to LDS once for 256 columns and a wave's 64 x 128 tile needs 12 LDS operand reads for 24 MFMAs instead of 8 for 12.
+// bf16 tensors since round 2 (26.5 -> 26.0 ms per bf16 step).  fp32 tensors: the kernel ALONE gains (238 VGPRs, no spills: residual
+// shape 0.153 -> 0.139 ms incl. the reduce of twice as many split partials), the STEP loses 1 % (1206 -> 1194 img/s, three interleaved
+// pairs on one box: beside the data-gradient kernel of the main stream the wide workgroups take 0.292 instead of 0.277 ms and the
+// parameter-gradient stream is the longer one) -- so fp32 tensors keep 128 columns; PCGAN_WGRAD_CW=256 selects the wide form (A/B).
 static inline int hsplit_wgrad_cw(const pcgan_conv_desc* d) {
-    return d->dtype == PCGAN_BF16 && hsplit_wgrad_bm(d) == 256 && d->C * d->R * d->S >= 8 * 256 ? 256 : 128;
+    static const bool wide_f32 = [] { const char* e = getenv("PCGAN_WGRAD_CW"); return e && atoi(e) == 256; }();
+    const bool wide = d->dtype == PCGAN_BF16 || (d->dtype == PCGAN_F32 && d->pad_mode == 1 && wide_f32);
+    return wide && hsplit_wgrad_bm(d) == 256 && d->C * d->R * d->S >= 8 * 256 ? 256 : 128;
 }
 
 static inline int hsplit_wgrad_splits(const pcgan_conv_desc* d, int* nst_split) {
