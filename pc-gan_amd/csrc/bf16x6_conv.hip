@@ -1897,8 +1897,8 @@ static inline int hsplit_wgrad_bm(const pcgan_conv_desc* d) {
 // pairs on one box: beside the data-gradient kernel of the main stream the wide workgroups take 0.292 instead of 0.277 ms and the
 // parameter-gradient stream is the longer one) -- so fp32 tensors keep 128 columns; PCGAN_WGRAD_CW=256 selects the wide form (A/B).
 static inline int hsplit_wgrad_cw(const pcgan_conv_desc* d) {
-    static const bool wide_f32 = [] { const char* e = getenv("PCGAN_WGRAD_CW"); return e && atoi(e) == 256; }();
-    const bool wide = d->dtype == PCGAN_BF16 || (d->dtype == PCGAN_F32 && d->pad_mode == 1 && wide_f32);
+    static const int force = [] { const char* e = getenv("PCGAN_WGRAD_CW"); return e ? atoi(e) : 0; }();      // 256: fp32 too; 128: bf16 too
+    const bool wide = (d->dtype == PCGAN_BF16 && force != 128) || (d->dtype == PCGAN_F32 && d->pad_mode == 1 && force == 256);
     return wide && hsplit_wgrad_bm(d) == 256 && d->C * d->R * d->S >= 8 * 256 ? 256 : 128;
 }
 
