@@ -160,8 +160,9 @@ int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, flo
  * pcgan_bn_stats_merged = pcgan_plane_stats + pcgan_bn_merge (+ num_batches_tracked += 1 when `batches` != NULL);
  * pcgan_bn_bwd_stats_reduced = pcgan_norm_bwd_stats(per_plane = 0) + pcgan_bn_bwd_reduce.  The workgroup whose plane completes a
  * channel ("last arriver", counted on ticket[c]) finishes that channel with the stand-alone kernels' arithmetic in their order, so the
- * results are the same bits.  ticket: C unsigned words owned by the caller, zeroed ONCE when the layer is created and never cleared
- * (arrival k is the last of its call iff (k + 1) % N == 0); forward and backward use separate arrays; calls sharing an array must be
+ * results are the same bits.  ticket: C unsigned words owned by the caller, zeroed ONCE when the layer is created; the arrival that finds
+ * old + 1 == N is the last of its call and stores 0 back, so every call starts from 0 whatever N the previous call had (partial last
+ * batch of an epoch, test() at another batch size) and a captured graph replays; forward and backward use separate arrays; calls sharing an array must be
  * ordered (one stream, or stream dependencies) -- a BatchNorm layer's passes are ordered anyway for its running statistics. */
 int pcgan_bn_stats_merged(const void* x, float* mean_nc, float* m2_nc, float* mean_c, float* var_c, float* running_mean,
                           float* running_var, long long* batches, unsigned int* ticket, int N, int C, int HW, float momentum, int dtype,

@@ -2025,11 +2025,13 @@ __global__ void __launch_bounds__(256) smallm_wgrad_strip_kernel(WgradArgs a) {
 #pragma unroll
                 for (int k = 0; k < NW; ++k) xin[(sj + 1) & 1][k] = ldx<TA>(rX, rowoff[k] + co, 0u);
             }
-            // One v_fmac_f32 per term, written out: left to itself the compiler pairs the accumulators into v_pk_fma_f32 with operand
-            // selects (op_sel:[0,1,0]), and THAT form of this kernel returned different sums from run to run whenever an f16-MFMA kernel
-            // of another stream shared the CUs (encoder / residual-block kernels beside the head's weight gradient: the only
-            // run-to-run difference of a whole optimize_parameters(); alone, or beside fp32-MFMA / copy kernels, it was exact;
-            // scripts/diag_race.py reproduces it 30 / 30, built with -fno-slp-vectorize 0 / 30).  Same arithmetic, same order.
+            // One v_fmac_f32 per term, written out.  WORKAROUND, cause not established: left to itself the compiler pairs the
+            // accumulators into v_pk_fma_f32 with operand selects, and THAT build of this kernel returned different sums from run to
+            // run whenever an f16-MFMA kernel of another stream shared the CUs (scripts/diag_race.py: 30 / 30; alone, or beside
+            // fp32-MFMA / copy kernels, exact).  Round 4's ISA study (scripts/micro/head_wgrad_isa.md) shows the compiler's wait counts
+            // are correct (no read or overwrite of a register with an outstanding load) and that the one form unique to that build is
+            // `op_sel:[0,1,0]` (high dword of src1 broadcast) -- absent from every other kernel; tests/test_isa_guard.py bans it from
+            // the library.  Same arithmetic, same order.
 #pragma unroll
             for (int ri = 0; ri < NT; ++ri)
 #pragma unroll

@@ -19,9 +19,13 @@ namespace pcgan {
 // arrivals reads the partials with sc1 loads (they bypass the non-coherent caches) and finishes the channel with the arithmetic of the
 // stand-alone merge kernels (same order: the result does not depend on which workgroup is last).  No fences: a release fence per
 // workgroup writes back the whole L2 of its XCD (MI355X_MICROARCH.md: 1.7 - 6.5 us each) -- the first version of this kernel with
-// __threadfence() made the step 2.7 ms SLOWER than the three-launch form it replaces.  Tickets only ever grow -- arrival k is the last of its call iff (k + 1) % N == 0 -- so
-// nothing is cleared between calls and a captured hipGraph replays correctly; the calls that share a ticket array run in stream order
-// (a BatchNorm net never runs two passes at once: its running statistics must stay ordered anyway).
+// __threadfence() made the step 2.7 ms SLOWER than the three-launch form it replaces.  The arrival that finds old + 1 == N is the last
+// of its call and puts the ticket back to 0 (an agent-scope atomic store, complete when the launch is): the decision does not depend on
+// the history of the ticket array, so calls with DIFFERENT batch sizes may share it (the partial last batch of an epoch, test() and
+// get_current_visuals() at another N: round 3's never-cleared form, (old + 1) % N == 0, picked a wrong last arriver for the rest of the
+// run once a call with another N had moved the counter off a multiple of N) and a captured hipGraph replays correctly; the calls that
+// share a ticket array run in stream order (a BatchNorm net never runs two passes at once: its running statistics must stay ordered
+// anyway), so the reset of one launch is visible to the next.
 struct BnTicket {
     unsigned* ticket;       // [C] arrival counters of this layer and pass direction, or null: no merge in this launch
     int N, C;
@@ -34,7 +38,9 @@ __device__ __forceinline__ bool bn_last_arriver(const BnTicket& t, int c, int* f
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through stores have left before the ticket moves
         const unsigned old = __hip_atomic_fetch_add(&t.ticket[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag_lds = ((old + 1u) % (unsigned)t.N) == 0u;
+        const bool last = (old + 1u) == (unsigned)t.N;
+        if (last) __hip_atomic_store(&t.ticket[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag_lds = last;
     }
     __syncthreads();
     return *flag_lds != 0;

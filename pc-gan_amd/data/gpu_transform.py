@@ -166,4 +166,6 @@ class GpuTransform(object):
                 ctypes.byref(g.desc), src.data_ptr(), g.kh.data_ptr(), g.bh.data_ptr(), g.kv.data_ptr(), g.bv.data_ptr(),
                 a_dev.data_ptr(), out.data_ptr(), len(idx), g.band, g.rows, stream), 'image_transform')
             a_dev.record_stream(torch.cuda.current_stream(self.device))
+        from ..hip import ops
+        ops.mark_ready(out)      # producer's event: the step's ahead-of-time passes over this batch wait for THIS, not for the main stream
         return out

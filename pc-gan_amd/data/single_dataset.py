@@ -53,6 +53,10 @@ class SingleDataset(BaseDataset):
             rng.shuffle(self.A_paths)
 
     def __len__(self):
-        if not getattr(self, 'external_shuffle', False) and not self.opt.sorted:     # the reference reshuffles on every len() (:49-54)
+        # The reference reshuffles on EVERY len() (data/single_dataset.py:45-47), also under --sorted -- so its --sorted order only
+        # survives until the DataLoader asks for the length.  INTENTIONAL DEVIATION (deviations): --sorted keeps the sorted
+        # order here (generate_images.py / test.py / siamese.py --mode embedding rely on a fixed order so that the i-th output belongs
+        # to the i-th path); without --sorted the reference's reshuffle-on-len() behaviour is kept.
+        if not getattr(self, 'external_shuffle', False) and not self.opt.sorted:
             self.reshuffle()
         return len(self.A_paths)

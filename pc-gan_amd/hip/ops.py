@@ -224,16 +224,26 @@ def upload_stream(device):
     return st
 
 
+def mark_ready(t, stream=None):
+    """PRODUCER side: declare that device tensor `t` holds its contents once everything queued so far on `stream` (default: the current
+    stream) has run -- to_act's upload, the loader's --gpu_transform output, a custom loader that fills a device buffer.  Whoever
+    rewrites the buffer afterwards (also through a raw pointer or `.data`, which do not bump the tensor version) calls this again."""
+    ev = torch.cuda.Event()
+    ev.record(stream if stream is not None else torch.cuda.current_stream(t.device))
+    t._pcgan_ready = (t._version, ev)
+    return ev
+
+
 def ready_event(t):
-    """an event after which the device tensor `t` holds its current contents: attached by whoever produced it on another stream
-    (to_act), else recorded on the current stream the first time the tensor is seen and kept while its version stays the same -- a
-    batch that has been resident for a while is ready without waiting for what the current stream has queued since"""
+    """CONSUMER side: an event after which the device tensor `t` holds its current contents.  The producer's event when it attached one
+    (mark_ready) and the tensor version is still the one it was attached at; otherwise an event recorded NOW on the current stream,
+    i.e. "after everything queued so far" -- the plain stream order, never cached.  (Round 3 recorded an event at first sight and kept
+    it while the version stayed the same: a buffer rewritten behind the version counter kept a stale "ready")"""
     ent = t.__dict__.get('_pcgan_ready')
     if ent is not None and ent[0] == t._version:
         return ent[1]
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(t.device))
-    t._pcgan_ready = (t._version, ev)
     return ev
 
 
@@ -309,8 +319,10 @@ def _want_maxima(dt, C):
     return HSPLIT and dt == F32 and C % 16 == 0
 
 
-def _attach_amax(t, pmax):
-    t._pcgan_amax = (t._version, pmax, _raw_stream())
+def _attach_amax(t, pmax, event=None):
+    """maxima written by the kernel that wrote `t` itself need no event: whoever may read `t` is already ordered behind that kernel.
+    Maxima taken by a SEPARATE pass (amax_of below) carry the event recorded behind that pass."""
+    t._pcgan_amax = (t._version, pmax, _raw_stream(), event)
 
 
 def amax_of(x):
@@ -319,15 +331,23 @@ def amax_of(x):
     ent = x.__dict__.get('_pcgan_amax')
     if ent is not None and ent[0] == x._version:
         AMAX_STATS['attached'] += 1
-        if ent[2] != _raw_stream():      # consumed on another stream than it was produced on (parameter-gradient side stream)
-            ent[1].record_stream(torch.cuda.current_stream())
+        if ent[2] != _raw_stream():      # consumed on another stream than it was produced on
+            cur = torch.cuda.current_stream()
+            if len(ent) > 3 and ent[3] is not None:
+                # taken by an absmax pass on that other stream (a weight gradient on the parameter-gradient stream computes the maxima
+                # of an un-annotated dy, the data gradient on the main stream finds them attached): being ordered behind the producer
+                # of x says nothing about that pass -- wait for it
+                cur.wait_event(ent[3])
+            ent[1].record_stream(cur)
         return ent[1]
     AMAX_STATS['computed'] += 1
     lib = _L.load()
     slots = int(lib.pcgan_absmax_slots(x.numel()))
     out = torch.empty(slots, dtype=torch.float32, device=x.device)
     _L.check(lib.pcgan_absmax(_p(x), x.numel(), _DTYPES[x.dtype], _p(out), slots, _stream()), 'absmax')
-    _attach_amax(x, out)      # a second consumer of the same tensor version (forward and weight gradient of one layer) reuses the pass
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    _attach_amax(x, out, ev)      # a second consumer of the same tensor version (forward and weight gradient of one layer) reuses the pass
     return out
 
 

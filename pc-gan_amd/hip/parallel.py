@@ -11,6 +11,8 @@ large flat all-reduce per optimizer (not per-tensor buckets) keeps the per-link 
 ~0.5 ms against a ~70 ms compute step.
 """
 import os
+import socket
+import sys
 
 import torch
 import torch.distributed as dist
@@ -34,7 +36,108 @@ def init_process_group(backend=None):
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        selfcheck_collectives()
     return world, rank, local
+
+
+class CollectiveSelfCheckError(RuntimeError):
+    pass
+
+
+def selfcheck_collectives(n=256):
+    """First thing after the process group exists (round 4: the RCCL branch had never run on more than one rank, so its first run
+    must not be able to fail silently): a 1 KiB gradient-shaped all-reduce through the SAME code path the step uses
+    (allreduce_mean_: ReduceOp.AVG on RCCL, SUM + scale on gloo) against (a) a plain SUM all-reduce divided by the world size and
+    (b) the closed form -- rank r contributes (r + 1) * [1 .. n], so the mean is (world + 1) / 2 * [1 .. n], exact in fp32 --
+    and a broadcast from rank 0.  Raises CollectiveSelfCheckError on every rank (they all see the same wrong numbers) naming what
+    differed; returns the largest deviation (0.0 expected)."""
+    if not is_distributed():
+        return 0.0
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = torch.device('cuda', torch.cuda.current_device()) if (dist.get_backend() == 'nccl' or torch.cuda.is_available()) else torch.device('cpu')
+    if dist.get_backend() == 'gloo' and os.environ.get('PCGAN_SELFCHECK_CPU'):
+        dev = torch.device('cpu')
+    base = torch.arange(1, n + 1, dtype=torch.float32, device=dev)
+    mine = base * float(rank + 1)
+    avg = allreduce_mean_(mine.clone())
+    tot = mine.clone()
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    want = base * ((world + 1) / 2.0)
+    e_avg = float((avg - want).abs().max())
+    e_sum = float((tot / world - want).abs().max())
+    b = mine.clone()
+    dist.broadcast(b, 0)
+    e_bc = float((b - base).abs().max())
+    worst = max(e_avg, e_sum, e_bc)
+    if worst != 0.0:
+        raise CollectiveSelfCheckError(
+            'pcgan_amd: collective self-check failed on rank %d / %d (backend %s): |AVG - closed form| = %g, |SUM / world - closed form| '
+            '= %g, |broadcast - rank 0| = %g -- the gradient all-reduce cannot be trusted on this fabric / build'
+            % (rank, world, dist.get_backend(), e_avg, e_sum, e_bc))
+    return worst
+
+
+def rank_identity(device=None):
+    """what bench.py --gpus N records per rank so that the record PROVES N distinct GPUs took part: device uuid / name / PCI bus,
+    host, pid, RCCL version, backend"""
+    info = {'rank': env_world()[1], 'host': socket.gethostname(), 'pid': os.getpid(),
+            'backend': dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None}
+    if torch.cuda.is_available():
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        pr = torch.cuda.get_device_properties(idx)
+        info.update({'device_index': idx, 'device_name': pr.name, 'device_uuid': str(getattr(pr, 'uuid', '')),
+                     'pci_bus_id': getattr(pr, 'pci_bus_id', None), 'cus': pr.multi_processor_count})
+        try:
+            info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001  (diagnostics only)
+            info['rccl_version'] = 'unavailable: %s' % e
+    return info
+
+
+# ---- PCGAN_DDP_CHECK=k: every k-th optimizer step all ranks compare a hash of their flat parameter buffers and the job ends non-zero
+# on the first divergence (replicas must stay bit-identical: same start, same averaged gradients, same Adam arithmetic)
+DDP_CHECK_EVERY = int(os.environ.get('PCGAN_DDP_CHECK', '0') or 0)
+_ddp_check_calls = {}
+
+
+def flat_hash(flat):
+    """two int64 checksums of a flat fp32 buffer's BITS (plain sum, position-weighted sum): equal buffers <=> equal hashes for all
+    practical purposes; torch integer ops -- a debugging aid off the hot path, not arithmetic of the step"""
+    bits = flat.detach().view(torch.int32).to(torch.int64)
+    w = (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 65521) + 1
+    return torch.stack([bits.sum(), (bits * w).sum()])
+
+
+class ReplicaDivergenceError(RuntimeError):
+    pass
+
+
+def ddp_check(optimizer, name='', every=None, exit_on_divergence=True):
+    """call after optimizer.step(); every `every`-th call (default PCGAN_DDP_CHECK) compares flat_hash(optimizer.flat) across ranks
+    (MIN and MAX all-reduce of the hash: identical on all ranks iff they agree).  On divergence every rank prints its own hash and
+    the job exits with code 3 -- a fresh exit from the running process, never a re-exec (gpurun forbids exec after HIP init).
+    Returns True when a comparison ran and passed."""
+    every = DDP_CHECK_EVERY if every is None else every
+    if not every or not is_distributed():
+        return False
+    n = _ddp_check_calls[name] = _ddp_check_calls.get(name, 0) + 1
+    if n % every:
+        return False
+    flat = getattr(optimizer, 'flat', None)
+    if flat is None:
+        flat = torch.cat([p.detach().reshape(-1) for g in optimizer.param_groups for p in g['params']])
+    h = flat_hash(flat)
+    lo, hi = h.clone(), h.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if bool((lo != hi).any()):
+        msg = ('pcgan_amd: replicas DIVERGED at optimizer %r step %d: rank %d hash %s (min %s, max %s over ranks)'
+               % (name, n, dist.get_rank(), h.tolist(), lo.tolist(), hi.tolist()))
+        print(msg, file=sys.stderr, flush=True)
+        if exit_on_divergence:
+            sys.exit(3)
+        raise ReplicaDivergenceError(msg)
+    return True
 
 
 def is_distributed():

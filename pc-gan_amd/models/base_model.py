@@ -40,8 +40,7 @@ class BaseModel(object):
         if not (isinstance(image, torch.Tensor) and self.device.type == 'cuda'):
             return image.to(self.device)
         if image.is_cuda and image.dtype == self.act_dtype:
-            ops.ready_event(image)
-            return image
+            return image      # resident already: ready when its producer said so (ops.mark_ready), else in plain stream order
         cur = torch.cuda.current_stream(self.device)
         up = ops.upload_stream(self.device)
         src_ev = ops.ready_event(image) if image.is_cuda else None
@@ -54,7 +53,7 @@ class BaseModel(object):
                 out = ops.cast(out.contiguous(), self.act_dtype)
             ev = torch.cuda.Event()
             ev.record(up)
-        out._pcgan_ready = (out._version, ev)
+        out._pcgan_ready = (out._version, ev)      # (= ops.mark_ready(out, up) with the event recorded inside the stream context)
         cur.wait_event(ev)
         out.record_stream(cur)
         return out

@@ -193,6 +193,7 @@ class WSGANCycleModel(BaseModel):
         self.backward_D()
         parallel.sync_gradients(self.optimizer_D)
         self.optimizer_D.step()
+        parallel.ddp_check(self.optimizer_D, 'D')
         # update G, E
         self.set_requires_grad(self.netD, False)
         self.optimizer_G.zero_grad()
@@ -202,6 +203,8 @@ class WSGANCycleModel(BaseModel):
         parallel.sync_gradients(self.optimizer_E)
         self.optimizer_G.step()
         self.optimizer_E.step()
+        parallel.ddp_check(self.optimizer_G, 'G')
+        parallel.ddp_check(self.optimizer_E, 'E')
 
     def get_current_visuals(self):
         self.set_requires_grad(self.netG, False)

@@ -429,6 +429,7 @@ class WSGANEmbModel(BaseModel):
         self.backward_D()
         parallel.sync_gradients(self.optimizer_D)
         self.optimizer_D.step()
+        parallel.ddp_check(self.optimizer_D, 'D')
 
     def update_G(self):
         self.set_requires_grad(self.netD, False)
@@ -436,6 +437,7 @@ class WSGANEmbModel(BaseModel):
         self.backward_G()
         parallel.sync_gradients(self.optimizer_G)
         self.optimizer_G.step()
+        parallel.ddp_check(self.optimizer_G, 'G')
         self._mark_g_updated()
 
     def _mark_g_updated(self):
@@ -463,9 +465,11 @@ class WSGANEmbModel(BaseModel):
         self.backward_D()
         finish_G()
         self.optimizer_G.step()
+        parallel.ddp_check(self.optimizer_G, 'G')
         self._mark_g_updated()
         parallel.sync_gradients(self.optimizer_D)
         self.optimizer_D.step()
+        parallel.ddp_check(self.optimizer_D, 'D')
 
     def get_current_visuals(self):
         self._join_rec()

@@ -34,3 +34,31 @@ def test_committed_line_has_the_contract_fields():
         assert line['experiment_bf16x6']['default'] is False and line['experiment_bf16x6']['value'] > 0
     c = line['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+
+
+def test_round4_line_says_exactly_what_ran():
+    """the line names its arithmetic, uploads its batches inside the timed region, reports the CPU baseline at the
+    best thread count of a sweep, and carries the counter-derived matrix-pipe busy share per residual kernel.  Checked on the line
+    committed this round (profiles/r04_bench_n1.json, printed by bench.py on an MI355X)."""
+    path = os.path.join(ROOT, 'profiles', 'r04_bench_n1.json')
+    assert os.path.exists(path), 'commit this round\'s bench line as profiles/r04_bench_n1.json'
+    line = json.loads(open(path).read())
+    assert line['dtype'] == 'f32' and 'fp16 pieces' in line['arithmetic'] and '3 piece products' in line['arithmetic']
+    assert 'inside the timed region' in line['input']
+    c = line['cpu_baseline']
+    assert c['kind'] == 'port' and str(c['cores']) in c['threads_swept'] and len(c['threads_swept']) >= 2
+    assert c['value'] >= max(c['threads_swept'].values()) * 0.7      # the reported value is the winner's, not an oversubscribed default
+    assert c['host_cpus']['usable'] >= 1
+    r = line['roofline']
+    assert set(r['kernels']) == {'res_fwd', 'res_dgrad', 'res_wgrad'}
+    for k, e in r['kernels'].items():
+        assert 'mfma_busy' in e and 'frac' in e and 'frac_alone' in e and e['traffic'] is not None, k
+        assert e['mfma_busy'] is None or 0.0 < e['mfma_busy'] <= 1.0
+    assert 'route_bf16x6' in line and 'route_fp32_mfma' in line
+    assert line['host_issue_ms_per_step'] > 0
+
+
+def test_cpu_budget_is_cgroup_aware():
+    import bench
+    n, why = bench.host_cpu_budget()
+    assert 1 <= n <= (os.cpu_count() or 1) and 'affinity' in why

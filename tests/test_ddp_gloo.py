@@ -139,3 +139,57 @@ def test_n_rank_step_equals_single_process_reference(tmp_path, world):
     for k, g in got['gD'].items():
         want = sum(h[1][k] for h in halves) / world
         close(g, want, 'D grad ' + k)
+
+
+# ---- round 4: the first multi-rank run must diagnose itself -- all three pieces over gloo on the CPU
+def _diag_worker(rank, world, port, mode):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from pcgan_amd.hip import parallel
+    from pcgan_amd.hip.optim import FusedAdam
+    from pcgan_amd.models import networks
+    parallel.init_process_group('gloo')          # runs selfcheck_collectives() itself
+    assert parallel.selfcheck_collectives() == 0.0
+    # a collective that does not average (what a broken ReduceOp.AVG would look like) is caught on every rank
+    real = parallel.allreduce_mean_
+
+    def broken(flat, async_op=False):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+    parallel.allreduce_mean_ = broken
+    try:
+        with pytest.raises(parallel.CollectiveSelfCheckError, match='AVG'):
+            parallel.selfcheck_collectives()
+    finally:
+        parallel.allreduce_mean_ = real
+    ident = parallel.rank_identity()
+    assert ident['rank'] == rank and ident['backend'] == 'gloo' and ident['pid'] == os.getpid() and ident['host']
+    # replica hash check: equal replicas pass, a single flipped bit on one rank is caught
+    D = networks.define_D(3, 1, 8, 'n_layers', 3, 'batch', True, 'normal')
+    parallel.broadcast_parameters(D)
+    opt = FusedAdam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    assert parallel.ddp_check(opt, 'D', every=2) is False          # first call: not due yet
+    assert parallel.ddp_check(opt, 'D', every=2) is True           # second: compared, equal
+    if rank == world - 1:
+        bits = opt.flat.view(torch.int32)
+        bits[12345 % bits.numel()] ^= 1                            # one ulp on one rank
+    if mode == 'raise':
+        with pytest.raises(parallel.ReplicaDivergenceError, match='DIVERGED'):
+            parallel.ddp_check(opt, 'D2', every=1, exit_on_divergence=False)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        parallel.ddp_check(opt, 'D2', every=1)                     # every rank exits with code 3
+
+
+@pytest.mark.timeout(300)
+def test_collective_selfcheck_rank_identity_and_replica_hash_check():
+    mp.spawn(_diag_worker, args=(2, _free_port(), 'raise'), nprocs=2, join=True)
+
+
+@pytest.mark.timeout(300)
+def test_replica_divergence_ends_the_job_with_exit_code_3():
+    with pytest.raises(mp.ProcessExitedException) as e:
+        mp.spawn(_diag_worker, args=(2, _free_port(), 'exit'), nprocs=2, join=True)
+    assert e.value.exit_code == 3

@@ -471,7 +471,8 @@ def test_batch_norm_one_launch_statistics(shape, dev):
     """the one-launch statistics of the large BatchNorm tensors (pcgan_bn_stats_merged / pcgan_bn_bwd_stats_reduced: the last-arriving
     workgroup of a channel merges its N plane results) against the two-launch pairs they stand for (plane_stats + bn_merge,
     norm_bwd_stats + bn_bwd_reduce): BIT-IDENTICAL means / variances / running statistics / gradient sums, the batch counter moves by
-    one per call, and the never-cleared arrival tickets keep working call after call (also beside other kernels on a second stream)"""
+    one per call, and the arrival tickets (put back to zero by each call's last arriver) keep working call after call (also beside other
+    kernels on a second stream)"""
     from pcgan_amd.hip import ops
     g = torch.Generator().manual_seed(sum(shape))
     N, C, H, W = shape
@@ -497,11 +498,43 @@ def test_batch_norm_one_launch_statistics(shape, dev):
         assert torch.equal(mean_a, mean_b) and torch.equal(var_a, var_b), 'call %d' % call
         assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2), 'running statistics, call %d' % call
         assert int(nb) == call + 1
-        assert int(t_f.min()) == int(t_f.max()) == (call + 1) * N
+        assert int(t_f.min()) == int(t_f.max()) == 0          # the last arriver of every channel reset its ticket
         y = ops.norm_act_fwd(x, mean_a, var_a, None, None, None, False, 1e-5, 2, 0.2)
         s1n, s2n = ops.norm_bwd_stats(dy, x, y, mean_a, var_a, False, 1e-5, 2, 0.2)
         s1a, s2a = ops.bn_bwd_reduce(s1n, s2n, N, C)
         s1b, s2b = ops.bn_bwd_stats_reduced(dy, x, y, mean_a, var_a, 1e-5, 2, 0.2, t_b)
         torch.cuda.synchronize()
         assert torch.equal(s1a, s1b) and torch.equal(s2a, s2b), 'gradient sums, call %d' % call
-        assert int(t_b.min()) == int(t_b.max()) == (call + 1) * N
+        assert int(t_b.min()) == int(t_b.max()) == 0
+
+
+def test_batch_norm_one_launch_statistics_alternating_batch_sizes(dev):
+    """ONE ticket array shared by calls with different batch sizes (the partial last batch of an epoch: the loader has no drop_last,
+    as in the reference; test() / get_current_visuals() at another N): 32, 20, 32, 1-image-short, 32 -- every call bit-identical to the
+    two-launch pair.  Round 3's never-cleared tickets ((old + 1) % N == 0) chose a wrong last arriver from the second call on."""
+    from pcgan_amd.hip import ops
+    g = torch.Generator().manual_seed(7)
+    C, H, W = 24, 20, 20
+    tick = torch.zeros(2 * C, dtype=torch.int32, device=dev)
+    t_f, t_b = tick[:C], tick[C:]
+    rm1, rv1 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    nb = torch.zeros((), dtype=torch.int64, device=dev)
+    for call, N in enumerate([32, 20, 32, 31, 7, 32]):
+        x = (torch.randn((N, C, H, W), generator=g) * (1.0 + call) - 0.3 * call).to(dev)
+        dy = torch.randn((N, C, H, W), generator=g).to(dev)
+        mean_nc, m2_nc = ops.plane_stats(x)
+        mean_a, var_a = ops.bn_merge(mean_nc, m2_nc, N, C, H * W, rm1, rv1, 0.1)
+        mean_b, var_b = ops.bn_stats_merged(x, rm2, rv2, nb, t_f, 0.1)
+        torch.cuda.synchronize()
+        assert torch.equal(mean_a, mean_b) and torch.equal(var_a, var_b), 'call %d (N = %d)' % (call, N)
+        assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2), 'running statistics, call %d (N = %d)' % (call, N)
+        assert int(nb) == call + 1
+        assert int(t_f.abs().max()) == 0
+        y = ops.norm_act_fwd(x, mean_a, var_a, None, None, None, False, 1e-5, 2, 0.2)
+        s1n, s2n = ops.norm_bwd_stats(dy, x, y, mean_a, var_a, False, 1e-5, 2, 0.2)
+        s1a, s2a = ops.bn_bwd_reduce(s1n, s2n, N, C)
+        s1b, s2b = ops.bn_bwd_stats_reduced(dy, x, y, mean_a, var_a, 1e-5, 2, 0.2, t_b)
+        torch.cuda.synchronize()
+        assert torch.equal(s1a, s1b) and torch.equal(s2a, s2b), 'gradient sums, call %d (N = %d)' % (call, N)
+        assert int(t_b.abs().max()) == 0
