@@ -135,18 +135,29 @@ def host_cpu_budget():
     return n, why
 
 
-def cpu_baseline(batch=8, timed_per_setting=2, final_steps=3):
+def _progress(msg):
+    print('[bench %6.1f s] %s' % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def cpu_baseline(batch=8, sweep_batch=4, final_steps=3, sweep_budget_s=45.0):
     """The oracle's CPU step (reference-equivalent PyTorch-CPU path) on a bounded sample, at the BEST thread count this box offers:
-    torch.set_num_threads is swept over {8, 16, 32, 64, usable CPUs, all hardware threads} (1 untimed + `timed_per_setting` timed
-    steps each), then `final_steps` more timed steps at the winner; value = median of the winner's timed steps.  A stated baseline
-    must be the best the host's cores can do -- round 3 ran on torch's default of 128 threads and got half of what 8 threads give."""
+    torch.set_num_threads is swept over {usable CPUs, 16, 32, 8, 64, all hardware threads} -- most promising first, 1 untimed + 1 timed
+    step each at batch `sweep_batch`, stopped when `sweep_budget_s` is used up -- then 1 untimed + `final_steps` timed steps at the
+    winner at batch `batch`; value = median of those.  A stated baseline must be the best the host's cores can do: round 3 ran on
+    torch's default of 128 threads (the box's hardware threads; the container's CPU share is smaller) and got half of what 8 give."""
     from oracle import networks_ref as N
     from oracle import step_ref as S
     from oracle import weights as W
     default_threads = torch.get_num_threads()
     usable, why = host_cpu_budget()
     hw = os.cpu_count() or usable
-    cand = sorted({t for t in (8, 16, 32, 64, usable, hw) if 1 <= t <= hw})
+    cand = []
+    for t in (usable, 16, 32, 8, 64, hw):
+        if 1 <= t <= hw and t not in cand:
+            cand.append(t)
     G = N.ResnetGeneratorRef(3, 3, 1, 64, 'instance', 9)
     D = N.NLayerDiscriminatorRef(3, 1, 64, 3, 'batch', True)
     E = N.SiameseFeatureRef(N.ResNetFeatureRef('resnet18'), 'avg', (32, 1), 1, 0.7, False)
@@ -154,40 +165,42 @@ def cpu_baseline(batch=8, timed_per_setting=2, final_steps=3):
     for i, net in enumerate((G, D, E, IP)):
         net.load_state_dict(W.fill_state_dict(net.state_dict(), 50 + i))
     m = S.WSGANEmbStepRef(G, D, E, IP)
-    b = synthetic_batch(batch, SIZE, 0)
-    m.set_input(b['A'], b['B'], [int(v) for v in b['label']])
 
-    def timed(n):
-        out = []
-        for _ in range(n):
-            t0 = time.perf_counter()
-            m.optimize_parameters()
-            out.append(time.perf_counter() - t0)
-        return out
+    def feed(n):
+        b = synthetic_batch(n, SIZE, 0)
+        m.set_input(b['A'], b['B'], [int(v) for v in b['label']])
+
+    def one():
+        t0 = time.perf_counter()
+        m.optimize_parameters()
+        return time.perf_counter() - t0
     t_begin = time.perf_counter()
     sweep = {}
     try:
-        torch.set_num_threads(min(cand, key=lambda t: abs(t - min(usable, 16))))
-        m.optimize_parameters()                # warm-up (oneDNN primitive creation, allocator)
+        feed(sweep_batch)
         for t in cand:
             torch.set_num_threads(t)
-            m.optimize_parameters()            # untimed: the pool resizes, per-thread scratch is allocated
-            sweep[t] = timed(timed_per_setting)
-            if time.perf_counter() - t_begin > 120:      # bounded: a slow host stops the sweep, the best so far stands
+            one()                              # untimed: oneDNN primitives (first setting), pool resize, per-thread scratch
+            sweep[t] = one()
+            _progress('cpu_baseline sweep: %d threads %.2f img/s (batch %d)' % (t, sweep_batch / sweep[t], sweep_batch))
+            if time.perf_counter() - t_begin > sweep_budget_s:      # bounded: the most promising settings came first
                 break
-        best = min(sweep, key=lambda t: sorted(sweep[t])[len(sweep[t]) // 2])
+        best = min(sweep, key=sweep.get)
         torch.set_num_threads(best)
-        times = sorted(sweep[best] + timed(final_steps))
+        feed(batch)
+        one()
+        times = sorted(one() for _ in range(final_steps))
     finally:
         torch.set_num_threads(default_threads)
     med = times[len(times) // 2]
     return {'value': round(batch / med, 3), 'unit': 'images/sec', 'cores': best, 'kind': 'port',
             'best': round(batch / times[0], 3), 'worst': round(batch / times[-1], 3),
-            'threads_swept': {str(t): round(batch / sorted(v)[len(v) // 2], 3) for t, v in sweep.items()},
+            'threads_swept': {str(t): round(sweep_batch / v, 3) for t, v in sweep.items()},
             'host_cpus': {'hardware_threads': hw, 'usable': usable, 'basis': why, 'torch_default_threads': default_threads},
-            'sample': '%d timed steps at the best of %d thread counts (sweep: 1 untimed + %d timed steps each) of the oracle CPU step, '
-                      'batch %d, 128x128, same nets/flags; value = median step at %d threads; %.0f s of CPU work in all' % (
-                          len(times), len(sweep), timed_per_setting, batch, best, time.perf_counter() - t_begin)}
+            'sample': '%d timed steps (1 untimed) of the oracle CPU step at batch %d, 128x128, same nets/flags, at the best of %d thread '
+                      'counts (sweep: 1 untimed + 1 timed step each at batch %d, most promising first, %.0f s budget); value = median '
+                      'step at %d threads; %.0f s of CPU work in all' % (
+                          len(times), batch, len(sweep), sweep_batch, sweep_budget_s, best, time.perf_counter() - t_begin)}
 
 
 def main():
@@ -223,8 +236,10 @@ def main():
         model.optimize_parameters()
 
     from pcgan_amd.hip import ops
+    _progress('model built, warm-up')
     for i in range(args.warmup):
         step(i)
+    _progress('timed region')
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -260,6 +275,7 @@ def main():
             assert len(uuids) == world, 'bench.py --gpus %d: ranks share a GPU (%d distinct devices): %r' % (world, len(uuids), sorted(uuids))
     losses = model.get_current_losses()
     assert all(v == v and abs(v) < 1e6 for v in losses.values()), 'non-finite loss: %r' % losses
+    _progress('timed region done: %.2f ms/step' % (dt / args.steps * 1e3))
 
     timed = {k: ops.timer_read(k) for k in ('res_fwd', 'res_dgrad', 'res_wgrad', 'res_wgrad_main')}
     # the same kernels running ALONE: three more steps with the parameter-gradient and branch streams off (in the step the data
@@ -409,6 +425,7 @@ def main():
         # exact three-piece bf16 split (PCGAN_SPLIT=bf16, the default before the fp16 route) and the fp32 MFMA implicit GEMM
         # (PCGAN_BF16X6=0, round 1's default) -- the A/B behind the default
         def rerun(what, switch):
+            _progress('re-timing on the route ' + switch)
             for i in range(args.warmup):
                 step(i)
             torch.cuda.synchronize()
@@ -431,7 +448,9 @@ def main():
         finally:
             ops.BF16X6, ops.HSPLIT = saved
     if world == 1 and not args.no_cpu_baseline:
+        _progress('cpu baseline')
         out['cpu_baseline'] = cpu_baseline()
+    _progress('done')
     print(json.dumps(out))
 
 

@@ -310,6 +310,14 @@ int pcgan_conv2d_bwd_weight_bsplit(const pcgan_conv_desc* d, const void* x, cons
  * pcgan_absmax_slots(n) = the count that keeps the pass bandwidth-bound.  Weight tensors use exactly 64 slots. */
 int pcgan_absmax_slots(size_t n);
 int pcgan_absmax(const void* x, size_t n, int dtype, float* out, int slots, pcgan_stream_t s);
+/* Audit of the maxima a tensor carries (the fp16 route trusts them: a claim that is too SMALL overflows an fp16 piece -- the
+ * non-finite sentinel below reports that; a claim that is too LARGE, e.g. after the tensor was rewritten with smaller values through
+ * `.data` / a raw pointer, pushes the low pieces into subnormals and loses bits silently).  claimed[0 .. n_claimed) = the attached
+ * partial maxima, fresh[0 .. n_fresh) = the partials of a pcgan_absmax pass over the tensor as it is now; both are maxima of the same
+ * stored values, so they must agree exactly.  counts (three device words owned by the caller): [0] += 1 if the tensor holds more than
+ * claimed, [1] += 1 if its largest value is below 2^-8 of the claim, [2] += 1 for any other mismatch.  One tiny launch; the host
+ * (hip/ops.py: amax_of) audits every n-th consumption of attached maxima (every one in the test suite). */
+int pcgan_amax_audit(const float* claimed, int n_claimed, const float* fresh, int n_fresh, unsigned int* counts, pcgan_stream_t s);
 int pcgan_conv2d_hsplit_supported(const pcgan_conv_desc* d, int pass);
 size_t pcgan_conv2d_hsplit_packed_bytes(const pcgan_conv_desc* d, int pass);
 int pcgan_conv2d_hsplit_pack(const pcgan_conv_desc* d, int pass, const float* w, void* packed, pcgan_stream_t s);

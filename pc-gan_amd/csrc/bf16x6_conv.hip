@@ -142,6 +142,27 @@ __global__ void __launch_bounds__(256) absmax_kernel(const TA* __restrict__ x, s
     if (threadIdx.x == 0) out[blockIdx.x] = m;
 }
 
+// Audit of operand maxima (round 4): `claimed` = the partial maxima a tensor carries (its producer's, or an earlier absmax pass),
+// `fresh` = the partials of an absmax pass made NOW.  Both are maxima over the same stored values, so their largest entries must be
+// EQUAL; counts[0] += 1 when the tensor holds a larger value than claimed (an fp16 piece would overflow), counts[1] += 1 when its
+// largest value is below 2^-8 of the claim (the scaled operand sits >= 8 bits under the fp16 target range: low pieces go subnormal and
+// precision is lost SILENTLY -- the case the non-finite sentinel cannot see), counts[2] += 1 for any other mismatch.
+__global__ void __launch_bounds__(256) amax_audit_kernel(const float* __restrict__ claimed, int nc, const float* __restrict__ fresh, int nf,
+                                                         unsigned* __restrict__ counts) {
+    __shared__ float red[16];
+    float c = 0.f, f = 0.f;
+    for (int i = threadIdx.x; i < nc; i += 256) c = fmaxf(c, claimed[i]);
+    for (int i = threadIdx.x; i < nf; i += 256) f = fmaxf(f, fresh[i]);
+    c = block_max(c, red);
+    __syncthreads();
+    f = block_max(f, red);
+    if (threadIdx.x == 0 && f != c) {
+        if (!(f <= c)) atomicAdd(counts + 0, 1u);                  // larger than claimed (or NaN)
+        else if (f < c * 0.00390625f) atomicAdd(counts + 1, 1u);    // under-scaled by 2^8 or more
+        else atomicAdd(counts + 2, 1u);
+    }
+}
+
 // largest magnitude of every ROW of a convolution's weight matrix, w[K][C][T]: by_c = 0 the rows of the forward GEMM (output channel k:
 // C * T contiguous values), by_c = 1 the rows of the data gradient (input channel c: K runs of T values).  One workgroup per row.
 __global__ void __launch_bounds__(256) weight_row_absmax_kernel(const float* __restrict__ w, int K, int C, int T, int by_c, float* __restrict__ out) {
@@ -1777,6 +1798,13 @@ extern "C" int pcgan_absmax(const void* x, size_t n, int dtype, float* out, int 
     const dim3 grid((unsigned)slots);
     if (dtype == PCGAN_BF16) hipLaunchKernelGGL(pcgan::absmax_kernel<pcgan::bf16>, grid, dim3(256), 0, st, (const pcgan::bf16*)x, n, out);
     else hipLaunchKernelGGL(pcgan::absmax_kernel<float>, grid, dim3(256), 0, st, (const float*)x, n, out);
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcgan_amax_audit(const float* claimed, int n_claimed, const float* fresh, int n_fresh, unsigned int* counts, pcgan_stream_t s) {
+    PCGAN_CHECK(claimed && fresh && counts && n_claimed > 0 && n_fresh > 0, "amax_audit: null pointer or empty maxima");
+    hipLaunchKernelGGL(pcgan::amax_audit_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, claimed, n_claimed, fresh, n_fresh, counts);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

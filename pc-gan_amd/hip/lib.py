@@ -99,6 +99,7 @@ SIGNATURES = {
     'pcgan_conv2d_bwd_weight_bsplit': (_i, [_dp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     'pcgan_absmax_slots': (_i, [_sz]),
     'pcgan_absmax': (_i, [_vp, _sz, _i, _vp, _i, _vp]),
+    'pcgan_amax_audit': (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     'pcgan_conv2d_hsplit_supported': (_i, [_dp, _i]),
     'pcgan_conv2d_hsplit_packed_bytes': (_sz, [_dp, _i]),
     'pcgan_conv2d_hsplit_pack': (_i, [_dp, _i, _vp, _vp, _vp]),

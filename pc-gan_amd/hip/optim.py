@@ -52,11 +52,17 @@ class FusedAdam(torch.optim.Optimizer):
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self._lr_host = float(lr)
         self._step_host = 0
+        self.updated = None       # event behind the last update when it ran on the gradient stream (step_on_grad_stream)
 
     def zero_grad(self, set_to_none=False):
         """Zero the flat gradient buffer (one memset) and keep every .grad a view into it so that
         autograd accumulates in place."""
-        ops.join_side_stream()
+        if self.updated is not None and self.gflat.is_cuda:
+            # the last update ran ON the parameter-gradient stream (behind every kernel that wrote these gradients): waiting for IT is
+            # enough -- a full join would stall this stream behind the other optimizer's weight gradients still in flight there
+            torch.cuda.current_stream(self.gflat.device).wait_event(self.updated)
+        else:
+            ops.join_side_stream()
         self.gflat.zero_()
         for p, gv in self._views:
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
@@ -74,9 +80,28 @@ class FusedAdam(torch.optim.Optimizer):
                     p.data = view
                 o += (n + _ALIGN - 1) // _ALIGN * _ALIGN
 
+    def step_on_grad_stream(self):
+        """The same update, queued on the parameter-gradient stream: behind the weight- / bias-gradient kernels that stream still holds
+        and behind everything the current stream has queued so far (gradients autograd accumulated there: BatchNorm's affine
+        parameters).  The current stream does NOT wait: it goes on with work that needs neither these gradients nor the new weights
+        (wsgan_emb: backward_D after the generator's update, the next step's forward after the discriminator's).  `self.updated` is the
+        event consumers of the new weights wait for.  Same kernel, same inputs, same order on that stream: bit-identical results."""
+        cur = torch.cuda.current_stream(self.flat.device)
+        side = ops.side_stream_for(cur)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self.step(_joined=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self.updated = ev
+        ops._side_state['dirty'] = True
+        return ev
+
     @torch.no_grad()
-    def step(self, closure=None):
-        ops.join_side_stream()            # parameter-gradient kernels run on a side stream
+    def step(self, closure=None, _joined=False):
+        if not _joined:
+            ops.join_side_stream(force=True)      # parameter-gradient kernels run on a side stream
+            self.updated = None
         g = self.param_groups[0]
         lr = float(g['lr'])
         if lr != self._lr_host:           # scheduler changed it (once per epoch)

@@ -122,15 +122,23 @@ class BaseModel(object):
         print('-----------------------------------------------')
 
     # ------------------------------------------------------------------ checkpoints
+    def sync_parameter_updates(self):
+        """order the current stream behind optimizer updates still queued on the parameter-gradient stream (hip/optim.py:
+        step_on_grad_stream) -- called wherever parameters are read outside the training step (checkpoints, visuals, tests)"""
+        if torch.cuda.is_available():
+            hip_ops.join_side_stream(force=True)
+
     def save_networks(self, which_epoch):
         if parallel.is_distributed() and torch.distributed.get_rank() != 0:
             return
+        self.sync_parameter_updates()
         os.makedirs(self.save_dir, exist_ok=True)
         for name, net in self._nets():
             weights = getattr(net, 'module', net).state_dict()
             torch.save(OrderedDict((k, v.detach().cpu()) for k, v in weights.items()), self._checkpoint(which_epoch, name))
 
     def load_networks(self, which_epoch):
+        self.sync_parameter_updates()
         for name, net in self._nets(self.load_model_names or self.model_names):
             net = getattr(net, 'module', net)
             path = self._checkpoint(which_epoch, name)

@@ -37,6 +37,12 @@ _G1_AHEAD = os.environ.get('PCGAN_G1_AHEAD', '1') == '1'
 # the AlexNet identity term on its own stream beside the discriminator branch: round 2's default; with the cross-step overlap four
 # streams then crowd the same phase of backward_G and the step is 4.5 % SLOWER (1093 vs 1143 img/s, same box) -> off
 _IP_BRANCH = os.environ.get('PCGAN_IP_BRANCH', '0') == '1'
+# Round 4: the two Adam updates run ON the parameter-gradient stream, behind the weight gradients, and the main stream does not join
+# that stream at the end of a backward pass (hip/ops.py: defer_side_join, hip/optim.py: step_on_grad_stream): backward_D starts while
+# the generator's last weight gradients and its update are still running, the next step's forward while the discriminator's are.
+# Consumers of the new weights wait for the update's event.  Single process only (under torch.distributed the all-reduce sits between
+# backward and update: the reference's order, kept until a multi-GPU record exists).  PCGAN_ADAM_ON_GRAD_STREAM=0: the main stream joins.
+_ADAM_ON_GRAD_STREAM = os.environ.get('PCGAN_ADAM_ON_GRAD_STREAM', '1') == '1'
 
 MAGIC_EPS = 1e-20
 
@@ -251,6 +257,8 @@ class WSGANEmbModel(BaseModel):
 
     def forward(self):
         o = self.opt
+        if self.isTrain:
+            self._wait_updated(self.optimizer_G)      # generator passes on this stream (and on branches forked from it): after its last update
         self.real_A_IP = upsample2d(self.real_A, o.fineSize_IP)
         frozen = o.lr_E <= 0.0
         # The frozen encoder's passes over the two real image sets depend on the batch and on the encoder's own state only (weights
@@ -304,6 +312,7 @@ class WSGANEmbModel(BaseModel):
             self._rec_branch = None
 
     def test(self):
+        self.sync_parameter_updates()
         self._g_updated = None
         if hasattr(self, 'real_B'):
             if 'real_B' not in self.visual_names:
@@ -314,12 +323,14 @@ class WSGANEmbModel(BaseModel):
                 self.fake_B = self.netG(self.real_A, self.embedding_B)
 
     def sample_from_prior(self):
+        self.sync_parameter_updates()
         self._g_updated = None
         y_B, _ = self._encode(upsample2d(self.real_B, self.opt.fineSize_E))
         self.embedding_B = self.embedding_normalize(y_B.detach())
         return self.netG(self.real_A, self.embedding_B)
 
     def sample_from_label(self, label):
+        self.sync_parameter_updates()
         self._g_updated = None
         emb_B = torch.Tensor([self.embedding_bins[label]]).reshape(1, 1, 1, 1).to(self.device)
         return self.netG(self.real_A, self.embedding_normalize(emb_B))
@@ -423,26 +434,49 @@ class WSGANEmbModel(BaseModel):
         else:
             self.loss_z_rec = self.criterionRec(pred_y, self.y_B) * o.lambda_z
 
+    def _on_grad_stream(self, optimizer):
+        """may this optimizer's update run on the parameter-gradient stream?  (the stock FusedAdam.step on a GPU, one process; an
+        instance-level `step` -- the tests' gradient grabbers -- takes the joined path and reads finished gradients)"""
+        return (_ADAM_ON_GRAD_STREAM and hip_ops.SIDE_STREAM and isinstance(optimizer, FusedAdam) and 'step' not in optimizer.__dict__
+                and optimizer.flat.is_cuda and not parallel.is_distributed())
+
+    def _step(self, optimizer, name):
+        if self._on_grad_stream(optimizer):
+            optimizer.step_on_grad_stream()
+        else:
+            hip_ops.join_side_stream(force=True)
+            parallel.sync_gradients(optimizer)
+            optimizer.step()
+        parallel.ddp_check(optimizer, name)
+
+    def _wait_updated(self, optimizer):
+        """the current stream reads this optimizer's parameters next: order it behind an update still queued on the gradient stream"""
+        ev = getattr(optimizer, 'updated', None)
+        if ev is not None and self.real_A.is_cuda:
+            torch.cuda.current_stream(self.real_A.device).wait_event(ev)
+
     def update_D(self):
         self.set_requires_grad(self.netD, True)
         self.optimizer_D.zero_grad()
-        self.backward_D()
-        parallel.sync_gradients(self.optimizer_D)
-        self.optimizer_D.step()
-        parallel.ddp_check(self.optimizer_D, 'D')
+        with hip_ops.defer_side_join(self._on_grad_stream(self.optimizer_D)):
+            self.backward_D()
+        self._step(self.optimizer_D, 'D')
 
     def update_G(self):
         self.set_requires_grad(self.netD, False)
         self.optimizer_G.zero_grad()
-        self.backward_G()
-        parallel.sync_gradients(self.optimizer_G)
-        self.optimizer_G.step()
-        parallel.ddp_check(self.optimizer_G, 'G')
+        self._wait_updated(self.optimizer_D)      # backward_G runs the discriminator: after its last update
+        with hip_ops.defer_side_join(self._on_grad_stream(self.optimizer_G)):
+            self.backward_G()
+        self._step(self.optimizer_G, 'G')
         self._mark_g_updated()
 
     def _mark_g_updated(self):
         """the point in the current stream after which the generator's weights are those of this update (forward(): G1 branch)"""
         if self.real_A.is_cuda:
+            if getattr(self.optimizer_G, 'updated', None) is not None:       # the update runs on the gradient stream: its own event
+                self._g_updated = self.optimizer_G.updated
+                return
             self._g_updated = torch.cuda.Event()
             self._g_updated.record(torch.cuda.current_stream(self.real_A.device))
 
@@ -473,6 +507,7 @@ class WSGANEmbModel(BaseModel):
 
     def get_current_visuals(self):
         self._join_rec()
+        self.sync_parameter_updates()
         self._g_updated = None      # generator passes outside the step move its running statistics: the next forward() queues behind them
         self.set_requires_grad(self.netG, False)
         ret = OrderedDict()

@@ -30,14 +30,24 @@ def dev():
 @pytest.fixture(autouse=True)
 def _fp16_route_never_overflows(request):
     """After EVERY GPU test: no fp16-route convolution may have produced inf / NaN (hip/ops.py: the non-finite sentinel) -- a
-    stale operand maximum would overflow an fp16 piece and poison its results silently otherwise."""
+    stale operand maximum would overflow an fp16 piece and poison its results silently otherwise -- and no audited operand maximum
+    may differ from the tensor it is attached to (round 4: the too-LARGE direction loses precision without any inf)."""
+    gpu = request.node.get_closest_marker('gpu') is not None
+    if gpu:
+        import torch
+        if torch.cuda.is_available():
+            from pcgan_amd.hip import ops
+            if 'PCGAN_AMAX_AUDIT' not in os.environ:
+                ops.AMAX_AUDIT_EVERY = 1        # the suite audits EVERY consumption of attached operand maxima (production: every 64th)
     yield
-    if request.node.get_closest_marker('gpu') is None:
+    if not gpu:
         return
     import torch
     if not torch.cuda.is_available():
         return
     from pcgan_amd.hip import ops
     n = ops.nonfinite_count()
+    stale = ops.stale_maxima_count()
     if request.node.get_closest_marker('allow_nonfinite') is None:
         assert n == 0, '%d wave(s) of fp16-route kernels produced inf / NaN during this test' % n
+        assert stale == (0, 0, 0), 'operand maxima that no longer describe their tensor (too small, too large, other): %r' % (stale,)

@@ -89,7 +89,9 @@ def test_kernels_are_bit_stable_beside_f16_mfma_kernels(dev):
 def test_cross_step_overlap_changes_nothing(tmp_path, dev, monkeypatch):
     """Round 3's cross-step overlap (models/wsgan_emb_model.py: forward): the frozen encoder's passes over the new batch, the generator's
     first pass (G1) and its second pass (G2) run on their own streams behind the events of their inputs, beside the previous step's
-    backward_D / Adam.  Same kernels in the same per-net order, so six optimize_parameters() at the benchmark's network sizes (bs 8,
+    backward_D / Adam.  Round 4 adds: both Adam updates queued ON the parameter-gradient stream (FusedAdam.step_on_grad_stream) with no
+    join at the end of a backward pass -- backward_D starts under the generator's last weight gradients, the next forward under the
+    discriminator's; consumers wait for the update's event.  Same kernels in the same per-net order, so six optimize_parameters() at the benchmark's network sizes (bs 8,
     resident batches as in bench.py) must end in the SAME BITS with the overlap on (twice: run-to-run) and with every stream switched
     off: weights of G and D, the encoder's running statistics, the last losses and images."""
     import bench
@@ -100,6 +102,7 @@ def test_cross_step_overlap_changes_nothing(tmp_path, dev, monkeypatch):
         monkeypatch.setattr(W, '_E_AHEAD', overlap)
         monkeypatch.setattr(W, '_G1_AHEAD', overlap)
         monkeypatch.setattr(W, '_G2_BRANCH', overlap)
+        monkeypatch.setattr(W, '_ADAM_ON_GRAD_STREAM', overlap)      # round 4: the Adam updates on the parameter-gradient stream, no join after backward
         monkeypatch.setattr(ops, 'BRANCH_STREAMS', overlap)
         torch.manual_seed(7)
         d = tmp_path / ('o%d_%d' % (overlap, len(list(tmp_path.iterdir()))))

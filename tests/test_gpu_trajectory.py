@@ -1,0 +1,85 @@
+"""A training TRAJECTORY as the stand-in for the FID gate.
+
+The north star asks for "FID within +-1.0 of the reference after equal training iterations"; Inception weights cannot be fetched
+here, so the gate itself stays open.  What CAN be shown is that the HIP step trains like the reference's step over many
+iterations WITHOUT re-aligning parameters in between (tests/test_gpu_step.py compares two iterations and re-aligns: Adam turns the
+sign of rounding noise on zero-gradient parameters into +-lr moves, so trajectories part by O(lr) per step): 30 consecutive
+optimize_parameters() -- reference train.py:28-36 semantics: set_input, optimize_parameters, per step -- of the tiny fixture
+(9-block G ngf 8, 3-layer PatchGAN, ResNet-18 E, AlexNet IP; batch 4, 32x32; a different seeded batch and label set every step;
+no random draws in the default variant) on the HIP path and on the oracle from the same weights.
+
+Stated bands (measured values are printed):
+  * every loss, mean absolute deviation over steps 10-30 <= 2 % of that loss's mean magnitude over the window + 2e-3,
+  * mean D(fake) and mean D(real) over the window within 2 % (relative) of the oracle's,
+  * no loss diverging: every HIP loss finite and <= 4 x the oracle's maximum of that loss (+ 1.0),
+  * the trajectories really are un-realigned: parameters differ between the two sides at the end (by O(steps x lr), not by O(1)).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.make_golden import step_batch
+from test_oracle_golden import build_oracle_step
+
+pytestmark = pytest.mark.gpu
+STEPS, WINDOW = 30, slice(10, 30)
+BAND_REL, BAND_ABS = 2e-2, 2e-3
+
+
+def _batch(it):
+    b = step_batch('default', it)
+    g = torch.Generator().manual_seed(9000 + it)
+    b['label'] = torch.randint(0, 3, (4,), generator=g)
+    return b
+
+
+@pytest.mark.timeout(900)
+def test_thirty_unaligned_steps_track_the_oracle(tmp_path, dev):
+    from test_gpu_step import build_hip_model
+    model, opt = build_hip_model('default', tmp_path)
+    oracle = build_oracle_step('default')
+    names = list(oracle.LOSS_NAMES)
+    hip_l, ref_l, hip_d, ref_d = [], [], [], []
+    for it in range(STEPS):
+        b = _batch(it)
+        oracle.set_input(b['A'], b['B'], [int(v) for v in b['label']])
+        oracle.optimize_parameters()
+        model.set_input(b)
+        model.optimize_parameters()
+        hl, rl = model.get_current_losses(), oracle.losses()
+        hip_l.append([hl[n] for n in names])
+        ref_l.append([rl[n] for n in names])
+        with torch.no_grad():       # mean discriminator outputs on this step's fake / real images (train-mode BatchNorm on both sides)
+            hip_d.append([float(model.netD(model.fake_B.detach(), model.embedding_B).float().mean()),
+                          float(model.netD(model.real_B, model.embedding_B).float().mean())])
+            ref_d.append([float(oracle.netD(oracle.fake_B.detach(), oracle.embedding_B).mean()),
+                          float(oracle.netD(oracle.real_B, oracle.embedding_B).mean())])
+    hip_l, ref_l, hip_d, ref_d = (np.asarray(a, dtype=np.float64) for a in (hip_l, ref_l, hip_d, ref_d))
+    assert np.isfinite(hip_l).all(), 'a HIP loss went non-finite'
+    report, problems = [], []
+    np.set_printoptions(precision=5, suppress=True, linewidth=200)
+    for j, n in enumerate(names):
+        mad = float(np.abs(hip_l[WINDOW, j] - ref_l[WINDOW, j]).mean())
+        mag = float(np.abs(ref_l[WINDOW, j]).mean())
+        report.append('%s %.2e (of %.3g)' % (n, mad, mag))
+        print('loss %-14s hip    %s\n%19s oracle %s' % (n, hip_l[:, j], '', ref_l[:, j]))
+        if not mad <= BAND_REL * mag + BAND_ABS:
+            problems.append('loss %s: mean |hip - oracle| over steps 10-30 = %.3e (mean magnitude %.3e)' % (n, mad, mag))
+        if not hip_l[:, j].max() <= 4.0 * ref_l[:, j].max() + 1.0:
+            problems.append('loss %s diverges: hip max %.4g, oracle max %.4g' % (n, hip_l[:, j].max(), ref_l[:, j].max()))
+    for j, n in enumerate(('D(fake)', 'D(real)')):
+        h, r = float(hip_d[WINDOW, j].mean()), float(ref_d[WINDOW, j].mean())
+        report.append('%s %.5f / %.5f' % (n, h, r))
+        print('%-19s hip    %s\n%19s oracle %s' % (n, hip_d[:, j], '', ref_d[:, j]))
+        if not abs(h - r) <= 2e-2 * abs(r):
+            problems.append('mean %s over steps 10-30: hip %.5f vs oracle %.5f' % (n, h, r))
+    print('trajectory (mean |hip - oracle| over steps 10-30 per loss; D means hip / oracle): ' + '; '.join(report))
+    assert not problems, problems
+    # un-realigned: the two sides hold DIFFERENT parameters by now (sign noise on zero-gradient parameters, amplified by Adam), but
+    # only by O(steps x lr)
+    hp = torch.cat([p.detach().reshape(-1).cpu() for p in model.netG.parameters()])
+    rp = torch.cat([p.detach().reshape(-1) for p in oracle.netG.parameters()])
+    gap = float((hp - rp).abs().max())
+    report.append('max |theta_G hip - oracle| after %d steps %.2e' % (STEPS, gap))
+    assert 0.0 < gap <= 4 * STEPS * 2e-4, 'generator parameters apart by %.3e after %d un-realigned steps (lr 2e-4)' % (gap, STEPS)
+    print('trajectory (mean |hip - oracle| over steps 10-30 per loss; D means hip / oracle): ' + '; '.join(report))
