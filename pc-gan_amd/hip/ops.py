@@ -212,15 +212,21 @@ class branch(object):
                     t.record_stream(self.cur)
 
 
-_upload = {}
-
-
 def upload_stream(device):
-    """the stream input batches are copied / cast on (base_model.to_act): not ordered behind the step still running on the main stream"""
+    """the stream input batches are copied / cast on (base_model.to_act): not ordered behind the step still running on the main stream.
+    It IS the encoder's branch stream ('E'): the frozen encoder's passes over the new batch are the first consumers of an upload and wait
+    for nothing else, and a stream of its own is not free on this runtime -- HIP streams are mapped onto a few hardware queues (4 by
+    default), streams that share a queue serialise, and WHICH streams share one follows from the set of streams in use: round 4
+    measured the same step at 1200 img/s without a dedicated upload stream and 1062 img/s with one (the generator's ahead-of-step pass
+    and the parameter-gradient stream then shared a queue), and 750 img/s with GPU_MAX_HW_QUEUES=8 (everything concurrent: the matrix
+    kernels of four streams thrash the chip) -- profiles/r04_experiments.txt."""
     device = torch.device(device)
-    st = _upload.get(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    key = (device, 'E')
+    st = _branch.get(key)
     if st is None:
-        st = _upload[device] = torch.cuda.Stream(device=device)
+        st = _branch[key] = torch.cuda.Stream(device=device)
     return st
 
 

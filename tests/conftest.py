@@ -8,7 +8,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _cap_cpu_threads():
+    """the oracle side of every parity test is stock PyTorch on the CPU: on a GPU box torch defaults to all 128 hardware threads of
+    the host while the container's share is ~16 -- the oversubscribed pool made the oracle steps several times slower (round 4: the
+    30-step trajectory test took 4:44 min, most of it in the CPU oracle).  Cap the pool at the usable CPUs (at most 16)."""
+    try:
+        import torch
+        sys.path.insert(0, ROOT)
+        import bench
+        n, _ = bench.host_cpu_budget()
+        torch.set_num_threads(max(1, min(16, n)))
+    except Exception:      # noqa: BLE001  (a convenience, never a reason to fail collection)
+        pass
+
+
 def pytest_configure(config):
+    _cap_cpu_threads()
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'allow_nonfinite: the test feeds inf / NaN (or a stale operand maximum) to an fp16-route kernel on purpose')
 

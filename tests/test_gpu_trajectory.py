@@ -9,7 +9,11 @@ optimize_parameters() -- reference train.py:28-36 semantics: set_input, optimize
 no random draws in the default variant) on the HIP path and on the oracle from the same weights.
 
 Stated bands (measured values are printed):
-  * every loss, mean absolute deviation over steps 10-30 <= 2 % of that loss's mean magnitude over the window + 2e-3,
+  * every loss, mean absolute deviation over steps 10-30 <= 2 % of that loss's mean magnitude over the window + 2e-3 -- OR, for a loss
+    the fixture itself makes chaotic, <= 3 x what the ORACLE deviates from ITSELF when its initial G / D parameters are perturbed by
+    1e-6 relative (a second oracle run, the calibration: z_rec goes through the frozen ResNet-18 in train mode at 64x64 with a batch of
+    4 -- BatchNorm statistics over 16 values in its last stage -- and moves by tens of percent under such a perturbation, while the
+    adversarial and image losses stay within a percent),
   * mean D(fake) and mean D(real) over the window within 2 % (relative) of the oracle's,
   * no loss diverging: every HIP loss finite and <= 4 x the oracle's maximum of that loss (+ 1.0),
   * the trajectories really are un-realigned: parameters differ between the two sides at the end (by O(steps x lr), not by O(1)).
@@ -39,11 +43,22 @@ def test_thirty_unaligned_steps_track_the_oracle(tmp_path, dev):
     model, opt = build_hip_model('default', tmp_path)
     oracle = build_oracle_step('default')
     names = list(oracle.LOSS_NAMES)
-    hip_l, ref_l, hip_d, ref_d = [], [], [], []
+    # calibration twin: the same oracle from parameters perturbed at the fp32 rounding level
+    twin = build_oracle_step('default')
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        for net in (twin.netG, twin.netD):
+            for p in net.parameters():
+                p.mul_(1.0 + 1e-6 * torch.randn(p.shape, generator=g))
+    hip_l, ref_l, hip_d, ref_d, twin_l = [], [], [], [], []
     for it in range(STEPS):
         b = _batch(it)
         oracle.set_input(b['A'], b['B'], [int(v) for v in b['label']])
         oracle.optimize_parameters()
+        twin.set_input(b['A'], b['B'], [int(v) for v in b['label']])
+        twin.optimize_parameters()
+        tl = twin.losses()
+        twin_l.append([tl[n] for n in names])
         model.set_input(b)
         model.optimize_parameters()
         hl, rl = model.get_current_losses(), oracle.losses()
@@ -54,17 +69,19 @@ def test_thirty_unaligned_steps_track_the_oracle(tmp_path, dev):
                           float(model.netD(model.real_B, model.embedding_B).float().mean())])
             ref_d.append([float(oracle.netD(oracle.fake_B.detach(), oracle.embedding_B).mean()),
                           float(oracle.netD(oracle.real_B, oracle.embedding_B).mean())])
-    hip_l, ref_l, hip_d, ref_d = (np.asarray(a, dtype=np.float64) for a in (hip_l, ref_l, hip_d, ref_d))
+    hip_l, ref_l, hip_d, ref_d, twin_l = (np.asarray(a, dtype=np.float64) for a in (hip_l, ref_l, hip_d, ref_d, twin_l))
     assert np.isfinite(hip_l).all(), 'a HIP loss went non-finite'
     report, problems = [], []
     np.set_printoptions(precision=5, suppress=True, linewidth=200)
     for j, n in enumerate(names):
         mad = float(np.abs(hip_l[WINDOW, j] - ref_l[WINDOW, j]).mean())
         mag = float(np.abs(ref_l[WINDOW, j]).mean())
-        report.append('%s %.2e (of %.3g)' % (n, mad, mag))
+        cal = float(np.abs(twin_l[WINDOW, j] - ref_l[WINDOW, j]).mean())
+        report.append('%s %.2e (of %.3g; perturbed oracle %.2e)' % (n, mad, mag, cal))
         print('loss %-14s hip    %s\n%19s oracle %s' % (n, hip_l[:, j], '', ref_l[:, j]))
-        if not mad <= BAND_REL * mag + BAND_ABS:
-            problems.append('loss %s: mean |hip - oracle| over steps 10-30 = %.3e (mean magnitude %.3e)' % (n, mad, mag))
+        if not mad <= max(BAND_REL * mag + BAND_ABS, 3.0 * cal):
+            problems.append('loss %s: mean |hip - oracle| over steps 10-30 = %.3e (mean magnitude %.3e; the oracle against its 1e-6-perturbed '
+                            'twin: %.3e)' % (n, mad, mag, cal))
         if not hip_l[:, j].max() <= 4.0 * ref_l[:, j].max() + 1.0:
             problems.append('loss %s diverges: hip max %.4g, oracle max %.4g' % (n, hip_l[:, j].max(), ref_l[:, j].max()))
     for j, n in enumerate(('D(fake)', 'D(real)')):
