@@ -14,11 +14,13 @@
  *     `void*` of the storage type named by the call's `dtype` argument / the descriptor's `dtype` field (PCGAN_F32 or
  *     PCGAN_BF16); everything typed `float*` -- parameters, parameter gradients, biases, statistics, losses, optimizer
  *     state -- is fp32 in either mode, and all arithmetic accumulates in fp32.
- *   - no hidden allocation, no device synchronisation, no global mutable state:
- *     the caller provides the workspace (query *_workspace_bytes first) and the
- *     hipStream_t (torch.cuda.current_stream().cuda_stream); every launch is
- *     asynchronous on that stream, so calls are graph-capturable and may run
- *     concurrently on distinct streams.
+ *   - no hidden allocation, no device synchronisation, NO ENVIRONMENT VARIABLES (round 4: the 14 getenv reads of round 3
+ *     are gone): the caller provides the workspace (query *_workspace_bytes first) and the hipStream_t
+ *     (torch.cuda.current_stream().cuda_stream); every launch is asynchronous on that stream, so calls are
+ *     graph-capturable and may run concurrently on distinct streams.  The library's ENTIRE process-global state is the three
+ *     items declared at the end of this header, each set only by an explicit call: the routing options (pcgan_set_option:
+ *     five integers with measured-best defaults), the non-finite sentinel pointer (pcgan_set_nonfinite_counter) and the
+ *     measurement-only kernel timer (pcgan_timer_enable).  Nothing else is mutable between calls.
  *   - return value 0 = ok; non-zero = error, text via pcgan_last_error()
  *     (thread-local).  The Python side turns non-zero into RuntimeError.
  */
@@ -425,12 +427,23 @@ int pcgan_conv2d_bwd_data_thin(const pcgan_conv_desc* d, const void* dy, const f
  * (kind 0 forward, 1 data gradient, 2 weight gradient incl. its padded copy and reduce, 3 the weight gradient's main kernel),
  * whichever entry point issued them.  pcgan_timer_enable(capacity) creates `capacity` event pairs per kind and switches recording on
  * (0: off, events destroyed); pcgan_timer_read waits for the recorded pairs of one kind, writes their durations in ms (at most cap) and
- * resets that kind; returns the count or -1.  The only global state of the library; off by default, never records inside a graph capture. */
+ * resets that kind; returns the count or -1.  Off by default, never records inside a graph capture. */
 /* Non-finite sentinel of the fp16 two-piece route: the kernels that scale their operands by a device-side maximum count the waves that
  * produced an inf / NaN result into *dev_word (a device word the caller owns and zeroes; NULL switches the sentinel off).  An operand
  * element above the maximum its scale came from -- a stale maximum -- overflows fp16 and poisons everything it touches, so a non-zero
  * count means "stale operand maxima or non-finite inputs"; the host checks it where it synchronises anyway. */
 int pcgan_set_nonfinite_counter(unsigned int* dev_word);
+/* Routing options below the C-ABI (A/B measurement; the defaults are the measured-best settings and need no call).  Set before the
+ * calls they affect; *_supported / *_workspace_bytes queries follow the current values.
+ *   "bsplit_halo"   1  residual convolutions (3x3 reflect, width 32 / 64) on the window kernel; 0: per-tap gather kernel
+ *   "wgrad_gen"     1  weight gradients with zero padding <= 1 apply the padding inside the gather; 0: padded copy of x
+ *   "wgrad_padcopy" 0  1: the residual blocks' weight gradient reads a reflection-padded copy of x (round 2's form)
+ *   "wgrad_cw"      0  columns per workgroup of the matrix-pipe weight gradient: 0 = as measured (128 for fp32 tensors, 256 for bf16),
+ *                      128 / 256 force one form
+ *   "hgemm_bf16"    1  bf16 tensors on the one-product bf16 MFMA form of the packed implicit GEMM; 0: fp32 MFMA kernels
+ * Unknown keys / values return non-zero. */
+int pcgan_set_option(const char* key, int value);
+int pcgan_get_option(const char* key, int* value);
 int pcgan_timer_enable(int capacity);
 int pcgan_timer_read(int kind, float* ms, int cap);
 

@@ -1516,15 +1516,9 @@ static void launch_bsplit(const pcgan_conv_desc* d, int bm, dim3 grid, hipStream
     }
 }
 
-// the halo kernel takes a layer when a pixel tile is whole image rows and the chunks come in pairs; PCGAN_BSPLIT_HALO=0 keeps
+// the halo kernel takes a layer when a pixel tile is whole image rows and the chunks come in pairs; option "bsplit_halo" = 0 keeps
 // every layer on the per-tap gather kernel (A/B measurement)
-static bool halo_enabled() {
-    static const int on = [] {
-        const char* e = getenv("PCGAN_BSPLIT_HALO");
-        return e && e[0] == '0' ? 0 : 1;
-    }();
-    return on != 0;
-}
+static bool halo_enabled() { return option(OPT_BSPLIT_HALO) != 0; }
 static bool halo_geometry(int chan, int rows_out, int H, int W) {
     return (W == 32 || W == 64) && H >= 4 && H % (128 / W) == 0 && chan % 32 == 0 && rows_out % 256 == 0;
 }
@@ -1884,17 +1878,16 @@ extern "C" int pcgan_conv2d_bwd_data_hsplit_add(const pcgan_conv_desc* d, const 
 // weight gradient on the fp16 route (fp32 tensors) / bf16 route (bf16 tensors): padded copy of x (workspace), the kernel above over
 // splits of the pixel reduction, reduce
 // the general form of the kernel (GEN): zero padding of at most 1 applied inside the gather (no padded copy), ragged output width, row
-// tiles.  PCGAN_WGRAD_GEN=0 keeps the padded copy (A/B measurement; the ragged widths and K > 256 then leave this route)
+// tiles.  Option "wgrad_gen" = 0 keeps the padded copy (A/B measurement; the ragged widths and K > 256 then leave this route)
 static bool hsplit_wgrad_gen(const pcgan_conv_desc* d) {
-    static const bool on = [] { const char* e = getenv("PCGAN_WGRAD_GEN"); return !(e && e[0] == '0'); }();
-    if (!on || d->pad_mode != 0 || d->pad > 1) return false;
+    if (!pcgan::option(pcgan::OPT_WGRAD_GEN) || d->pad_mode != 0 || d->pad > 1) return false;
     return d->dtype == PCGAN_F32 || d->dtype == PCGAN_BF16;      // (bf16 tensors with ragged rows: element loads of dy, rows start on 2-byte boundaries)
 }
 
 extern "C" int pcgan_conv2d_hsplit_wgrad_inline(const pcgan_conv_desc* d) {
     if (!d || !pcgan_conv2d_hsplit_wgrad_supported(d)) return 0;
     const bool inline_reflect = d->stride == 1 && d->pad_mode == 1 && d->pad == 1 && d->R == 3 && d->S == 3 && d->H >= 2 &&
-                                d->W >= 16 && d->P == d->H && d->Q == d->W && getenv("PCGAN_WGRAD_PADCOPY") == nullptr;
+                                d->W >= 16 && d->P == d->H && d->Q == d->W && !pcgan::option(pcgan::OPT_WGRAD_PADCOPY);
     return (inline_reflect || d->pad == 0 || hsplit_wgrad_gen(d)) ? 1 : 0;
 }
 
@@ -1913,19 +1906,16 @@ extern "C" int pcgan_conv2d_hsplit_wgrad_supported(const pcgan_conv_desc* d) {
            d->N * d->C <= 65535;
 }
 
-static inline int hsplit_wgrad_bm(const pcgan_conv_desc* d) {
-    static const int force = [] { const char* e = getenv("PCGAN_WGRAD_BM"); return e ? atoi(e) : 0; }();      // experiments: 128
-    return (d->K > 128 && force != 128) ? 256 : 128;
-}
+static inline int hsplit_wgrad_bm(const pcgan_conv_desc* d) { return d->K > 128 ? 256 : 128; }
 
 // 256 columns per workgroup with the 256-row tile when that still leaves at least 8 column tiles: the dy tile is loaded, split and
 // written to LDS once for 256 columns and a wave's 64 x 128 tile needs 12 LDS operand reads for 24 MFMAs instead of 8 for 12.
 // bf16 tensors since round 2 (26.5 -> 26.0 ms per bf16 step).  fp32 tensors: the kernel ALONE gains (238 VGPRs, no spills: residual
 // shape 0.153 -> 0.139 ms incl. the reduce of twice as many split partials), the STEP loses 1 % (1206 -> 1194 img/s, three interleaved
 // pairs on one box: beside the data-gradient kernel of the main stream the wide workgroups take 0.292 instead of 0.277 ms and the
-// parameter-gradient stream is the longer one) -- so fp32 tensors keep 128 columns; PCGAN_WGRAD_CW=256 selects the wide form (A/B).
+// parameter-gradient stream is the longer one) -- so fp32 tensors keep 128 columns; option "wgrad_cw" = 256 selects the wide form (A/B).
 static inline int hsplit_wgrad_cw(const pcgan_conv_desc* d) {
-    static const int force = [] { const char* e = getenv("PCGAN_WGRAD_CW"); return e ? atoi(e) : 0; }();      // 256: fp32 too; 128: bf16 too
+    const int force = pcgan::option(pcgan::OPT_WGRAD_CW);      // 0: as measured best; 256: fp32 too; 128: bf16 too
     const bool wide = (d->dtype == PCGAN_BF16 && force != 128) || (d->dtype == PCGAN_F32 && d->pad_mode == 1 && force == 256);
     return wide && hsplit_wgrad_bm(d) == 256 && d->C * d->R * d->S >= 8 * 256 ? 256 : 128;
 }
@@ -1971,7 +1961,7 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     const void* xin = x;
     // the residual-block shape (fp32, 3x3, stride 1, reflection padding 1): the mirror is applied inside the gather, no padded copy
     const bool inline_reflect = d->stride == 1 && d->pad_mode == 1 && d->pad == 1 && d->R == 3 && d->S == 3 && d->H >= 2 && d->W >= 16 &&
-                                d->P == d->H && d->Q == d->W && getenv("PCGAN_WGRAD_PADCOPY") == nullptr;
+                                d->P == d->H && d->Q == d->W && !pcgan::option(pcgan::OPT_WGRAD_PADCOPY);
     int Hx = Hp, Wx = Wp;
     if (inline_reflect || gen) {
         Hx = d->H;

@@ -96,6 +96,32 @@ extern "C" int pcgan_set_nonfinite_counter(unsigned int* dev_word) {
     return 0;
 }
 
+namespace pcgan {
+static const char* const g_opt_names[OPT_COUNT] = {"bsplit_halo", "wgrad_gen", "wgrad_padcopy", "wgrad_cw", "hgemm_bf16"};
+static std::atomic<int> g_opt[OPT_COUNT] = {{1}, {1}, {0}, {0}, {1}};
+int option(int id) { return (id >= 0 && id < OPT_COUNT) ? g_opt[id].load(std::memory_order_relaxed) : 0; }
+static int option_index(const char* key) {
+    for (int i = 0; key && i < OPT_COUNT; ++i)
+        if (strcmp(key, g_opt_names[i]) == 0) return i;
+    return -1;
+}
+}  // namespace pcgan
+extern "C" int pcgan_set_option(const char* key, int value) {
+    using namespace pcgan;
+    const int i = option_index(key);
+    PCGAN_CHECK(i >= 0, "set_option: unknown option '%s' (bsplit_halo, wgrad_gen, wgrad_padcopy, wgrad_cw, hgemm_bf16)", key ? key : "(null)");
+    PCGAN_CHECK(i != OPT_WGRAD_CW || value == 0 || value == 128 || value == 256, "set_option: wgrad_cw takes 0 (default), 128 or 256, got %d", value);
+    g_opt[i].store(value);
+    return 0;
+}
+extern "C" int pcgan_get_option(const char* key, int* value) {
+    using namespace pcgan;
+    const int i = option_index(key);
+    PCGAN_CHECK(i >= 0 && value, "get_option: unknown option or null output");
+    *value = g_opt[i].load();
+    return 0;
+}
+
 extern "C" const char* pcgan_last_error(void) { return pcgan::g_err; }
 extern "C" int pcgan_version(void) { return 100; }
 

@@ -45,6 +45,12 @@ static inline int timer_kind_res(const pcgan_conv_desc* d, int kind) {
     return (d && d->K == 256 && d->C == 256 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad_mode == 1 && d->pad == 1) ? kind : -1;
 }
 
+// ---- routing options (include/pcgan_hip.h: pcgan_set_option) ------------------------------------------------------------------------
+// The library reads NO environment variables (round 4): the few A/B switches that live below the C-ABI are explicit options with
+// measured-best defaults, set by the host through pcgan_set_option(key, value) before the calls they affect.
+enum { OPT_BSPLIT_HALO = 0, OPT_WGRAD_GEN = 1, OPT_WGRAD_PADCOPY = 2, OPT_WGRAD_CW = 3, OPT_HGEMM_BF16 = 4, OPT_COUNT = 5 };
+int option(int id);
+
 // ---- non-finite sentinel of the fp16 route --------------------------------------------------------------------------------------------
 // An operand element larger than the maximum its scale was derived from (a stale `_pcgan_amax`: the tensor was rewritten behind the
 // host's back) overflows its fp16 piece to inf, and every product it enters becomes inf / NaN.  The epilogues of the fp16-route kernels

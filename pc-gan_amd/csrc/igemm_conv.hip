@@ -2401,17 +2401,11 @@ static int check_desc(const pcgan_conv_desc* d) {
 static inline bool chunked_k(int Cg, int M, int R, int S) { return (Cg % 16) == 0 && M > 4 && R * S <= NTAP_FWD; }
 // 4-channel stages (igemm2_kernel<.., 4>): 3-/4-channel gathered tensor, MFMA path, taps fit the table; weights stay in
 // the generic (tap, channel) order
-static inline bool cg4_k(int Cg, int M, int R, int S) {
-    static const bool off = getenv("PCGAN_NO_CG4") != nullptr;   // A/B experiments
-    return !off && round4(Cg) == 4 && M > 4 && R * S <= NTAP_CG4;
-}
+static inline bool cg4_k(int Cg, int M, int R, int S) { return round4(Cg) == 4 && M > 4 && R * S <= NTAP_CG4; }
 static inline long tile_blocks(int M, int ptot_max, int nphase, int mm, int pp) {
     return (long)((M + mm - 1) / mm) * ((ptot_max + pp - 1) / pp) * nphase;
 }
-static inline long split_below() {     // tiles (BP = 128) below which a long-K layer is cut along K; PCGAN_SPLIT_BELOW: experiments
-    static const long v = getenv("PCGAN_SPLIT_BELOW") ? atol(getenv("PCGAN_SPLIT_BELOW")) : 192;
-    return v;
-}
+static inline long split_below() { return 192; }     // tiles (BP = 128) below which a long-K layer is cut along K (profiles/r01_tile_sweep.txt)
 static inline bool may_split(int M, int ptot_max, int nphase) {
     const int m = M > 64 ? 128 : (M > 32 ? 64 : 32);
     return M > 4 && tile_blocks(M, ptot_max, nphase, m, 128) < split_below();
@@ -2434,15 +2428,6 @@ static void choose_tile(int M, int ptot_max, int nphase, int nst, bool allow_spl
     }
     if (m >= 64 && tile_blocks(M, ptot_max, nphase, m, p) < 384) p = 64;
     if (m == 128 && tile_blocks(M, ptot_max, nphase, m, p) < 384) m = 64;
-    const char* env = getenv("PCGAN_TILE");  // experiments: "BM,BP"
-    if (env) {
-        int em = 0, ep = 0;
-        if (sscanf(env, "%d,%d", &em, &ep) == 2 && (em == 128 || em == 64 || em == 32) && (ep == 128 || ep == 64) &&
-            !(em == 32 && ep == 64) && em <= (M > 64 ? 128 : (M > 32 ? 64 : 32))) {
-            m = em;
-            p = ep;
-        }
-    }
     *bm = m;
     *bp = p;
 }
@@ -2466,8 +2451,7 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
             }
             constexpr int SMODE = MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE;
             const bool unit = SMODE == MODE_BWD || (a.sl == 0 && a.ostep == 1);
-            static const bool no_strip = getenv("PCGAN_NO_STRIP") != nullptr;   // A/B experiments
-            if (unit && maxR >= 3 && maxR <= 7 && minH >= 8 && !no_strip) {   // (1-2 row taps: nothing to reuse)
+            if (unit && maxR >= 3 && maxR <= 7 && minH >= 8) {   // (1-2 row taps: nothing to reuse)
                 // few strips but many channels (the last PatchGAN conv, 512 -> 1 on 14x14): cut the channels over blockIdx.z
                 const int wgs = ((maxstrips + 63) / 64) * a.nphase;
                 int ks = 1;
@@ -2528,9 +2512,8 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, float* part_ws = nullptr, 
             PCGAN_CHECK(a.ph[i].nR * a.ph[i].nS <= (MODE == MODE_BWD_REFLECT ? NTAP_MIR : NTAP_FWD) && (a.ph[i].Kp % 16) == 0,
                         "igemm: chunked K order: bad phase");
     }
-    // bf16 tensors take the one-product bf16 MFMA form of the kernel whenever the shape allows (PCGAN_HGEMM=0: the fp32 MFMA kernels)
-    static const bool hgemm_bf16 = [] { const char* e = getenv("PCGAN_HGEMM"); return !(e && e[0] == '0'); }();
-    const bool half = a.dtype == PCGAN_BF16 && hgemm_bf16;
+    // bf16 tensors take the one-product bf16 MFMA form of the kernel whenever the shape allows (option "hgemm_bf16" = 0: the fp32 MFMA kernels)
+    const bool half = a.dtype == PCGAN_BF16 && option(OPT_HGEMM_BF16) != 0;
     if ((half || (a.hsplit && a.dtype == PCGAN_F32)) && cg16 && MODE != MODE_BWD_REFLECT && bm >= 64) {
         // fp16 two-piece form (fp32 tensors) / bf16 form (bf16 tensors) of the same launch: same tiles, phases, K splits
         constexpr int HMODE = MODE == MODE_BWD_REFLECT ? MODE_BWD : MODE;
@@ -2566,8 +2549,7 @@ static inline bool smallm_wgrad(const pcgan_conv_desc* d) { return d->K <= 4 && 
 
 // strip weight-gradient kernel: <= 3 output channels, stride 1, <= 7x7 taps, columns long enough for 8-pixel strips
 static inline bool smallm_wgrad_strip(const pcgan_conv_desc* d) {
-    static const bool off = getenv("PCGAN_NO_STRIP") != nullptr;
-    return !off && d->K <= 3 && d->stride == 1 && d->R <= 7 && d->S <= 7 && d->R >= 3 && d->P >= 16 && d->C >= 16;
+    return d->K <= 3 && d->stride == 1 && d->R <= 7 && d->S <= 7 && d->R >= 3 && d->P >= 16 && d->C >= 16;
 }
 
 static int wgrad_splits(const pcgan_conv_desc* d, int* chunks_per_split) {
@@ -2607,10 +2589,7 @@ static int wgrad_splits(const pcgan_conv_desc* d, int* chunks_per_split) {
         slots = 2 * cus;
     }
     int splits = 1;
-    if (const char* env = getenv("PCGAN_WGRAD_BLOCKS")) {   // experiments: explicit workgroup target
-        const int target = atoi(env) > 0 ? atoi(env) : 1024;
-        splits = target / tiles > 0 ? target / tiles : 1;
-    } else {
+    {
         double best = -1.0;
         for (int r = 1; r <= 4; ++r) {
             const int sp = (r * slots) / tiles;
@@ -3082,8 +3061,7 @@ extern "C" int pcgan_conv2d_bwd_weight(const pcgan_conv_desc* d, const void* x, 
     const bool reflect = d->pad_mode == 1;
     const bool veca = ((d->P * d->Q) % 4) == 0;
     const int kmode = smallc ? 1 : ((Cgp % 128) == 0 ? 2 : 0);
-    static const bool old_wgrad = getenv("PCGAN_OLD_WGRAD") != nullptr;   // A/B experiments
-    const bool w2 = !old_wgrad && (d->C % 64) == 0 && ((Cgp % 128) == 0 || Cgp == 64);
+    const bool w2 = (d->C % 64) == 0 && ((Cgp % 128) == 0 || Cgp == 64);
     if (w2) {
 #define LW2(MODE, BMV, VA) do { if (Cgp == 64) LAUNCH_TA(a.dtype, wgrad2_kernel, grid, a, MODE, BMV, VA, 2); \
                                 else LAUNCH_TA(a.dtype, wgrad2_kernel, grid, a, MODE, BMV, VA, 1); } while (0)

@@ -114,6 +114,8 @@ SIGNATURES = {
     'pcgan_resblock_bwd': (_i, [_rp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _sz, _vp, _vp, _vp]),
     'pcgan_set_nonfinite_counter': (_i, [_vp]),
+    'pcgan_set_option': (_i, [ctypes.c_char_p, _i]),
+    'pcgan_get_option': (_i, [ctypes.c_char_p, _vp]),
     'pcgan_timer_enable': (_i, [_i]),
     'pcgan_timer_read': (_i, [_i, _vp, _i]),
     'pcgan_conv2d_hgemm_supported': (_i, [_dp, _i]),
@@ -159,7 +161,37 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    _options_from_environment(lib)
     return lib
+
+
+# The library itself reads no environment variables (include/pcgan_hip.h); the HOST maps the A/B switches that live below the C-ABI
+# onto pcgan_set_option once, when the library is loaded.  (switch, option, value parser)
+_ENV_OPTIONS = (('PCGAN_BSPLIT_HALO', 'bsplit_halo', int), ('PCGAN_WGRAD_GEN', 'wgrad_gen', int), ('PCGAN_WGRAD_PADCOPY', 'wgrad_padcopy', int),
+                ('PCGAN_WGRAD_CW', 'wgrad_cw', int), ('PCGAN_HGEMM', 'hgemm_bf16', int))
+
+
+def _options_from_environment(lib):
+    for env, key, conv in _ENV_OPTIONS:
+        v = os.environ.get(env)
+        if v not in (None, ''):
+            set_option(key, conv(v), lib)
+
+
+def set_option(key, value, lib=None):
+    """pcgan_set_option: a routing option below the C-ABI (see the header); shape plans made under another value are the caller's to
+    drop (ops.clear_plans)"""
+    lib = lib or load()
+    if lib.pcgan_set_option(key.encode(), int(value)) != 0:
+        msg = lib.pcgan_last_error()
+        raise RuntimeError('pcgan_hip set_option failed: %s' % (msg.decode() if msg else '?'))
+
+
+def get_option(key):
+    v = ctypes.c_int(0)
+    if load().pcgan_get_option(key.encode(), ctypes.byref(v)) != 0:
+        raise RuntimeError('pcgan_hip get_option: unknown option %r' % key)
+    return v.value
 
 
 def check(status, what):

@@ -469,6 +469,12 @@ def _packed_weights(lib, d, pass_, w, cache, want_rowmax=False):
 _PLANS = {}
 
 
+def clear_plans():
+    """drop every cached launch plan (after lib.set_option changed what the library supports / routes)"""
+    _PLANS.clear()
+    _RB_PLANS.clear()
+
+
 class _Plan(object):
     __slots__ = ('d', 'dref', 'P', 'Q', 'ws_bytes', 'route', 'pack_pass')
 

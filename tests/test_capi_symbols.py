@@ -86,3 +86,20 @@ def test_weight_gradient_route_predicates():
         # fewer than 32 output channels / stride 4: other kernels
         assert h.pcgan_conv2d_hsplit_wgrad_supported(ctypes.byref(desc(32, 512, 15, 15, 1, 4, 1, 1, 0, dt))) == 0
         assert h.pcgan_conv2d_hsplit_wgrad_supported(ctypes.byref(desc(32, 3, 224, 224, 64, 11, 4, 2, 0, dt))) == 0
+
+
+def test_library_reads_no_environment_and_options_are_explicit():
+    """round 4: no getenv in the library's sources; the routing options are an explicit, validated table"""
+    import glob
+    from pcgan_amd.hip import lib
+    for src in glob.glob(os.path.join(ROOT, 'pc-gan_amd', 'csrc', '*')):
+        assert 'getenv' not in open(src).read(), src
+    h = lib.load()
+    for key, default in (('bsplit_halo', 1), ('wgrad_gen', 1), ('wgrad_padcopy', 0), ('wgrad_cw', 0), ('hgemm_bf16', 1)):
+        if not any(os.environ.get(e) for e, k, _ in lib._ENV_OPTIONS if k == key):
+            assert lib.get_option(key) == default, key
+    lib.set_option('wgrad_cw', 256)
+    assert lib.get_option('wgrad_cw') == 256
+    lib.set_option('wgrad_cw', 0)
+    assert h.pcgan_set_option(b'no_such_option', 1) != 0 and b'unknown option' in h.pcgan_last_error()
+    assert h.pcgan_set_option(b'wgrad_cw', 77) != 0

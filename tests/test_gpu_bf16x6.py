@@ -569,20 +569,26 @@ def test_per_channel_weight_scales(dev, monkeypatch, case):
 def test_residual_weight_gradient_reflects_in_the_gather(dev, monkeypatch, N, C, H, W):
     """round-2 verdict 5: the weight gradient of the reflection-padded 3x3 convolution read a padded COPY of x (37 MB written and re-read
     per launch at the benchmark's size, a launch of its own).  Now the mirror is applied inside the gather -- a row select per stage and one
-    register move at the two image edges -- and the result must be the SAME BITS as with the padded copy (PCGAN_WGRAD_PADCOPY=1: the old
-    path, kept for this comparison), incl. the first row of the tensor where the left-edge load starts one element in front of it."""
-    from pcgan_amd.hip import ops
+    register move at the two image edges -- and the result must be the SAME BITS as with the padded copy (library option
+    "wgrad_padcopy" = 1: the old path, kept for this comparison), incl. the first row of the tensor where the left-edge load starts one
+    element in front of it."""
+    from pcgan_amd.hip import ops, lib
     monkeypatch.setattr(ops, 'BSPLIT_MIN_PIXELS', 0)
     g = torch.Generator().manual_seed(N + C + H)
     K = 256 if C >= 64 else 64
     x = torch.randn(N, C, H, W, generator=g).to(dev)
     dy = torch.randn(N, K, H, W, generator=g).to(dev)
     assert ops._plan(ops._L.PASS_BWD_WEIGHT, N, C, H, W, K, 3, 3, 1, 1, 1, ops.F32).route == 'hsplit'
-    monkeypatch.delenv('PCGAN_WGRAD_PADCOPY', raising=False)
+    assert lib.get_option('wgrad_padcopy') == 0
     a = ops.conv2d_bwd_weight(x, dy, (K, C, 3, 3), 1, 1, 1)
-    monkeypatch.setenv('PCGAN_WGRAD_PADCOPY', '1')
-    b = ops.conv2d_bwd_weight(x, dy, (K, C, 3, 3), 1, 1, 1)
-    torch.cuda.synchronize()
+    try:
+        lib.set_option('wgrad_padcopy', 1)
+        ops.clear_plans()             # (the workspace of the padded-copy form is larger)
+        b = ops.conv2d_bwd_weight(x, dy, (K, C, 3, 3), 1, 1, 1)
+        torch.cuda.synchronize()
+    finally:
+        lib.set_option('wgrad_padcopy', 0)
+        ops.clear_plans()
     assert torch.equal(a, b)
     w = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
     R.conv2d(x.double().cpu(), w, None, 1, 1, 1).backward(dy.double().cpu())
