@@ -158,6 +158,16 @@ def mark_side_used():
 # only -- two passes through ONE BatchNorm net must stay ordered (running statistics).
 BRANCH_STREAMS = os.environ.get('PCGAN_BRANCH_STREAMS', '1') != '0'
 _branch = {}
+# Which branch NAMES share one stream.  HIP maps streams onto a few hardware queues (4 by default) and streams on one queue serialise;
+# which streams end up together used to follow from their creation order -- round 4 measured the same step at 1062 / 1210 / 750 img/s
+# for three such accidents (profiles/r04_experiments.txt).  The mapping is now stated: the generator's two passes are a dependency
+# chain (rec_A = G(fake_B)) and share the stream 'G'; with the main stream, the encoder's stream 'E' (which also carries the batch
+# uploads) and the parameter-gradient stream that makes four streams for four queues.  PCGAN_STREAM_ALIAS="name:target,..." re-maps
+# for A/B runs (target `main` = run that branch on the current stream).
+STREAM_ALIAS = {'G1': 'G', 'G2': 'G'}
+for _kv in os.environ.get('PCGAN_STREAM_ALIAS', '').split(','):
+    if ':' in _kv:
+        STREAM_ALIAS[_kv.split(':')[0].strip()] = _kv.split(':')[1].strip()
 
 
 class branch(object):
@@ -168,9 +178,10 @@ class branch(object):
     runs beside the tail of the previous step."""
 
     def __init__(self, name, enabled=True, after=None):
-        self.name = name
+        self.name = STREAM_ALIAS.get(name, name)
         self.after = after
-        self.on = enabled and BRANCH_STREAMS and torch.cuda.is_available() and name not in os.environ.get('PCGAN_BRANCH_OFF', '').split(',')
+        self.on = (enabled and BRANCH_STREAMS and torch.cuda.is_available() and self.name != 'main'
+                   and name not in os.environ.get('PCGAN_BRANCH_OFF', '').split(','))
 
     def __enter__(self):
         if self.on:
@@ -223,7 +234,7 @@ def upload_stream(device):
     device = torch.device(device)
     if device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
-    key = (device, 'E')
+    key = (device, STREAM_ALIAS.get('E', 'E'))
     st = _branch.get(key)
     if st is None:
         st = _branch[key] = torch.cuda.Stream(device=device)

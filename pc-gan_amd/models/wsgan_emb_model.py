@@ -37,12 +37,14 @@ _G1_AHEAD = os.environ.get('PCGAN_G1_AHEAD', '1') == '1'
 # the AlexNet identity term on its own stream beside the discriminator branch: round 2's default; with the cross-step overlap four
 # streams then crowd the same phase of backward_G and the step is 4.5 % SLOWER (1093 vs 1143 img/s, same box) -> off
 _IP_BRANCH = os.environ.get('PCGAN_IP_BRANCH', '0') == '1'
-# Round 4: the two Adam updates run ON the parameter-gradient stream, behind the weight gradients, and the main stream does not join
-# that stream at the end of a backward pass (hip/ops.py: defer_side_join, hip/optim.py: step_on_grad_stream): backward_D starts while
-# the generator's last weight gradients and its update are still running, the next step's forward while the discriminator's are.
-# Consumers of the new weights wait for the update's event.  Single process only (under torch.distributed the all-reduce sits between
-# backward and update: the reference's order, kept until a multi-GPU record exists).  PCGAN_ADAM_ON_GRAD_STREAM=0: the main stream joins.
-_ADAM_ON_GRAD_STREAM = os.environ.get('PCGAN_ADAM_ON_GRAD_STREAM', '1') == '1'
+# Round 4 experiment, default OFF (PCGAN_ADAM_ON_GRAD_STREAM=1 switches it on): the two Adam updates queued ON the parameter-gradient
+# stream, behind the weight gradients, with no join of that stream at the end of a backward pass (hip/ops.py: defer_side_join,
+# hip/optim.py: step_on_grad_stream) -- backward_D then starts while the generator's last weight gradients and its update are still
+# running, the next step's forward while the discriminator's are; consumers of the new weights wait for the update's event.  Bit-identical
+# (tests/test_gpu_concurrency.py runs it) and NEUTRAL on the step: 1166 / 1166 and 1204 / 1209 img/s in two same-box A/B runs
+# (profiles/r04_experiments.txt) -- the step is bound by the total time of its matrix-pipe kernels, not by the join.  Single process
+# only (under torch.distributed the all-reduce sits between backward and update).
+_ADAM_ON_GRAD_STREAM = os.environ.get('PCGAN_ADAM_ON_GRAD_STREAM', '0') == '1'
 
 MAGIC_EPS = 1e-20
 

@@ -3,12 +3,13 @@ scripts/run_res_conv.py): HBM-side bytes per launch of the three residual-convol
 launches (padded copy where there still is one, reduce).  usage: make_traffic_json.py <gpurun_out/tag> <out.json> <route>"""
 import json, re, sys
 out_dir, out_json, route = sys.argv[1], sys.argv[2], sys.argv[3]
+tag = (sys.argv[4] if len(sys.argv) > 4 else 'r04')
 
 
-def means(counter):
+def means(counter, file_tag=None):
     """kernel name prefix -> mean counter value per launch (KiB), from pmc_<counter>.txt"""
     res, cur = {}, None
-    for line in open('%s/pmc_%s.txt' % (out_dir, counter)):
+    for line in open('%s/pmc_%s.txt' % (out_dir, file_tag or counter)):
         m = re.match(r'^(\S.*?)\s+mean duration', line)
         if m:
             cur = m.group(1)
@@ -42,10 +43,26 @@ res = {'route': route, 'shape': '256->256 3x3 reflect @32x32, bs32',
                     'weight gradient\'s 4-byte partial stores read 35.4 MB against 33.0 MB written (14 x 256 x 2304 x 4) + 2.4 MB.  Infinity-Cache hits are '
                     'counted (these are L2 <-> fabric requests, an upper bound of HBM bytes)' % known,
        'fetch_scale': round(fetch_scale, 4), 'fetch_size_raw_kib_absmax': cal[0] if cal else None,
-       'source': 'profiles/r03_counters_residual_convs.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 scripts/run_res_conv.py 5'}
+       'source': 'profiles/%s_counters_residual_convs.txt:' % tag + ' rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 scripts/run_res_conv.py 5'}
 for k, pat in spec.items():
     fk, wk = pick(f, pat), pick(w, pat)
     res[k] = {'fetch_bytes': int(sum(fk.values()) * 1024 * fetch_scale), 'fetch_size_raw_kib': round(sum(fk.values()), 1), 'write_bytes': int(sum(wk.values()) * 1024),
               'algorithmic_bytes': alg_w if k == 'wgrad' else alg, 'kernels': sorted(fk)}
+# share of the active cycles the matrix pipes are busy: SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's 1024 SIMDs) over
+# GRBM_GUI_ACTIVE (summed over the 8 XCDs) x 128 SIMDs per XCD -- its own --pmc pass
+try:
+    MF = 'SQ_VALU_MFMA_BUSY_CYCLES_GRBM_GUI_ACTIVE'
+    busy, act = means('SQ_VALU_MFMA_BUSY_CYCLES', MF), means('GRBM_GUI_ACTIVE', MF)
+    main = {'fwd': spec['fwd'], 'dgrad': spec['dgrad'], 'wgrad': r'hsplit_wgrad_kernel<256, 1, float, 1(, 0)?>'}
+    res['mfma_busy'] = {}
+    for k, pat in main.items():
+        b, a = pick(busy, pat), pick(act, pat)
+        if b and a:
+            res['mfma_busy'][k] = round(sum(b.values()) / (sum(a.values()) * 128.0), 4)
+    res['mfma_busy_note'] = ('SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128): busy SIMD-cycles of the matrix pipes over active cycles x SIMDs per XCD '
+                             '(both counters are sums over the chip / the 8 XCDs); the weight gradient\'s figure is its main kernel\'s')
+except (OSError, KeyError, ZeroDivisionError) as e:
+    res['mfma_busy'] = None
+    res['mfma_busy_note'] = 'no matrix-pipe pass found: %r' % (e,)
 json.dump(res, open(out_json, 'w'), indent=1)
 print(json.dumps(res, indent=1))

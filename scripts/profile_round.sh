@@ -3,12 +3,10 @@
 # the same command (default streams) and single-stream, kernel dashboard, and separate --pmc passes over the three residual-convolution
 # kernels.  Everything lands under gpurun_out/$1/.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { tail -20 $OUT/bench_n1.err; exit 1; }
-cut -c1-400 $OUT/bench_n1.json
 python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err || tail -5 $OUT/bench_bf16.err
 cut -c1-300 $OUT/bench_bf16.json
 python scripts/bench_kernels.py > $OUT/kernel_dashboard_fp32.txt 2>&1 || true
@@ -31,5 +29,10 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LD
     rm -rf $D
 done
 ( for N in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES_GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT_SQ_LDS_IDX_ACTIVE_SQ_WAVE; do echo "== rocprofv3 --pmc $N --kernel-trace -- python3 scripts/run_res_conv.py 5"; cat $OUT/pmc_$N.txt; done ) > $OUT/counters_residual_convs.txt 2>/dev/null || true
-python3 $GRAFT_REPO_ROOT/scripts/make_traffic_json.py $OUT $OUT/residual_kernel_traffic.json f16x2 > /dev/null || true
+python3 $GRAFT_REPO_ROOT/scripts/make_traffic_json.py $OUT $OUT/residual_kernel_traffic.json f16x2 r04 > /dev/null || true
 cut -c1-600 $OUT/residual_kernel_traffic.json
+# the bench line LAST: it reads the traffic / matrix-pipe figures of THIS run's counter passes (profiles/<tag>_residual_kernel_traffic.json)
+cp $OUT/residual_kernel_traffic.json $GRAFT_REPO_ROOT/profiles/r04_residual_kernel_traffic.json || true
+cd $GRAFT_REPO_ROOT
+python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { tail -20 $OUT/bench_n1.err; exit 1; }
+cut -c1-400 $OUT/bench_n1.json
