@@ -144,7 +144,7 @@ _T0 = time.perf_counter()
 
 def cpu_baseline(batch=8, sweep_batch=4, final_steps=3, sweep_budget_s=45.0):
     """The oracle's CPU step (reference-equivalent PyTorch-CPU path) on a bounded sample, at the BEST thread count this box offers:
-    torch.set_num_threads is swept over {usable CPUs, 16, 32, 8, 64, all hardware threads} -- most promising first, 1 untimed + 1 timed
+    torch.set_num_threads is swept over {usable CPUs, 16, 32, 8, 64, all hardware threads} capped at 4 x the usable CPUs -- most promising first, 1 untimed + 1 timed
     step each at batch `sweep_batch`, stopped when `sweep_budget_s` is used up -- then 1 untimed + `final_steps` timed steps at the
     winner at batch `batch`; value = median of those.  A stated baseline must be the best the host's cores can do: round 3 ran on
     torch's default of 128 threads (the box's hardware threads; the container's CPU share is smaller) and got half of what 8 give."""
@@ -156,7 +156,9 @@ def cpu_baseline(batch=8, sweep_batch=4, final_steps=3, sweep_budget_s=45.0):
     hw = os.cpu_count() or usable
     cand = []
     for t in (usable, 16, 32, 8, 64, hw):
-        if 1 <= t <= hw and t not in cand:
+        # never more than 4 x the usable CPUs: a 128-thread OpenMP pool on a 16-CPU share does not merely run slowly, its spin-waiting
+        # barriers stall for minutes (round 4: the sweep's 128-thread setting hung the bench until the box's silence watchdog killed it)
+        if 1 <= t <= min(hw, 4 * usable) and t not in cand:
             cand.append(t)
     G = N.ResnetGeneratorRef(3, 3, 1, 64, 'instance', 9)
     D = N.NLayerDiscriminatorRef(3, 1, 64, 3, 'batch', True)

@@ -422,6 +422,19 @@ int pcgan_conv2d_fwd_thin(const pcgan_conv_desc* d, const void* x, const float* 
 int pcgan_conv2d_bwd_data_thin(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed, void* dx,
                                void* ws, size_t ws_bytes, pcgan_stream_t s);
 
+/* ---- weight gradient of the residual-block convolution, "image-innermost" form (round 4; csrc/wgrad_direct.hip) -------------------------
+ * nn.Conv2d(dim, dim, 3) behind nn.ReflectionPad2d(1) in ResnetBlock (models/networks.py:621-648), autograd's weight gradient; fp32 tensors,
+ * fp16 two-piece arithmetic as pcgan_conv2d_bwd_weight_hsplit (same operand maxima, same error level).  A transposing pre-pass scales and
+ * splits x and dy ONCE into 16-byte records of 8 images per (pixel, channel) -- a filter tap then shifts the pixel, not the position
+ * inside a record -- and the main kernel loads every MFMA operand fragment straight from memory: no LDS, no barrier, no split arithmetic
+ * in the loop (the per-tap form re-gathers and re-splits x nine times and is LDS-bound).  3x3, stride 1, reflection padding 1,
+ * N % 16 == 0, K % 128 == 0, C % 32 == 0.  ws: pcgan_conv2d_wgrad_direct_workspace_bytes(d) bytes (the four piece arrays, the split
+ * partials, two scale words).  dw[K][C][3][3], accumulate != 0: dw += (the optimizer's gradient buffer). */
+int pcgan_conv2d_wgrad_direct_supported(const pcgan_conv_desc* d);
+size_t pcgan_conv2d_wgrad_direct_workspace_bytes(const pcgan_conv_desc* d);
+int pcgan_conv2d_bwd_weight_direct(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_xamax, const void* dy,
+                                   const float* dy_amax, int n_dyamax, float* dw, int accumulate, void* ws, size_t ws_bytes, pcgan_stream_t s);
+
 /* ---- kernel timer (measurement only) -----------------------------------------------------------------------------------------------
  * bench.py's roofline block: HIP events on the launch stream around every launch of the three residual-block convolution kernels
  * (kind 0 forward, 1 data gradient, 2 weight gradient incl. its padded copy and reduce, 3 the weight gradient's main kernel),

@@ -1937,7 +1937,10 @@ extern "C" size_t pcgan_conv2d_hsplit_wgrad_workspace_bytes(const pcgan_conv_des
     int per;
     const int splits = hsplit_wgrad_splits(d, &per);
     const size_t xpad = hsplit_wgrad_gen(d) ? 0 : pcgan::align_up((size_t)d->N * d->C * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * 4, 256);
-    return xpad + (size_t)splits * d->K * d->C * d->R * d->S * 4;
+    const size_t own = xpad + (size_t)splits * d->K * d->C * d->R * d->S * 4;
+    // (option "wgrad_direct": the residual-block shape is handed to the image-innermost form of wgrad_direct.hip, which needs more room)
+    const size_t direct = pcgan::option(pcgan::OPT_WGRAD_DIRECT) ? pcgan_conv2d_wgrad_direct_workspace_bytes(d) : 0;
+    return own > direct ? own : direct;
 }
 
 extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_xamax, const void* dy,
@@ -1947,6 +1950,8 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     const bool half = d->dtype == PCGAN_BF16;
     PCGAN_CHECK(x && dy && dw && ws && ws_bytes >= pcgan_conv2d_hsplit_wgrad_workspace_bytes(d), "conv2d_bwd_weight_hsplit: null pointer or small workspace");
     PCGAN_CHECK(half || (x_amax && dy_amax && n_xamax > 0 && n_dyamax > 0), "conv2d_bwd_weight_hsplit: fp32 tensors need their operand maxima");
+    if (pcgan::option(pcgan::OPT_WGRAD_DIRECT) && pcgan_conv2d_wgrad_direct_supported(d))
+        return pcgan_conv2d_bwd_weight_direct(d, x, x_amax, n_xamax, dy, dy_amax, n_dyamax, dw, accumulate, ws, ws_bytes, s);
     hipStream_t st = (hipStream_t)s;
     const bool res_like = pcgan::timer_kind_res(d, 0) == 0;
     pcgan::TimerScope timer(res_like ? pcgan::TIMER_RES_WGRAD : -1, st);       // padded copy + main kernel + reduce

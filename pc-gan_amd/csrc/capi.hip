@@ -97,8 +97,8 @@ extern "C" int pcgan_set_nonfinite_counter(unsigned int* dev_word) {
 }
 
 namespace pcgan {
-static const char* const g_opt_names[OPT_COUNT] = {"bsplit_halo", "wgrad_gen", "wgrad_padcopy", "wgrad_cw", "hgemm_bf16"};
-static std::atomic<int> g_opt[OPT_COUNT] = {{1}, {1}, {0}, {0}, {1}};
+static const char* const g_opt_names[OPT_COUNT] = {"bsplit_halo", "wgrad_gen", "wgrad_padcopy", "wgrad_cw", "hgemm_bf16", "wgd_look", "wgrad_direct"};
+static std::atomic<int> g_opt[OPT_COUNT] = {{1}, {1}, {0}, {0}, {1}, {3}, {0}};
 int option(int id) { return (id >= 0 && id < OPT_COUNT) ? g_opt[id].load(std::memory_order_relaxed) : 0; }
 static int option_index(const char* key) {
     for (int i = 0; key && i < OPT_COUNT; ++i)

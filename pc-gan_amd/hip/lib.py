@@ -132,6 +132,9 @@ SIGNATURES = {
     'pcgan_conv2d_hsplit_wgrad_inline': (_i, [_dp]),
     'pcgan_conv2d_hsplit_wgrad_workspace_bytes': (_sz, [_dp]),
     'pcgan_conv2d_bwd_weight_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    'pcgan_conv2d_wgrad_direct_supported': (_i, [_dp]),
+    'pcgan_conv2d_wgrad_direct_workspace_bytes': (_sz, [_dp]),
+    'pcgan_conv2d_bwd_weight_direct': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     'pcgan_image_transform_band': (_i, [_ip, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     'pcgan_image_transform': (_i, [_ip, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
@@ -168,7 +171,8 @@ def load():
 # The library itself reads no environment variables (include/pcgan_hip.h); the HOST maps the A/B switches that live below the C-ABI
 # onto pcgan_set_option once, when the library is loaded.  (switch, option, value parser)
 _ENV_OPTIONS = (('PCGAN_BSPLIT_HALO', 'bsplit_halo', int), ('PCGAN_WGRAD_GEN', 'wgrad_gen', int), ('PCGAN_WGRAD_PADCOPY', 'wgrad_padcopy', int),
-                ('PCGAN_WGRAD_CW', 'wgrad_cw', int), ('PCGAN_HGEMM', 'hgemm_bf16', int))
+                ('PCGAN_WGRAD_CW', 'wgrad_cw', int), ('PCGAN_HGEMM', 'hgemm_bf16', int), ('PCGAN_WGRAD_DIRECT', 'wgrad_direct', int),
+                ('PCGAN_WGD_LOOK', 'wgd_look', int))
 
 
 def _options_from_environment(lib):

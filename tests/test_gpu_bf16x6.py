@@ -594,3 +594,45 @@ def test_residual_weight_gradient_reflects_in_the_gather(dev, monkeypatch, N, C,
     R.conv2d(x.double().cpu(), w, None, 1, 1, 1).backward(dy.double().cpu())
     err = float((a.double().cpu() - w.grad).norm() / w.grad.norm())
     assert err < 3e-6, err
+
+
+@pytest.mark.parametrize('N,C,H,W', [(32, 256, 32, 32), (16, 128, 16, 32), (16, 256, 8, 20), (32, 128, 64, 64)])
+def test_weight_gradient_image_innermost_form(dev, N, C, H, W):
+    """round 4 experiment (csrc/wgrad_direct.hip, library option "wgrad_direct", default off): the residual convolution's weight gradient
+    with every MFMA operand fragment loaded straight from memory -- a transposing pre-pass scales / splits x and dy once into 16-byte
+    records of 8 images, the main kernel has no LDS, no barrier and no split arithmetic -- against float64 on a slice of output channels
+    (3e-6, the bound of the per-tap kernel) and against the per-tap kernel on the whole tensor; accumulation into an existing gradient;
+    odd widths (W = 20: scalar tail of the pre-pass) and the split boundaries of the pixel reduction (all shapes)."""
+    import ctypes
+    from pcgan_amd.hip import ops, lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(N + C + H + W)
+    K = C
+    x = torch.randn(N, C, H, W, generator=g).relu_().to(dev)
+    dy = (torch.randn(N, K, H, W, generator=g) * 0.05).to(dev)
+    d = ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 1)
+    assert lib.pcgan_conv2d_wgrad_direct_supported(ctypes.byref(d))
+    nb = int(lib.pcgan_conv2d_wgrad_direct_workspace_bytes(ctypes.byref(d)))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    xmax, dmax = ops.amax_of(x), ops.amax_of(dy)
+    vp = ctypes.c_void_p
+    dw = torch.full((K, C, 3, 3), 0.5, device=dev)
+    for acc in (0, 1):
+        L.check(lib.pcgan_conv2d_bwd_weight_direct(ctypes.byref(d), vp(x.data_ptr()), vp(xmax.data_ptr()), xmax.numel(), vp(dy.data_ptr()),
+                                                   vp(dmax.data_ptr()), dmax.numel(), vp(dw.data_ptr()), acc, vp(ws.data_ptr()), nb,
+                                                   vp(torch.cuda.current_stream().cuda_stream)), 'bwd_weight_direct')
+    torch.cuda.synchronize()
+    once = dw / 2           # overwritten, then accumulated once more: exactly twice the gradient
+    ks = [0, 1, K // 3, K - 1]
+    w = torch.zeros(len(ks), C, 3, 3, dtype=torch.float64, requires_grad=True)
+    xp = torch.nn.functional.pad(x.double().cpu(), (1, 1, 1, 1), mode='reflect')
+    for n0 in range(0, N, 8):
+        torch.nn.functional.conv2d(xp[n0:n0 + 8], w).backward(dy[n0:n0 + 8, ks].double().cpu())
+    err = float((once[ks].double().cpu() - w.grad).norm() / w.grad.norm())
+    assert err < 3e-6, err
+    ref = ops.conv2d_bwd_weight(x, dy, (K, C, 3, 3), 1, 1, 1)
+    assert float((once.double() - ref.double()).norm() / ref.double().norm()) < 3e-6
+    # refusals: what the form does not take is said so, not computed wrongly
+    for bad in (ops.make_desc(8, C, H, W, K, 3, 3, 1, 1, 1), ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 0), ops.make_desc(N, 48, H, W, K, 3, 3, 1, 1, 1),
+                ops.make_desc(N, C, H, W, K, 3, 3, 2, 1, 1)):
+        assert not lib.pcgan_conv2d_wgrad_direct_supported(ctypes.byref(bad))
