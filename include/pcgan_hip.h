@@ -422,6 +422,22 @@ int pcgan_conv2d_fwd_thin(const pcgan_conv_desc* d, const void* x, const float* 
 int pcgan_conv2d_bwd_data_thin(const pcgan_conv_desc* d, const void* dy, const float* dy_amax, int n_amax, const void* packed, void* dx,
                                void* ws, size_t ws_bytes, pcgan_stream_t s);
 
+/* A RUN of `nblocks` consecutive ResnetBlocks per call (round 4: the generator's nine blocks, models/networks.py:589-592): the
+ * launches of nblocks pcgan_resblock_fwd / _bwd calls, block i reading block i - 1's output and plane maxima, from one host call.
+ * Per-block tensors are slices of stacked buffers: y1, h, y2, out [nblocks][N*C*H*W]; stats [nblocks][4*N*C]; amax [nblocks][2*N*C];
+ * backward: dy2, dy1 [nblocks][N*C*H*W] (read by `side` after the call), dh [N*C*H*W], dxs [2][N*C*H*W] (gradient handed from block
+ * to block), scratch [nblocks][5*N*C]; dx = gradient of the chain's input.  Per-block parameter pointers (packed weights, biases,
+ * running statistics, gradient slots; a bias / running-statistics entry may be NULL) come as HOST arrays of nblocks pointers. */
+int pcgan_restrunk_fwd(const pcgan_resblock_desc* d, int nblocks, const void* x, const float* x_amax, int n_xamax, const void* const* pk1,
+                       const float* const* b1, const void* const* pk2, const float* const* b2, float* const* rm1, float* const* rv1,
+                       float* const* rm2, float* const* rv2, void* y1, void* h, void* y2, void* out, float* stats, float* amax,
+                       pcgan_stream_t s);
+int pcgan_restrunk_bwd(const pcgan_resblock_desc* d, int nblocks, const void* dout, const void* x, const float* x_amax, int n_xamax,
+                       const void* y1, const void* h, const void* y2, const void* out, const float* stats, const float* amax,
+                       const void* const* pk1b, const void* const* pk2b, float* const* dw1, float* const* db1, float* const* dw2,
+                       float* const* db2, void* dy2, void* dh, void* dy1, void* dxs, void* dx, float* scratch, void* wgrad_ws,
+                       size_t wgrad_ws_bytes, pcgan_stream_t s, pcgan_stream_t side, pcgan_event_t fork_event);
+
 /* ---- weight gradient of the residual-block convolution, "image-innermost" form (round 4; csrc/wgrad_direct.hip) -------------------------
  * nn.Conv2d(dim, dim, 3) behind nn.ReflectionPad2d(1) in ResnetBlock (models/networks.py:621-648), autograd's weight gradient; fp32 tensors,
  * fp16 two-piece arithmetic as pcgan_conv2d_bwd_weight_hsplit (same operand maxima, same error level).  A transposing pre-pass scales and

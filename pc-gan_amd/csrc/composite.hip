@@ -98,3 +98,52 @@ extern "C" int pcgan_resblock_bwd(const pcgan_resblock_desc* d, const void* dout
     STEP(pcgan_conv2d_bwd_data_hsplit_add(&c, dy1, dy1_amax, NC, pk1b, dout, dx, s));
     return 0;
 }
+
+// ---- a run of ResnetBlocks per call (round 4) -----------------------------------------------------------------------------------------
+// The generator's nine blocks are one chain: block i reads block i - 1's output and its plane maxima.  pcgan_restrunk_fwd / _bwd issue
+// the launches of `nblocks` consecutive pcgan_resblock_fwd / _bwd calls from ONE host call (18 -> 2 calls per generator pass and
+// direction, one autograd node instead of nine); same kernels, arguments, order and streams: bit-identical again.  Per-block tensors are
+// slices of stacked buffers ([nblocks][...]); per-block parameter pointers come as host arrays.
+extern "C" int pcgan_restrunk_fwd(const pcgan_resblock_desc* d, int nblocks, const void* x, const float* x_amax, int n_xamax,
+                                  const void* const* pk1, const float* const* b1, const void* const* pk2, const float* const* b2,
+                                  float* const* rm1, float* const* rv1, float* const* rm2, float* const* rv2, void* y1, void* h, void* y2,
+                                  void* out, float* stats, float* amax, pcgan_stream_t s) {
+    PCGAN_CHECK(pcgan_resblock_supported(d) && nblocks >= 1, "restrunk_fwd: unsupported shape or empty chain");
+    PCGAN_CHECK(x && x_amax && n_xamax > 0 && pk1 && pk2 && b1 && b2 && rm1 && rv1 && rm2 && rv2 && y1 && h && y2 && out && stats && amax,
+                "restrunk_fwd: null pointer");
+    const size_t NC = (size_t)d->N * d->C, el = NC * d->H * d->W * 4;
+    for (int i = 0; i < nblocks; ++i) {
+        const void* xi = i == 0 ? x : (const char*)out + (size_t)(i - 1) * el;
+        const float* xa = i == 0 ? x_amax : amax + (size_t)(i - 1) * 2 * NC + NC;
+        STEP(pcgan_resblock_fwd(d, xi, xa, i == 0 ? n_xamax : (int)NC, pk1[i], b1[i], pk2[i], b2[i], rm1[i], rv1[i], rm2[i], rv2[i],
+                                (char*)y1 + i * el, (char*)h + i * el, (char*)y2 + i * el, (char*)out + i * el, stats + (size_t)i * 4 * NC,
+                                amax + (size_t)i * 2 * NC, s));
+    }
+    return 0;
+}
+
+// dx receives the gradient of the chain's input.  dy2 / dy1: [nblocks] temporaries (read by the parameter-gradient stream after the
+// call returns); dh: one temporary; dxs: [2] ping-pong buffers for the gradient handed from block to block (all on stream `s`).
+extern "C" int pcgan_restrunk_bwd(const pcgan_resblock_desc* d, int nblocks, const void* dout, const void* x, const float* x_amax, int n_xamax,
+                                  const void* y1, const void* h, const void* y2, const void* out, const float* stats, const float* amax,
+                                  const void* const* pk1b, const void* const* pk2b, float* const* dw1, float* const* db1, float* const* dw2,
+                                  float* const* db2, void* dy2, void* dh, void* dy1, void* dxs, void* dx, float* scratch, void* wgrad_ws,
+                                  size_t wgrad_ws_bytes, pcgan_stream_t s, pcgan_stream_t side, pcgan_event_t fork_event) {
+    PCGAN_CHECK(pcgan_resblock_supported(d) && nblocks >= 1, "restrunk_bwd: unsupported shape or empty chain");
+    PCGAN_CHECK(dout && x && x_amax && n_xamax > 0 && y1 && h && y2 && out && stats && amax && pk1b && pk2b && dw1 && db1 && dw2 && db2 &&
+                    dy2 && dh && dy1 && dxs && dx && scratch && wgrad_ws && fork_event,
+                "restrunk_bwd: null pointer");
+    const size_t NC = (size_t)d->N * d->C, el = NC * d->H * d->W * 4;
+    const void* g = dout;
+    for (int i = nblocks - 1; i >= 0; --i) {
+        const void* xi = i == 0 ? x : (const char*)out + (size_t)(i - 1) * el;
+        const float* xa = i == 0 ? x_amax : amax + (size_t)(i - 1) * 2 * NC + NC;
+        void* dxi = i == 0 ? dx : (char*)dxs + (size_t)(i & 1) * el;
+        STEP(pcgan_resblock_bwd(d, g, xi, xa, i == 0 ? n_xamax : (int)NC, (const char*)y1 + i * el, (const char*)h + i * el,
+                                amax + (size_t)i * 2 * NC, (const char*)y2 + i * el, stats + (size_t)i * 4 * NC, pk1b[i], pk2b[i], dw1[i], db1[i],
+                                dw2[i], db2[i], (char*)dy2 + i * el, dh, (char*)dy1 + i * el, dxi, scratch + (size_t)i * 5 * NC, wgrad_ws,
+                                wgrad_ws_bytes, s, side, fork_event));
+        g = dxi;
+    }
+    return 0;
+}

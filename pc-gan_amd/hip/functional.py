@@ -144,6 +144,65 @@ def resblock(x, conv1, conv2, in1, in2, pl):
     return _ResBlockFn.apply(x, conv1.weight, conv1.bias, conv2.weight, conv2.bias, pl, in1, in2)
 
 
+class _ResTrunkFn(torch.autograd.Function):
+    """A run of ResnetBlocks (the generator's nine, reference models/networks.py:589-592) as ONE autograd node and ONE library call per
+    pass (ops.restrunk_fwd / restrunk_bwd = the launches of the per-block composite calls, bit for bit).  params: (w1, b1, w2, b2) per
+    block, flat, so that autograd sees them."""
+
+    @staticmethod
+    def forward(ctx, x, pl, norms, *params):
+        nb = len(params) // 4
+        blocks = []
+        for i in range(nb):
+            w1, b1, w2, b2 = params[4 * i:4 * i + 4]
+            in1, in2 = norms[i]
+            u1 = in1.training and in1.running_mean is not None
+            u2 = in2.training and in2.running_mean is not None
+            blocks.append((w1, b1, w2, b2, in1.running_mean if u1 else None, in1.running_var if u1 else None,
+                           in2.running_mean if u2 else None, in2.running_var if u2 else None, _pack_cache(w1), _pack_cache(w2)))
+        out, saved = ops.restrunk_fwd(pl, x, blocks)
+        ctx.pl, ctx.saved, ctx.params = pl, saved, params
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        params = ctx.params
+        blocks = []
+        for i in range(len(params) // 4):
+            w1, b1, w2, b2 = params[4 * i:4 * i + 4]
+            t = [_fused_grad_target(p) for p in (w1, b1, w2, b2)]
+            assert t[0] is not None and t[2] is not None and (b1 is None or t[1] is not None) and (b2 is None or t[3] is not None), \
+                'pcgan_amd: the composite residual trunk needs FusedAdam gradient buffers (checked in forward)'
+            blocks.append((w1, w2, t[0], t[1], t[2], t[3], _pack_cache(w1), _pack_cache(w2)))
+        dx = ops.restrunk_bwd(ctx.pl, _c(dout), x, ctx.saved, blocks)
+        ctx.saved = None
+        return (dx, None, None) + (None,) * len(params)
+
+
+def restrunk(x, mods):
+    """mods: consecutive ResnetBlock modules with the composite layout; the chain through ONE call when every block qualifies (same
+    plan), else None (the caller runs them one by one)"""
+    if not (ops.TRUNK and len(mods) >= 2):
+        return None
+    pl = None
+    params, norms = [], []
+    for m in mods:
+        cb = m.conv_block
+        p = resblock_composite_ok(x, cb[1], cb[5], cb[2], cb[6])
+        if p is None or (pl is not None and p is not pl):
+            return None
+        pl = p
+        params += [cb[1].weight, cb[1].bias, cb[5].weight, cb[5].bias]
+        norms.append((cb[2], cb[6]))
+    y = _ResTrunkFn.apply(x, pl, norms, *params)
+    ent = ops._LAST_TRUNK.pop('amax', None)
+    if ent is not None and '_pcgan_amax' not in y.__dict__ and ent[0] == y._version:
+        y._pcgan_amax = ent       # the plane maxima of the chain's output (the next convolution's operand scale)
+    return y
+
+
 def conv2d(x, w, b=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE, slope=0.0):
     """nn.Conv2d (optionally preceded by nn.ReflectionPad2d(pad): pad_mode=1) with the
     following pointwise activation fused into the epilogue."""

@@ -192,6 +192,19 @@ def run_sequential(seq, x, residual=None):
             a = _act_of(m)
             x = F.activation(x, a[0], a[1])
             i += 1
+        elif getattr(m, '_composite_layout', False):
+            # a run of ResnetBlocks (the generator's nine): one library call and one autograd node for the chain when every block
+            # qualifies for the composite path (hip/functional.py: restrunk), else block by block
+            j = i
+            while j < n and getattr(mods[j], '_composite_layout', False):
+                j += 1
+            y = F.restrunk(x, mods[i:j]) if j - i >= 2 else None
+            if y is None:
+                for k in range(i, j):
+                    x = mods[k](x)
+            else:
+                x = y
+            i = j
         else:
             x = m(x)   # ConvTranspose2d, MaxPool2d, Dropout2d, nested blocks ...
             i += 1

@@ -738,6 +738,7 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, pad_mode=0, accumulate_into=N
 # (include/pcgan_hip.h "composite"): the same launches as the per-op sequence conv -> IN+ReLU -> conv -> IN+skip (and its backward)
 # from ONE ctypes call -- the host side of a config-2 step spends ~12 of its 27 ms on the 18 blocks x 2 generator passes.
 COMPOSITE = os.environ.get('PCGAN_COMPOSITE', '1') != '0'
+TRUNK = os.environ.get('PCGAN_TRUNK', '1') != '0'      # runs of ResnetBlocks in ONE library call (pcgan_restrunk_*); 0: one call per block
 COMPOSITE_STATS = {'fwd': 0, 'bwd': 0}
 _RB_PLANS = {}
 _FORK_EVENTS = {}
@@ -824,6 +825,81 @@ def resblock_bwd(pl, dout, x, saved, w1, w2, dw1, db1, dw2, db2, pack1, pack2):
     AMAX_STATS['attached'] += 6        # (x, h, dy2 x 2, dy1 x 2: the operand maxima all came from the norm kernels)
     PLANE_SUM_STATS['fused'] += 2
     COMPOSITE_STATS['bwd'] += 1
+    mark_side_used()
+    return dx
+
+
+_LAST_TRUNK = {}
+
+
+def _ptr_array(items):
+    return (ctypes.c_void_p * len(items))(*[(t.data_ptr() if t is not None else None) for t in items])
+
+
+def restrunk_fwd(pl, x, blocks):
+    """a run of ResnetBlocks in one library call (pcgan_restrunk_fwd).  blocks: [(w1, b1, w2, b2, rm1, rv1, rm2, rv2, pack1, pack2)].
+    returns the last block's output (a slice of the stacked outputs, plane maxima attached) and what the backward call needs"""
+    lib = _L.load()
+    nb = len(blocks)
+    N, C = x.shape[0], x.shape[1]
+    for b in blocks:
+        _chk(*b[:8])
+    _chk(x)
+    pk1 = [_packed_weights(lib, pl.conv, PASS_FWD_HSPLIT, b[0], b[8]) for b in blocks]
+    pk2 = [_packed_weights(lib, pl.conv, PASS_FWD_HSPLIT, b[2], b[9]) for b in blocks]
+    xmax = amax_of(x)
+    shape = (nb,) + tuple(x.shape)
+    y1, h, y2, out = (torch.empty(shape, dtype=x.dtype, device=x.device) for _ in range(4))
+    stats = torch.empty(nb * 4 * N * C, dtype=torch.float32, device=x.device)
+    amax = torch.empty(nb * 2 * N * C, dtype=torch.float32, device=x.device)
+    _L.check(lib.pcgan_restrunk_fwd(pl.dref, nb, _p(x), _p(xmax), xmax.numel(), _ptr_array(pk1), _ptr_array([b[1] for b in blocks]),
+                                    _ptr_array(pk2), _ptr_array([b[3] for b in blocks]), _ptr_array([b[4] for b in blocks]),
+                                    _ptr_array([b[5] for b in blocks]), _ptr_array([b[6] for b in blocks]), _ptr_array([b[7] for b in blocks]),
+                                    _p(y1), _p(h), _p(y2), _p(out), _p(stats), _p(amax), _stream()), 'restrunk_fwd')
+    ROUTE_STATS[('fwd', 'hsplit')] = ROUTE_STATS.get(('fwd', 'hsplit'), 0) + 2 * nb
+    COMPOSITE_STATS['fwd'] += nb
+    COMPOSITE_STATS['trunk_fwd'] = COMPOSITE_STATS.get('trunk_fwd', 0) + 1
+    AMAX_STATS['attached'] += 2 * nb - 1      # (every convolution but the first took its operand maxima from the norm kernel in front of it)
+    last = out[nb - 1]
+    _attach_amax(last, amax[(2 * nb - 1) * N * C:])
+    _LAST_TRUNK['amax'] = last.__dict__['_pcgan_amax']      # (autograd may hand the caller another tensor object for a view output)
+    return last, (y1, h, y2, out, stats, amax, xmax)
+
+
+def restrunk_bwd(pl, dout, x, saved, blocks):
+    """blocks: [(w1, w2, dw1, db1, dw2, db2, pack1, pack2)]; dx of the chain's input, parameter gradients ADDED on the side stream"""
+    y1, h, y2, out, stats, amax, xmax = saved
+    lib = _L.load()
+    nb = len(blocks)
+    N, C = x.shape[0], x.shape[1]
+    _chk(dout, x)
+    pk1b = [_packed_weights(lib, pl.conv, PASS_BWD_HSPLIT, b[0], b[6]) for b in blocks]
+    pk2b = [_packed_weights(lib, pl.conv, PASS_BWD_HSPLIT, b[1], b[7]) for b in blocks]
+    cur = torch.cuda.current_stream()
+    side = side_stream_for(cur)
+    wkey = (x.device, pl.ws_bytes)
+    ws = _WGRAD_WS.get(wkey)
+    if ws is None:
+        with torch.cuda.stream(side):
+            ws = _WGRAD_WS[wkey] = _ws(pl.ws_bytes, x.device)
+    shape = (nb,) + tuple(x.shape)
+    dy2, dy1 = torch.empty(shape, dtype=x.dtype, device=x.device), torch.empty(shape, dtype=x.dtype, device=x.device)
+    dh, dx = torch.empty_like(x), torch.empty_like(x)
+    dxs = torch.empty((2,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    scratch = torch.empty(nb * 5 * N * C, dtype=torch.float32, device=x.device)
+    for t in (x, h, out, dy2, dy1, scratch, amax, xmax):      # read by the side stream after this call returns
+        t.record_stream(side)
+    _L.check(lib.pcgan_restrunk_bwd(pl.dref, nb, _p(dout), _p(x), _p(xmax), xmax.numel(), _p(y1), _p(h), _p(y2), _p(out), _p(stats), _p(amax),
+                                    _ptr_array(pk1b), _ptr_array(pk2b), _ptr_array([b[2] for b in blocks]), _ptr_array([b[3] for b in blocks]),
+                                    _ptr_array([b[4] for b in blocks]), _ptr_array([b[5] for b in blocks]), _p(dy2), _p(dh), _p(dy1), _p(dxs),
+                                    _p(dx), _p(scratch), _p(ws), ws.numel(), _vp(cur.cuda_stream), _vp(side.cuda_stream),
+                                    _fork_event(x.device)), 'restrunk_bwd')
+    ROUTE_STATS[('dgrad', 'hsplit')] = ROUTE_STATS.get(('dgrad', 'hsplit'), 0) + 2 * nb
+    ROUTE_STATS[('wgrad', 'hsplit')] = ROUTE_STATS.get(('wgrad', 'hsplit'), 0) + 2 * nb
+    AMAX_STATS['attached'] += 6 * nb
+    PLANE_SUM_STATS['fused'] += 2 * nb
+    COMPOSITE_STATS['bwd'] += nb
+    COMPOSITE_STATS['trunk_bwd'] = COMPOSITE_STATS.get('trunk_bwd', 0) + 1
     mark_side_used()
     return dx
 

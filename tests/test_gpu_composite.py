@@ -99,16 +99,19 @@ def test_composite_falls_back_where_it_does_not_apply(dev, monkeypatch):
 
 def test_full_size_step_composite_equals_per_op(tmp_path, dev, monkeypatch):
     """two optimize_parameters() of the config-2 networks (9-block generator, batch 2, routing threshold lowered so the residual
-    blocks take the production kernels): parameters of G and D, images and losses bit-identical with and without the composite"""
+    blocks take the production kernels): parameters of G and D, images and losses bit-identical (a) with the nine blocks of a generator
+    pass as ONE library call and autograd node per direction (round 4: pcgan_restrunk_fwd / _bwd), (b) with one composite call per
+    block, (c) layer by layer"""
     import bench
     from pcgan_amd.hip import ops
     monkeypatch.setattr(ops, 'BSPLIT_MIN_PIXELS', 0)
     res = []
-    for comp in (True, False):
+    for comp, trunk in ((True, True), (True, False), (False, False)):
         monkeypatch.setattr(ops, 'COMPOSITE', comp)
+        monkeypatch.setattr(ops, 'TRUNK', trunk)
         before = dict(ops.COMPOSITE_STATS)
         torch.manual_seed(0)
-        tmp = tmp_path / ('composite%d' % int(comp))
+        tmp = tmp_path / ('composite%d%d' % (int(comp), int(trunk)))
         tmp.mkdir()
         model, opt = bench.build_model(0, 2, 128, str(tmp), seed=3)
         for it in range(2):
@@ -117,13 +120,71 @@ def test_full_size_step_composite_equals_per_op(tmp_path, dev, monkeypatch):
         torch.cuda.synchronize()
         took = ops.COMPOSITE_STATS['fwd'] - before['fwd']
         assert took == (2 * 2 * 9 if comp else 0), took
+        trunks = ops.COMPOSITE_STATS.get('trunk_fwd', 0) - before.get('trunk_fwd', 0), ops.COMPOSITE_STATS.get('trunk_bwd', 0) - before.get('trunk_bwd', 0)
+        assert trunks == ((4, 4) if trunk else (0, 0)), trunks      # 2 steps x 2 generator passes: one call per pass and direction
         res.append({'G': model.optimizer_G.flat.detach().clone(), 'D': model.optimizer_D.flat.detach().clone(),
                     'fake_B': model.fake_B.detach().clone(), 'rec_A': model.rec_A.detach().clone(),
                     'losses': dict(model.get_current_losses()),
                     'bufs': {k: v.detach().clone() for k, v in model.netG.state_dict().items() if 'running' in k}})
-    a, b = res
-    for k in ('G', 'D', 'fake_B', 'rec_A'):
-        assert torch.equal(a[k], b[k]), k
-    assert a['losses'] == b['losses']
-    for k in a['bufs']:
-        assert torch.equal(a['bufs'][k], b['bufs'][k]), k
+    for b in res[1:]:
+        a = res[0]
+        for k in ('G', 'D', 'fake_B', 'rec_A'):
+            assert torch.equal(a[k], b[k]), k
+        assert a['losses'] == b['losses']
+        for k in a['bufs']:
+            assert torch.equal(a['bufs'][k], b['bufs'][k]), k
+
+
+@pytest.mark.parametrize('nb,N,H', [(3, 4, 32), (9, 32, 32), (2, 2, 64)])
+def test_restrunk_is_the_chain_of_block_calls(dev, monkeypatch, nb, N, H):
+    """pcgan_restrunk_fwd / _bwd on a chain of nb ResnetBlocks inside an nn.Sequential (as in ResnetGenerator): output, input gradient,
+    every weight / bias gradient accumulated over two passes and every running statistic BIT-IDENTICAL to one composite call per block;
+    the chain's output carries its plane maxima for the next convolution"""
+    import torch.nn as tnn
+    from pcgan_amd.hip import ops, nn as hnn
+    from pcgan_amd.hip.optim import FusedAdam
+    from pcgan_amd.models import networks
+    monkeypatch.setattr(ops, 'BSPLIT_MIN_PIXELS', 0)
+    C = 256
+
+    def build():
+        torch.manual_seed(9)
+        seq = tnn.Sequential(*[networks.ResnetBlock(C, 'reflect', lambda c: hnn.InstanceNorm2d(c, affine=False, track_running_stats=True), 0, True)
+                               for _ in range(nb)]).to(dev)
+        with torch.no_grad():
+            for p in seq.parameters():
+                p.mul_(3.0)
+        return seq, FusedAdam(seq.parameters(), lr=2e-4, betas=(0.5, 0.999))
+
+    g = torch.Generator().manual_seed(nb + N)
+    xs = [(torch.randn(N, C, H, H, generator=g) * 0.7).to(dev) for _ in range(2)]
+    dys = [torch.randn(N, C, H, H, generator=g).to(dev) for _ in range(2)]
+
+    def run(trunk):
+        monkeypatch.setattr(ops, 'TRUNK', trunk)
+        seq, opt = build()
+        before = ops.COMPOSITE_STATS.get('trunk_fwd', 0), ops.COMPOSITE_STATS.get('trunk_bwd', 0)
+        opt.zero_grad()
+        outs, dxs = [], []
+        for x0, dy in zip(xs, dys):
+            x = x0.clone().requires_grad_(True)
+            xin = x * 1.0
+            ops._attach_amax(xin, ops.amax_of(xin.detach()))
+            out = hnn.run_sequential(seq, xin)
+            assert '_pcgan_amax' in out.__dict__ and out.__dict__['_pcgan_amax'][0] == out._version, 'the chain output lost its plane maxima'
+            out.backward(dy)
+            outs.append(out.detach().clone())
+            dxs.append(x.grad.detach().clone())
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        took = ops.COMPOSITE_STATS.get('trunk_fwd', 0) - before[0], ops.COMPOSITE_STATS.get('trunk_bwd', 0) - before[1]
+        assert took == ((2, 2) if trunk else (0, 0)), took
+        return outs, dxs, opt.gflat.detach().clone(), {k: v.detach().clone() for k, v in seq.state_dict().items() if 'running' in k}
+
+    a, b = run(True), run(False)
+    for i in range(2):
+        assert torch.equal(a[0][i], b[0][i]), 'chain output, pass %d' % i
+        assert torch.equal(a[1][i], b[1][i]), 'input gradient, pass %d' % i
+    assert torch.equal(a[2], b[2]) and float(a[2].abs().max()) > 0, 'weight / bias gradients in the flat buffer'
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
