@@ -118,7 +118,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
     if (wg >= a.nwg) return;
     const int split = wg / a.tiles, tile = wg - split * a.tiles;
-    const int rh = tile & 1, tr = (tile >> 1) % 3, cb = tile / 6;      // row half (128 output channels), tap row, block of 32 input channels
+    const WgdGeom& g0 = a.g;
+    const int nrh = g0.K / 128;
+    const int rh = tile % nrh, tr = (tile / nrh) % 3, cb = tile / (3 * nrh);      // row block (128 output channels), tap row, block of 32 input channels
     const int lane = threadIdx.x, l32 = lane & 31, h = lane >> 5;
     const WgdGeom& g = a.g;
     const int HW = g.H * g.W, HWp = g.Hp * g.Wp;
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     {
         const int st = first < 0 ? 0 : first;
         const int row = st / RW;
-        lxv = st - row * RW - 2 - (first < 0 ? -first : 0);      // (first < 0 only for split 0: steps -2, -1 are dead)
+        lxv = st - row * RW - 2;      // (first < 0 only for split 0: its steps -2, -1 are dead and do not move the position)
         lgp = row / g.H;
         ly = row - lgp * g.H;
     }
