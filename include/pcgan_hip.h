@@ -470,6 +470,9 @@ int pcgan_set_nonfinite_counter(unsigned int* dev_word);
  *   "wgrad_cw"      0  columns per workgroup of the matrix-pipe weight gradient: 0 = as measured (128 for fp32 tensors, 256 for bf16),
  *                      128 / 256 force one form
  *   "hgemm_bf16"    1  bf16 tensors on the one-product bf16 MFMA form of the packed implicit GEMM; 0: fp32 MFMA kernels
+ *   "wgrad_direct"  0  1: pcgan_conv2d_bwd_weight_hsplit hands the shapes pcgan_conv2d_wgrad_direct_supported takes to the
+ *                      image-innermost form below (round-4 experiment: same results level, no step gain); the workspace query follows
+ *   "wgd_look"      3  K steps the operand loads of that form's main kernel run ahead of its MFMAs (2, 3 or 4)
  * Unknown keys / values return non-zero. */
 int pcgan_set_option(const char* key, int value);
 int pcgan_get_option(const char* key, int* value);

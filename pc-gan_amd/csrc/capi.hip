@@ -109,7 +109,7 @@ static int option_index(const char* key) {
 extern "C" int pcgan_set_option(const char* key, int value) {
     using namespace pcgan;
     const int i = option_index(key);
-    PCGAN_CHECK(i >= 0, "set_option: unknown option '%s' (bsplit_halo, wgrad_gen, wgrad_padcopy, wgrad_cw, hgemm_bf16)", key ? key : "(null)");
+    PCGAN_CHECK(i >= 0, "set_option: unknown option '%s' (bsplit_halo, wgrad_gen, wgrad_padcopy, wgrad_cw, hgemm_bf16, wgd_look, wgrad_direct)", key ? key : "(null)");
     PCGAN_CHECK(i != OPT_WGRAD_CW || value == 0 || value == 128 || value == 256, "set_option: wgrad_cw takes 0 (default), 128 or 256, got %d", value);
     g_opt[i].store(value);
     return 0;
