@@ -166,12 +166,6 @@ int pcgan_bn_bwd_reduce(const float* s1_nc, const float* s2_nc, float* s1_c, flo
  * old + 1 == N is the last of its call and stores 0 back, so every call starts from 0 whatever N the previous call had (partial last
  * batch of an epoch, test() at another batch size) and a captured graph replays; forward and backward use separate arrays; calls sharing an array must be
  * ordered (one stream, or stream dependencies) -- a BatchNorm layer's passes are ordered anyway for its running statistics. */
-/* The running-statistics update (and batch counter) of a train-mode BatchNorm2d pass once more, from the batch statistics it kept
- * (mean_c, biased var_c over `count` = N*H*W values): the effect on the module's buffers of a second forward pass over the same input
- * with the same weights -- WSGANEmbModel.backward_D's D(fake_B) pass (models/wsgan_emb_model.py:303-305) repeats backward_G's (:386),
- * the build computes it once. */
-int pcgan_bn_running_again(const float* mean_c, const float* var_c, float* running_mean, float* running_var, long long* batches, int C,
-                           long long count, float momentum, pcgan_stream_t s);
 int pcgan_bn_stats_merged(const void* x, float* mean_nc, float* m2_nc, float* mean_c, float* var_c, float* running_mean,
                           float* running_var, long long* batches, unsigned int* ticket, int N, int C, int HW, float momentum, int dtype,
                           pcgan_stream_t s);

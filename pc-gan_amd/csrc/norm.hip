@@ -154,19 +154,6 @@ __global__ void in_running_kernel(const float* __restrict__ mean_nc, const float
     }
 }
 
-// The running-statistics update of a train-mode BatchNorm2d pass applied ONCE MORE from the batch statistics that pass kept (mean_c and
-// the biased var_c): what a second forward pass over the SAME input with the SAME weights would do to the module's buffers, without
-// running it (models/wsgan_emb_model.py: backward_D re-uses backward_G's D(fake_B) activations -- the reference computes that pass twice).
-__global__ void bn_running_again_kernel(const float* __restrict__ mean_c, const float* __restrict__ var_c, float* running_mean,
-                                        float* running_var, long long* batches, int C, float cnt, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean_c[c];
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var_c[c] * cnt / (cnt - 1.f));
-    }
-    if (c == 0 && batches) batches[0] += 1;
-}
-
 struct NormArgs {
     const void* x;          // activation tensors: storage type T of the kernel template
     const void* y;
@@ -803,15 +790,6 @@ extern "C" int pcgan_in_running_update(const float* mean_nc, const float* m2_nc,
                 "in_running_update: bad arguments");
     hipLaunchKernelGGL(in_running_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)s, mean_nc, m2_nc,
                        running_mean, running_var, N, C, HW, momentum);
-    PCGAN_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int pcgan_bn_running_again(const float* mean_c, const float* var_c, float* running_mean, float* running_var, long long* batches, int C,
-                                      long long count, float momentum, pcgan_stream_t s) {
-    PCGAN_CHECK(mean_c && var_c && running_mean && running_var && C > 0 && count > 1, "bn_running_again: bad arguments");
-    hipLaunchKernelGGL(bn_running_again_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)s, mean_c, var_c, running_mean, running_var,
-                       batches, C, (float)count, momentum);
     PCGAN_LAUNCH_CHECK();
     return 0;
 }

@@ -15,25 +15,6 @@ def _c(t):
     return t if (t is None or t.is_contiguous()) else t.contiguous()
 
 
-# Whether backward passes compute PARAMETER gradients.  ctx.needs_input_grad is fixed when the forward runs; a backward traversal that
-# only wants the gradient of an input of a net whose parameters do require gradients (WSGANEmbModel.backward_G through the
-# discriminator when backward_D re-uses that pass: torch.autograd.grad(loss, fake_B) still calls every node's backward in full)
-# switches the weight / bias / affine gradients off here.  Read by the autograd engine's thread while the caller waits: a plain flag.
-_GRAD_CTL = {'params': True}
-
-
-class param_grads(object):
-    def __init__(self, enabled):
-        self.enabled = enabled
-
-    def __enter__(self):
-        self.prev = _GRAD_CTL['params']
-        _GRAD_CTL['params'] = self.enabled
-
-    def __exit__(self, *exc):
-        _GRAD_CTL['params'] = self.prev
-
-
 def _fused_grad_target(p):
     """The parameter's slice of a FusedAdam flat gradient buffer, if it has one: the weight-/bias-gradient
     kernels then add into it directly and autograd receives None (no separate `grad += dw` pass, no dw
@@ -77,8 +58,8 @@ class _Conv2dFn(torch.autograd.Function):
         if act != ACT_NONE:
             dy = ops.act_bwd(dy, y, act, slope)
         dx = dw = db = None
-        want_w = ctx.needs_input_grad[1] and _GRAD_CTL['params']
-        want_b = ctx.has_bias and ctx.needs_input_grad[2] and _GRAD_CTL['params']
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         wt = _fused_grad_target(ctx.params[0]) if want_w else None
         bt = _fused_grad_target(ctx.params[1]) if want_b else None
         if ops.SIDE_STREAM and (not want_w or wt is not None) and (not want_b or bt is not None) and (want_w or want_b):
@@ -255,8 +236,8 @@ class _ConvTranspose2dFn(torch.autograd.Function):
         if ctx.x_amax is not None and ctx.x_amax[0] == x._version and '_pcgan_amax' not in x.__dict__:
             x._pcgan_amax = ctx.x_amax
         dx = dw = db = None
-        want_w = ctx.needs_input_grad[1] and _GRAD_CTL['params']
-        want_b = ctx.has_bias and ctx.needs_input_grad[2] and _GRAD_CTL['params']
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         wt = _fused_grad_target(ctx.params[0]) if want_w else None
         bt = _fused_grad_target(ctx.params[1]) if want_b else None
         if ops.SIDE_STREAM and (not want_w or wt is not None) and (not want_b or bt is not None) and (want_w or want_b):
@@ -288,9 +269,6 @@ def conv_transpose2d(x, w, b=None, stride=2, pad=1, out_pad=1):
 
 
 # ---------------------------------------------------------------------------- norms
-_LAST_STATS = {'in': None, 'bn': None}      # the batch statistics of the LAST norm forward (the calling module keeps them: nn.py)
-
-
 class _InstanceNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, running_mean, running_var, momentum, eps, act, slope, training):
@@ -307,7 +285,6 @@ class _InstanceNormActFn(torch.autograd.Function):
             y = ops.norm_act_fwd(x, mean, var, None, None, residual, per_plane, eps, act, slope)
         ctx.cfg = (eps, act, slope, per_plane, residual is not None)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, var)
-        _LAST_STATS['in'] = (mean, var, N, C, HW) if (training and running_mean is not None) else None
         return y
 
     @staticmethod
@@ -353,7 +330,6 @@ class _BatchNormActFn(torch.autograd.Function):
                 mean, var = running_mean, running_var
             y = ops.norm_act_fwd(x, mean, var, gamma, beta, residual, False, eps, act, slope)
         ctx.cfg = (eps, act, slope, training, residual is not None, fused)
-        _LAST_STATS['bn'] = (mean, var, N * HW) if (training and running_mean is not None and N * HW > 1) else None
         ctx.tickets = tickets
         ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, var, gamma)
         return y
@@ -383,8 +359,8 @@ class _BatchNormActFn(torch.autograd.Function):
                                               want_res and act != ACT_NONE)
         if want_res and dres is None:
             dres = dy
-        dgamma = s2 if (ctx.needs_input_grad[1] and _GRAD_CTL['params']) else None
-        dbeta = s1 if (ctx.needs_input_grad[2] and _GRAD_CTL['params']) else None
+        dgamma = s2 if ctx.needs_input_grad[1] else None
+        dbeta = s1 if ctx.needs_input_grad[2] else None
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 

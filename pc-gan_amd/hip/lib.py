@@ -132,7 +132,6 @@ SIGNATURES = {
     'pcgan_conv2d_hsplit_wgrad_inline': (_i, [_dp]),
     'pcgan_conv2d_hsplit_wgrad_workspace_bytes': (_sz, [_dp]),
     'pcgan_conv2d_bwd_weight_hsplit': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
-    'pcgan_bn_running_again': (_i, [_vp, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _vp]),
     'pcgan_restrunk_fwd': (_i, [_rp, _i, _vp, _vp, _i] + [_vp] * 8 + [_vp] * 6 + [_vp]),
     'pcgan_restrunk_bwd': (_i, [_rp, _i, _vp, _vp, _vp, _i] + [_vp] * 6 + [_vp] * 6 + [_vp] * 6 + [_vp, _sz, _vp, _vp, _vp]),
     'pcgan_conv2d_wgrad_direct_supported': (_i, [_dp]),

@@ -50,17 +50,8 @@ class InstanceNorm2d(tnn.InstanceNorm2d):
         if self.affine:
             raise NotImplementedError('pcgan_amd: InstanceNorm2d(affine=True) is outside the hot path')
         use_input_stats = self.training or not self.track_running_stats
-        y = F.instance_norm_act(x, self.running_mean, self.running_var, self.momentum, self.eps, act, slope,
-                                residual, use_input_stats)
-        self.__dict__['_pcgan_last_stats'] = F._LAST_STATS['in']
-        return y
-
-    def repeat_running_update(self):
-        """apply the running-statistics update of the LAST forward pass once more (a second pass over the same input, not run)"""
-        st = self.__dict__.get('_pcgan_last_stats')
-        if st is not None and self.running_mean is not None:
-            mean, m2, N, C, HW = st
-            F.ops.in_running_update(mean, m2, self.running_mean, self.running_var, N, C, HW, self.momentum)
+        return F.instance_norm_act(x, self.running_mean, self.running_var, self.momentum, self.eps, act, slope,
+                                   residual, use_input_stats)
 
 
 class BatchNorm2d(tnn.BatchNorm2d):
@@ -78,18 +69,9 @@ class BatchNorm2d(tnn.BatchNorm2d):
     def forward(self, x, act=ACT_NONE, slope=0.0, residual=None):
         training = self.training or self.running_mean is None
         tickets = self._tickets(x.device) if (training and x.is_cuda and self.running_mean is not None and BN_TICKETS) else None
-        y = F.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
-                             self.eps, act, slope, residual, training,
-                             self.num_batches_tracked if training else None, tickets)
-        self.__dict__['_pcgan_last_stats'] = F._LAST_STATS['bn'] if training else None
-        return y
-
-    def repeat_running_update(self):
-        """apply the running-statistics update (and the batch counter) of the LAST train-mode forward pass once more"""
-        st = self.__dict__.get('_pcgan_last_stats')
-        if st is not None and self.running_mean is not None:
-            mean, var, count = st
-            F.ops.bn_running_again(mean, var, self.running_mean, self.running_var, self.num_batches_tracked, count, self.momentum)
+        return F.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
+                                self.eps, act, slope, residual, training,
+                                self.num_batches_tracked if training else None, tickets)
 
 
 class Dropout2d(tnn.Dropout2d):

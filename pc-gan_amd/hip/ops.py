@@ -1045,13 +1045,6 @@ def bn_bwd_stats_reduced(dy, x, y, mean, var, eps, act, slope, ticket):
     return sc[:C], sc[C:]
 
 
-def bn_running_again(mean_c, var_c, running_mean, running_var, batches, count, momentum):
-    """the running-statistics update of a train-mode BatchNorm pass once more from the statistics it kept (pcgan_bn_running_again)"""
-    _chk(mean_c, var_c, running_mean, running_var)
-    _L.check(_L.load().pcgan_bn_running_again(_p(mean_c), _p(var_c), _p(running_mean), _p(running_var), _p(batches), mean_c.numel(), int(count),
-                                              float(momentum), _stream()), 'bn_running_again')
-
-
 def in_running_update(mean_nc, m2_nc, running_mean, running_var, N, C, HW, momentum):
     _chk(mean_nc, m2_nc, running_mean, running_var)
     _L.check(_L.load().pcgan_in_running_update(_p(mean_nc), _p(m2_nc), _p(running_mean), _p(running_var), N, C, HW,

@@ -324,13 +324,6 @@ class NLayerDiscriminator(tnn.Module):
         x = HF.concat_z(input, z) if z is not None else input
         return run_sequential(self.model, x)
 
-    def repeat_running_updates(self):
-        """what a second forward pass over the LAST input would do to the norm layers' buffers (running statistics, batch counters),
-        without running it: WSGANEmbModel.backward_D re-uses the D(fake_B) pass of backward_G"""
-        for m in self.model:
-            if hasattr(m, 'repeat_running_update'):
-                m.repeat_running_update()
-
 
 # ------------------------------------------------------------------------- encoders
 class SiameseFeature(tnn.Module):

@@ -45,14 +45,6 @@ _IP_BRANCH = os.environ.get('PCGAN_IP_BRANCH', '0') == '1'
 # (profiles/r04_experiments.txt) -- the step is bound by the total time of its matrix-pipe kernels, not by the join.  Single process
 # only (under torch.distributed the all-reduce sits between backward and update).
 _ADAM_ON_GRAD_STREAM = os.environ.get('PCGAN_ADAM_ON_GRAD_STREAM', '0') == '1'
-# backward_D's first discriminator pass, D(fake_B.detach(), rating) (reference models/wsgan_emb_model.py:303-305), repeats the pass
-# backward_G made for loss_G_GAN (:386) on the SAME image, the SAME rating and the SAME discriminator weights (D is updated after
-# backward_D; the generator's update in between does not touch fake_B, which forward() made).  The build runs that pass ONCE: backward_G
-# differentiates it with respect to fake_B only, backward_D differentiates the kept activations with respect to D's parameters, and the
-# norm layers' running statistics / batch counters receive the second pass's update from the kept batch statistics
-# (NLayerDiscriminator.repeat_running_updates) where that pass would have run.  Same losses, same gradients; one discriminator forward
-# pass (5 convolutions, 3 norm layers) less per step.  PCGAN_REUSE_D_FAKE=0: two passes, as the reference computes them.
-_REUSE_D_FAKE = os.environ.get('PCGAN_REUSE_D_FAKE', '1') == '1'
 
 MAGIC_EPS = 1e-20
 
@@ -351,12 +343,7 @@ class WSGANEmbModel(BaseModel):
 
     def backward_D(self):
         o = self.opt
-        kept = self.__dict__.pop('_d_fake_kept', None)
-        if kept is not None:
-            pred_fake = kept                               # backward_G's pass over the same inputs with the same weights
-            self.netD.repeat_running_updates()             # ... and what running it again would have done to the norm buffers
-        else:
-            pred_fake = self.netD(self.fake_B.detach(), self._rating_for_D().detach())
+        pred_fake = self.netD(self.fake_B.detach(), self._rating_for_D().detach())
         self.loss_D_fake = self.criterionGAN(pred_fake, False)
         img = self.real_A if o.use_real_A else self.real_B
         z_right = self.embedding_A if o.use_real_A else self.embedding_B
@@ -366,10 +353,7 @@ class WSGANEmbModel(BaseModel):
         target = self._relabel_lut.index_select(0, self._label_dev)
         self.loss_D_real_wrong = self.criterionGAN(self.netD(img, z_wrong.detach()), target)
         self.loss_D = (self.loss_D_fake + (self.loss_D_real_right + self.loss_D_real_wrong) * 0.5) * 0.5
-        if kept is not None:      # (the kept pass hangs on a detached copy of fake_B: nothing beyond the discriminator is reached)
-            self.loss_D.backward(inputs=[p for p in self.netD.parameters() if p.requires_grad])
-        else:
-            self.loss_D.backward()
+        self.loss_D.backward()
 
     def _common_G_losses(self):
         o = self.opt
@@ -383,16 +367,7 @@ class WSGANEmbModel(BaseModel):
                 self.loss_G_IP = self.criterionIP(self.netIP(self.transform_IP(self.fake_B_IP)), feature_A) * o.lambda_IP
         else:
             self.loss_G_IP = 0.0
-        self._d_fake_in = None
-        rating = self._rating_for_D()
-        if self._reuse_d_fake(rating):
-            # one discriminator pass for loss_G_GAN AND backward_D's loss_D_fake (see _REUSE_D_FAKE): it hangs on a detached leaf, its
-            # gradient with respect to that leaf is handed to fake_B in backward_G
-            self._d_fake_in = self.fake_B.detach().requires_grad_(True)
-            self._d_fake_kept = self.netD(self._d_fake_in, rating.detach())
-            self.loss_G_GAN = self.criterionGAN(self._d_fake_kept, True)
-        else:
-            self.loss_G_GAN = self.criterionGAN(self.netD(self.fake_B, rating), True)
+        self.loss_G_GAN = self.criterionGAN(self.netD(self.fake_B, self._rating_for_D()), True)
         self._join_rec()
         if o.lambda_A_GAN > 0.0:
             self.loss_G_GAN_cycle = self.criterionGAN(self.netD(self.rec_A, self.embedding_A), True) * o.lambda_A_GAN
@@ -401,12 +376,6 @@ class WSGANEmbModel(BaseModel):
         self.loss_G_L1 = self.criterionL1(self.fake_B, self.real_A) * o.lambda_L1 if o.lambda_L1 > 0.0 else 0.0
         self.loss_G_cycle = self.criterionCycle(self.rec_A, self.real_A) * o.lambda_A if o.lambda_A > 0.0 else 0.0
         return b_ip
-
-    def _reuse_d_fake(self, rating):
-        """may backward_D re-use this step's D(fake_B, rating) pass?  (training, D's parameters will carry gradients in backward_D, the
-        rating carries none to anybody: the frozen encoder's detached embedding)"""
-        return (_REUSE_D_FAKE and self.isTrain and self.fake_B.requires_grad and not rating.requires_grad
-                and getattr(self, '_d_reuse_armed', False))
 
     def backward_G(self):
         o = self.opt
@@ -430,21 +399,6 @@ class WSGANEmbModel(BaseModel):
             b_e.join(self.loss_z_rec)
         if b_ip is not None:
             b_ip.join(self.loss_G_IP)
-        if self._d_fake_in is not None:
-            # the discriminator pass is differentiated with respect to its image only (its parameters keep requires_grad for backward_D:
-            # their gradients are switched off for this traversal), kept for backward_D, and its gradient enters fake_B beside the others
-            from ..hip import functional as HF
-            with HF.param_grads(False):
-                (g_fake,) = torch.autograd.grad(self.loss_G_GAN, self._d_fake_in, retain_graph=True)
-            rest = self.loss_G_IP + self.loss_G_L1 + self.loss_G_cycle + self.loss_z_rec + self.loss_G_GAN_cycle
-            self.loss_G = self.loss_G_GAN.detach() + rest
-            roots, grads = [self.fake_B], [g_fake]
-            if isinstance(rest, torch.Tensor) and rest.requires_grad:
-                roots.append(rest)
-                grads.append(None)
-            torch.autograd.backward(roots, grads)
-            self._d_fake_in = None
-            return
         self.loss_G = self.loss_G_GAN + self.loss_G_IP + self.loss_G_L1 + self.loss_G_cycle + self.loss_z_rec \
             + self.loss_G_GAN_cycle
         if isinstance(self.loss_G, torch.Tensor) and self.loss_G.requires_grad:
@@ -511,10 +465,7 @@ class WSGANEmbModel(BaseModel):
         self._step(self.optimizer_D, 'D')
 
     def update_G(self):
-        # (with the re-used discriminator pass D's parameters keep requires_grad through backward_G -- the pass must record them for
-        # backward_D -- and their gradients are switched off for backward_G's traversal instead: functional.param_grads)
-        self._d_reuse_armed = _REUSE_D_FAKE and self.opt.lambda_A_GAN <= 0.0
-        self.set_requires_grad(self.netD, self._d_reuse_armed)
+        self.set_requires_grad(self.netD, False)
         self.optimizer_G.zero_grad()
         self._wait_updated(self.optimizer_D)      # backward_G runs the discriminator: after its last update
         with hip_ops.defer_side_join(self._on_grad_stream(self.optimizer_G)):
