@@ -373,8 +373,8 @@ int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const void* x, cons
  * Conv2d(dim, dim, 3, bias), InstanceNorm2d (models/networks.py:616-652; 9 blocks x 2 generator passes per step).  The per-op entry
  * points above cost the host one call per launch (6 forward, 10 backward per block: ~12 ms of a 32 ms step); these two launch exactly
  * the same kernels with the same arguments in the same order -- results are bit-identical to the per-op sequence -- from ONE call.
- * fp32 tensors on the fp16 two-piece route only (pcgan_resblock_supported: the shapes pcgan_conv2d_hsplit_supported /
- * pcgan_conv2d_hsplit_wgrad_supported / pcgan_instnorm_fused take); other shapes use the per-op calls.
+ * fp32 tensors on the fp16 two-piece route, or (round 4) bf16 tensors on the one-product forms (pcgan_resblock_supported: the shapes
+ * the residual-convolution kernels and pcgan_instnorm_fused take); other shapes use the per-op calls.
  *
  * forward   y1 = conv1(x) ; h = relu(IN(y1)) ; y2 = conv2(h) ; out = IN(y2) + x.  pk1 / pk2: pcgan_conv2d_hsplit_pack(PASS_FWD).
  *           stats[4][N*C] receives mean1, M2_1, mean2, M2_2 (kept for the backward pass); amax[2][N*C] the plane maxima of h and
@@ -388,6 +388,8 @@ int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const void* x, cons
 typedef struct {
     int N, C, H, W;
     float eps, momentum;
+    int dtype; /* PCGAN_F32: the fp16 two-piece route (x_amax / amax used); PCGAN_BF16 (round 4): bf16 tensors on the one-product forms --
+                  pk*: pcgan_conv2d_bsplit_pack / pcgan_conv2d_bsplit_dgrad_pack, x_amax / h_amax / amax unused (may be NULL) */
 } pcgan_resblock_desc;
 typedef void* pcgan_event_t; /* hipEvent_t */
 int pcgan_event_create(pcgan_event_t* ev);

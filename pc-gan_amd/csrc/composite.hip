@@ -11,9 +11,10 @@ namespace {
 inline pcgan_conv_desc conv_of(const pcgan_resblock_desc* d) {
     pcgan_conv_desc c;
     c.N = d->N; c.C = d->C; c.H = d->H; c.W = d->W; c.K = d->C; c.R = 3; c.S = 3;
-    c.stride = 1; c.pad = 1; c.pad_mode = 1; c.P = d->H; c.Q = d->W; c.dtype = PCGAN_F32;
+    c.stride = 1; c.pad = 1; c.pad_mode = 1; c.P = d->H; c.Q = d->W; c.dtype = d->dtype;
     return c;
 }
+inline bool half_of(const pcgan_resblock_desc* d) { return d->dtype == PCGAN_BF16; }
 }  // namespace
 
 extern "C" int pcgan_event_create(pcgan_event_t* ev) {
@@ -31,8 +32,11 @@ extern "C" int pcgan_event_destroy(pcgan_event_t ev) {
 }
 
 extern "C" int pcgan_resblock_supported(const pcgan_resblock_desc* d) {
-    if (!d || d->N < 1 || d->C < 1 || d->H < 3 || d->W < 3) return 0;
+    if (!d || d->N < 1 || d->C < 1 || d->H < 3 || d->W < 3 || (d->dtype != PCGAN_F32 && d->dtype != PCGAN_BF16)) return 0;
     const pcgan_conv_desc c = conv_of(d);
+    if (half_of(d))      // bf16 tensors: the one-product forms of the same kernels (no operand maxima, no scaling)
+        return pcgan_conv2d_bsplit_supported(&c) && pcgan_conv2d_bsplit_dgrad_supported(&c) && pcgan_conv2d_hsplit_wgrad_supported(&c) &&
+               pcgan_instnorm_fused(d->H * d->W);
     return pcgan_conv2d_hsplit_supported(&c, PCGAN_PASS_FWD) && pcgan_conv2d_hsplit_supported(&c, PCGAN_PASS_BWD_DATA) &&
            pcgan_conv2d_hsplit_wgrad_supported(&c) && pcgan_instnorm_fused(d->H * d->W);
 }
@@ -53,10 +57,20 @@ extern "C" int pcgan_resblock_fwd(const pcgan_resblock_desc* d, const void* x, c
                                   const float* b1, const void* pk2, const float* b2, float* rm1, float* rv1, float* rm2, float* rv2,
                                   void* y1, void* h, void* y2, void* out, float* stats, float* amax, pcgan_stream_t s) {
     PCGAN_CHECK(pcgan_resblock_supported(d), "resblock_fwd: unsupported shape");
-    PCGAN_CHECK(x && x_amax && n_xamax > 0 && pk1 && pk2 && y1 && h && y2 && out && stats && amax, "resblock_fwd: null pointer");
+    const bool half = half_of(d);
+    PCGAN_CHECK(x && (half || (x_amax && n_xamax > 0)) && pk1 && pk2 && y1 && h && y2 && out && stats && (half || amax), "resblock_fwd: null pointer");
     const pcgan_conv_desc c = conv_of(d);
     const int N = d->N, C = d->C, HW = d->H * d->W, NC = N * C;
     float *mean1 = stats, *m21 = stats + NC, *mean2 = stats + 2 * (size_t)NC, *m22 = stats + 3 * (size_t)NC;
+    if (half) {      // bf16 tensors (pk1 / pk2: pcgan_conv2d_bsplit_pack): same sequence, no operand maxima
+        STEP(pcgan_conv2d_fwd_bsplit(&c, x, pk1, b1, y1, PCGAN_ACT_NONE, 0.f, s));
+        STEP(pcgan_instnorm_fwd(y1, nullptr, h, mean1, m21, nullptr, N, C, HW, d->eps, PCGAN_ACT_RELU, 0.f, PCGAN_BF16, s));
+        if (rm1 && rv1) STEP(pcgan_in_running_update(mean1, m21, rm1, rv1, N, C, HW, d->momentum, s));
+        STEP(pcgan_conv2d_fwd_bsplit(&c, h, pk2, b2, y2, PCGAN_ACT_NONE, 0.f, s));
+        STEP(pcgan_instnorm_fwd(y2, x, out, mean2, m22, nullptr, N, C, HW, d->eps, PCGAN_ACT_NONE, 0.f, PCGAN_BF16, s));
+        if (rm2 && rv2) STEP(pcgan_in_running_update(mean2, m22, rm2, rv2, N, C, HW, d->momentum, s));
+        return 0;
+    }
     float *h_amax = amax, *o_amax = amax + NC;
     STEP(pcgan_conv2d_fwd_hsplit(&c, x, x_amax, n_xamax, pk1, b1, y1, PCGAN_ACT_NONE, 0.f, s));
     STEP(pcgan_instnorm_fwd(y1, nullptr, h, mean1, m21, h_amax, N, C, HW, d->eps, PCGAN_ACT_RELU, 0.f, PCGAN_F32, s));
@@ -73,7 +87,8 @@ extern "C" int pcgan_resblock_bwd(const pcgan_resblock_desc* d, const void* dout
                                   float* scratch, void* wgrad_ws, size_t wgrad_ws_bytes, pcgan_stream_t s, pcgan_stream_t side,
                                   pcgan_event_t fork_event) {
     PCGAN_CHECK(pcgan_resblock_supported(d), "resblock_bwd: unsupported shape");
-    PCGAN_CHECK(dout && x && x_amax && n_xamax > 0 && y1 && h && h_amax && y2 && stats && pk1b && pk2b && dw1 && dw2 && dy2 && dh && dy1 &&
+    const bool half = half_of(d);
+    PCGAN_CHECK(dout && x && (half || (x_amax && n_xamax > 0 && h_amax)) && y1 && h && y2 && stats && pk1b && pk2b && dw1 && dw2 && dy2 && dh && dy1 &&
                     dx && scratch && wgrad_ws && fork_event,
                 "resblock_bwd: null pointer");
     PCGAN_CHECK(side && side != s, "resblock_bwd: the parameter-gradient stream must be a second stream");
@@ -83,6 +98,22 @@ extern "C" int pcgan_resblock_bwd(const pcgan_resblock_desc* d, const void* dout
     float *psum = scratch, *dy2_amax = scratch + NC, *dy1_amax = scratch + 2 * (size_t)NC, *psum1 = scratch + 3 * (size_t)NC;
     hipStream_t ms = (hipStream_t)s, ss = (hipStream_t)side;
     hipEvent_t ev = (hipEvent_t)fork_event;
+    if (half) {      // bf16 tensors (pk1b / pk2b: pcgan_conv2d_bsplit_dgrad_pack): the same sequence; the skip connection's gradient is
+                     // added by pcgan_add after the data gradient (the per-op path's autograd sum: one bf16 rounding of the fp32 sum
+                     // either way), into dx from dh, which is free by then
+        STEP(pcgan_instnorm_bwd(dout, y2, nullptr, mean2, m22, dy2, psum, nullptr, nullptr, N, C, HW, d->eps, PCGAN_ACT_NONE, 0.f, PCGAN_BF16, s));
+        PCGAN_CHECK(hipEventRecord(ev, ms) == hipSuccess && hipStreamWaitEvent(ss, ev, 0) == hipSuccess, "resblock_bwd: stream fork failed");
+        STEP(pcgan_conv2d_bwd_weight_hsplit(&c, h, nullptr, 0, dy2, nullptr, 0, dw2, 1, wgrad_ws, wgrad_ws_bytes, side));
+        if (db2) STEP(pcgan_sum_planes(psum, db2, N, C, 1, side));
+        STEP(pcgan_conv2d_bwd_data_bsplit(&c, dy2, pk2b, dh, s));
+        STEP(pcgan_instnorm_bwd(dh, y1, h, mean1, m21, dy1, psum1, nullptr, nullptr, N, C, HW, d->eps, PCGAN_ACT_RELU, 0.f, PCGAN_BF16, s));
+        PCGAN_CHECK(hipEventRecord(ev, ms) == hipSuccess && hipStreamWaitEvent(ss, ev, 0) == hipSuccess, "resblock_bwd: stream fork failed");
+        STEP(pcgan_conv2d_bwd_weight_hsplit(&c, x, nullptr, 0, dy1, nullptr, 0, dw1, 1, wgrad_ws, wgrad_ws_bytes, side));
+        if (db1) STEP(pcgan_sum_planes(psum1, db1, N, C, 1, side));
+        STEP(pcgan_conv2d_bwd_data_bsplit(&c, dy1, pk1b, dh, s));
+        STEP(pcgan_add(dh, dout, dx, (size_t)NC * HW, PCGAN_BF16, s));
+        return 0;
+    }
     // second half of the block: out = IN(y2) + x
     STEP(pcgan_instnorm_bwd(dout, y2, nullptr, mean2, m22, dy2, psum, dy2_amax, nullptr, N, C, HW, d->eps, PCGAN_ACT_NONE, 0.f, PCGAN_F32, s));
     PCGAN_CHECK(hipEventRecord(ev, ms) == hipSuccess && hipStreamWaitEvent(ss, ev, 0) == hipSuccess, "resblock_bwd: stream fork failed");
@@ -109,9 +140,9 @@ extern "C" int pcgan_restrunk_fwd(const pcgan_resblock_desc* d, int nblocks, con
                                   float* const* rm1, float* const* rv1, float* const* rm2, float* const* rv2, void* y1, void* h, void* y2,
                                   void* out, float* stats, float* amax, pcgan_stream_t s) {
     PCGAN_CHECK(pcgan_resblock_supported(d) && nblocks >= 1, "restrunk_fwd: unsupported shape or empty chain");
-    PCGAN_CHECK(x && x_amax && n_xamax > 0 && pk1 && pk2 && b1 && b2 && rm1 && rv1 && rm2 && rv2 && y1 && h && y2 && out && stats && amax,
+    PCGAN_CHECK(x && (half_of(d) || (x_amax && n_xamax > 0)) && pk1 && pk2 && b1 && b2 && rm1 && rv1 && rm2 && rv2 && y1 && h && y2 && out && stats && amax,
                 "restrunk_fwd: null pointer");
-    const size_t NC = (size_t)d->N * d->C, el = NC * d->H * d->W * 4;
+    const size_t NC = (size_t)d->N * d->C, el = NC * d->H * d->W * (half_of(d) ? 2 : 4);
     for (int i = 0; i < nblocks; ++i) {
         const void* xi = i == 0 ? x : (const char*)out + (size_t)(i - 1) * el;
         const float* xa = i == 0 ? x_amax : amax + (size_t)(i - 1) * 2 * NC + NC;
@@ -130,10 +161,10 @@ extern "C" int pcgan_restrunk_bwd(const pcgan_resblock_desc* d, int nblocks, con
                                   float* const* db2, void* dy2, void* dh, void* dy1, void* dxs, void* dx, float* scratch, void* wgrad_ws,
                                   size_t wgrad_ws_bytes, pcgan_stream_t s, pcgan_stream_t side, pcgan_event_t fork_event) {
     PCGAN_CHECK(pcgan_resblock_supported(d) && nblocks >= 1, "restrunk_bwd: unsupported shape or empty chain");
-    PCGAN_CHECK(dout && x && x_amax && n_xamax > 0 && y1 && h && y2 && out && stats && amax && pk1b && pk2b && dw1 && db1 && dw2 && db2 &&
+    PCGAN_CHECK(dout && x && (half_of(d) || (x_amax && n_xamax > 0)) && y1 && h && y2 && out && stats && amax && pk1b && pk2b && dw1 && db1 && dw2 && db2 &&
                     dy2 && dh && dy1 && dxs && dx && scratch && wgrad_ws && fork_event,
                 "restrunk_bwd: null pointer");
-    const size_t NC = (size_t)d->N * d->C, el = NC * d->H * d->W * 4;
+    const size_t NC = (size_t)d->N * d->C, el = NC * d->H * d->W * (half_of(d) ? 2 : 4);
     const void* g = dout;
     for (int i = nblocks - 1; i >= 0; --i) {
         const void* xi = i == 0 ? x : (const char*)out + (size_t)(i - 1) * el;

@@ -116,7 +116,7 @@ class _ResBlockFn(torch.autograd.Function):
 
 def resblock_composite_ok(x, conv1, conv2, in1, in2):
     """the launch plan if this ResnetBlock call can take the composite path, else None"""
-    if not (ops.COMPOSITE and ops.SIDE_STREAM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+    if not (ops.COMPOSITE and ops.SIDE_STREAM and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 4 and x.is_contiguous()):
         return None
     if in1.eps != in2.eps or in1.momentum != in2.momentum or in1.momentum is None:
         return None
@@ -129,7 +129,7 @@ def resblock_composite_ok(x, conv1, conv2, in1, in2):
             return None
     if (conv1.bias is None) != (conv2.bias is None):
         return None
-    pl = ops.resblock_plan(N, C, H, W, in1.eps, in1.momentum)
+    pl = ops.resblock_plan(N, C, H, W, in1.eps, in1.momentum, ops.F32 if x.dtype == torch.float32 else ops.BF16)
     if not pl.ok:
         return None
     params = [p for p in (conv1.weight, conv1.bias, conv2.weight, conv2.bias) if p is not None]

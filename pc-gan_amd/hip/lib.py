@@ -23,7 +23,7 @@ class ImageDesc(ctypes.Structure):
 class ResBlockDesc(ctypes.Structure):
     """pcgan_resblock_desc (include/pcgan_hip.h)."""
     _fields_ = [('N', ctypes.c_int), ('C', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('eps', ctypes.c_float),
-                ('momentum', ctypes.c_float)]
+                ('momentum', ctypes.c_float), ('dtype', ctypes.c_int)]
 
 
 class ConvDesc(ctypes.Structure):

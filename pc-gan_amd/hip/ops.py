@@ -746,24 +746,26 @@ _WGRAD_WS = {}
 
 
 class _RBPlan(object):
-    __slots__ = ('d', 'dref', 'ok', 'conv', 'ws_bytes')
+    __slots__ = ('d', 'dref', 'ok', 'conv', 'ws_bytes', 'fwd_pass', 'bwd_pass', 'half')
 
 
-def resblock_plan(N, C, H, W, eps, momentum):
-    key = (N, C, H, W, float(eps), float(momentum), BF16X6, HSPLIT, HGEMM, BSPLIT_MIN_PIXELS)
+def resblock_plan(N, C, H, W, eps, momentum, dt=F32):
+    key = (N, C, H, W, float(eps), float(momentum), dt, BF16X6, HSPLIT, HGEMM, BSPLIT_MIN_PIXELS)
     p = _RB_PLANS.get(key)
     if p is None:
         lib = _L.load()
         p = _RBPlan()
-        p.d = ResBlockDesc(N, C, H, W, float(eps), float(momentum))
+        p.d = ResBlockDesc(N, C, H, W, float(eps), float(momentum), dt)
         p.dref = ctypes.byref(p.d)
-        # the composite is the per-op sequence on the fp16 route: taken exactly where the host would route all three passes there
-        p.ok = bool(COMPOSITE and lib.pcgan_resblock_supported(p.dref)
-                    and _plan(_L.PASS_FWD, N, C, H, W, C, 3, 3, 1, 1, 1, F32).route == 'hsplit'
-                    and _plan(_L.PASS_BWD_DATA, N, C, H, W, C, 3, 3, 1, 1, 1, F32).route == 'hsplit'
-                    and _plan(_L.PASS_BWD_WEIGHT, N, C, H, W, C, 3, 3, 1, 1, 1, F32).route == 'hsplit')
-        p.conv = _plan(_L.PASS_FWD, N, C, H, W, C, 3, 3, 1, 1, 1, F32).d if p.ok else None
+        # the composite is the per-op sequence: taken exactly where the host would route all three passes to the kernels it calls -- fp32
+        # tensors: the fp16 two-piece route; bf16 tensors (round 4): the one-product window kernels + the matrix-pipe weight gradient
+        want = ('hsplit', 'hsplit', 'hsplit') if dt == F32 else ('bsplit', 'bsplit', 'hsplit')
+        got = tuple(_plan(ps, N, C, H, W, C, 3, 3, 1, 1, 1, dt).route for ps in (_L.PASS_FWD, _L.PASS_BWD_DATA, _L.PASS_BWD_WEIGHT))
+        p.ok = bool(COMPOSITE and lib.pcgan_resblock_supported(p.dref) and got == want)
+        p.conv = _plan(_L.PASS_FWD, N, C, H, W, C, 3, 3, 1, 1, 1, dt).d if p.ok else None
         p.ws_bytes = int(lib.pcgan_resblock_wgrad_workspace_bytes(p.dref)) if p.ok else 0
+        p.fwd_pass, p.bwd_pass = (PASS_FWD_HSPLIT, PASS_BWD_HSPLIT) if dt == F32 else (PASS_FWD_BSPLIT, PASS_BWD_BSPLIT)
+        p.half = dt != F32
         _RB_PLANS[key] = p
     return p
 
@@ -779,32 +781,36 @@ def _fork_event(device):
 
 def resblock_fwd(pl, x, w1, b1, w2, b2, rm1, rv1, rm2, rv2, pack1, pack2):
     """returns out, (y1, h, y2, stats, amax, x_amax): everything the backward call needs besides x"""
-    _chk(x, w1, b1, w2, b2, rm1, rv1, rm2, rv2)
+    _chk(w1, b1, w2, b2, rm1, rv1, rm2, rv2)
+    _act(x)
     lib = _L.load()
     N, C = x.shape[0], x.shape[1]
-    pk1 = _packed_weights(lib, pl.conv, PASS_FWD_HSPLIT, w1, pack1)
-    pk2 = _packed_weights(lib, pl.conv, PASS_FWD_HSPLIT, w2, pack2)
-    xmax = amax_of(x)
+    pk1 = _packed_weights(lib, pl.conv, pl.fwd_pass, w1, pack1)
+    pk2 = _packed_weights(lib, pl.conv, pl.fwd_pass, w2, pack2)
+    xmax = None if pl.half else amax_of(x)      # (bf16 tensors: one product, no operand scaling)
     y1, h, y2, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
     stats = torch.empty(4 * N * C, dtype=torch.float32, device=x.device)
-    amax = torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
-    _L.check(lib.pcgan_resblock_fwd(pl.dref, _p(x), _p(xmax), xmax.numel(), _p(pk1), _p(b1), _p(pk2), _p(b2), _p(rm1), _p(rv1), _p(rm2),
-                                    _p(rv2), _p(y1), _p(h), _p(y2), _p(out), _p(stats), _p(amax), _stream()), 'resblock_fwd')
-    _count_route('fwd', 'hsplit')
-    _count_route('fwd', 'hsplit')
+    amax = None if pl.half else torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
+    _L.check(lib.pcgan_resblock_fwd(pl.dref, _p(x), _p(xmax), 0 if pl.half else xmax.numel(), _p(pk1), _p(b1), _p(pk2), _p(b2), _p(rm1), _p(rv1),
+                                    _p(rm2), _p(rv2), _p(y1), _p(h), _p(y2), _p(out), _p(stats), _p(amax), _stream()), 'resblock_fwd')
+    route = 'bsplit' if pl.half else 'hsplit'
+    _count_route('fwd', route)
+    _count_route('fwd', route)
     COMPOSITE_STATS['fwd'] += 1
-    _attach_amax(out, amax[N * C:])
+    if not pl.half:
+        _attach_amax(out, amax[N * C:])
     return out, (y1, h, y2, stats, amax, xmax)
 
 
 def resblock_bwd(pl, dout, x, saved, w1, w2, dw1, db1, dw2, db2, pack1, pack2):
     """dx (skip connection included); the parameter gradients are ADDED into dw* / db* on the parameter-gradient stream"""
-    _chk(dout, x, dw1, db1, dw2, db2)
+    _chk(dw1, db1, dw2, db2)
+    _act(dout, x)
     y1, h, y2, stats, amax, xmax = saved
     lib = _L.load()
     N, C = x.shape[0], x.shape[1]
-    pk1b = _packed_weights(lib, pl.conv, PASS_BWD_HSPLIT, w1, pack1)
-    pk2b = _packed_weights(lib, pl.conv, PASS_BWD_HSPLIT, w2, pack2)
+    pk1b = _packed_weights(lib, pl.conv, pl.bwd_pass, w1, pack1)
+    pk2b = _packed_weights(lib, pl.conv, pl.bwd_pass, w2, pack2)
     cur = torch.cuda.current_stream()
     side = side_stream_for(cur)
     wkey = (x.device, pl.ws_bytes)
@@ -815,14 +821,16 @@ def resblock_bwd(pl, dout, x, saved, w1, w2, dw1, db1, dw2, db2, pack1, pack2):
     dy2, dh, dy1, dx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
     scratch = torch.empty(5 * N * C, dtype=torch.float32, device=x.device)
     for t in (x, h, dy2, dy1, scratch, amax, xmax):      # read by the side stream after this call returns
-        t.record_stream(side)
-    _L.check(lib.pcgan_resblock_bwd(pl.dref, _p(dout), _p(x), _p(xmax), xmax.numel(), _p(y1), _p(h), _p(amax), _p(y2), _p(stats), _p(pk1b),
+        if t is not None:
+            t.record_stream(side)
+    _L.check(lib.pcgan_resblock_bwd(pl.dref, _p(dout), _p(x), _p(xmax), 0 if pl.half else xmax.numel(), _p(y1), _p(h), _p(amax), _p(y2), _p(stats), _p(pk1b),
                                     _p(pk2b), _p(dw1), _p(db1), _p(dw2), _p(db2), _p(dy2), _p(dh), _p(dy1), _p(dx), _p(scratch), _p(ws),
                                     ws.numel(), _vp(cur.cuda_stream), _vp(side.cuda_stream), _fork_event(x.device)), 'resblock_bwd')
     for _ in range(2):
-        _count_route('dgrad', 'hsplit')
+        _count_route('dgrad', 'bsplit' if pl.half else 'hsplit')
         _count_route('wgrad', 'hsplit')
-    AMAX_STATS['attached'] += 6        # (x, h, dy2 x 2, dy1 x 2: the operand maxima all came from the norm kernels)
+    if not pl.half:
+        AMAX_STATS['attached'] += 6        # (x, h, dy2 x 2, dy1 x 2: the operand maxima all came from the norm kernels)
     PLANE_SUM_STATS['fused'] += 2
     COMPOSITE_STATS['bwd'] += 1
     mark_side_used()
@@ -844,25 +852,27 @@ def restrunk_fwd(pl, x, blocks):
     N, C = x.shape[0], x.shape[1]
     for b in blocks:
         _chk(*b[:8])
-    _chk(x)
-    pk1 = [_packed_weights(lib, pl.conv, PASS_FWD_HSPLIT, b[0], b[8]) for b in blocks]
-    pk2 = [_packed_weights(lib, pl.conv, PASS_FWD_HSPLIT, b[2], b[9]) for b in blocks]
-    xmax = amax_of(x)
+    _act(x)
+    pk1 = [_packed_weights(lib, pl.conv, pl.fwd_pass, b[0], b[8]) for b in blocks]
+    pk2 = [_packed_weights(lib, pl.conv, pl.fwd_pass, b[2], b[9]) for b in blocks]
+    xmax = None if pl.half else amax_of(x)
     shape = (nb,) + tuple(x.shape)
     y1, h, y2, out = (torch.empty(shape, dtype=x.dtype, device=x.device) for _ in range(4))
     stats = torch.empty(nb * 4 * N * C, dtype=torch.float32, device=x.device)
     amax = torch.empty(nb * 2 * N * C, dtype=torch.float32, device=x.device)
-    _L.check(lib.pcgan_restrunk_fwd(pl.dref, nb, _p(x), _p(xmax), xmax.numel(), _ptr_array(pk1), _ptr_array([b[1] for b in blocks]),
+    _L.check(lib.pcgan_restrunk_fwd(pl.dref, nb, _p(x), _p(xmax), 0 if pl.half else xmax.numel(), _ptr_array(pk1), _ptr_array([b[1] for b in blocks]),
                                     _ptr_array(pk2), _ptr_array([b[3] for b in blocks]), _ptr_array([b[4] for b in blocks]),
                                     _ptr_array([b[5] for b in blocks]), _ptr_array([b[6] for b in blocks]), _ptr_array([b[7] for b in blocks]),
                                     _p(y1), _p(h), _p(y2), _p(out), _p(stats), _p(amax), _stream()), 'restrunk_fwd')
-    ROUTE_STATS[('fwd', 'hsplit')] = ROUTE_STATS.get(('fwd', 'hsplit'), 0) + 2 * nb
+    rk = ('fwd', 'bsplit' if pl.half else 'hsplit')
+    ROUTE_STATS[rk] = ROUTE_STATS.get(rk, 0) + 2 * nb
     COMPOSITE_STATS['fwd'] += nb
     COMPOSITE_STATS['trunk_fwd'] = COMPOSITE_STATS.get('trunk_fwd', 0) + 1
-    AMAX_STATS['attached'] += 2 * nb - 1      # (every convolution but the first took its operand maxima from the norm kernel in front of it)
     last = out[nb - 1]
-    _attach_amax(last, amax[(2 * nb - 1) * N * C:])
-    _LAST_TRUNK['amax'] = last.__dict__['_pcgan_amax']      # (autograd may hand the caller another tensor object for a view output)
+    if not pl.half:
+        AMAX_STATS['attached'] += 2 * nb - 1      # (every convolution but the first took its operand maxima from the norm kernel in front of it)
+        _attach_amax(last, amax[(2 * nb - 1) * N * C:])
+        _LAST_TRUNK['amax'] = last.__dict__['_pcgan_amax']      # (autograd may hand the caller another tensor object for a view output)
     return last, (y1, h, y2, out, stats, amax, xmax)
 
 
@@ -872,9 +882,9 @@ def restrunk_bwd(pl, dout, x, saved, blocks):
     lib = _L.load()
     nb = len(blocks)
     N, C = x.shape[0], x.shape[1]
-    _chk(dout, x)
-    pk1b = [_packed_weights(lib, pl.conv, PASS_BWD_HSPLIT, b[0], b[6]) for b in blocks]
-    pk2b = [_packed_weights(lib, pl.conv, PASS_BWD_HSPLIT, b[1], b[7]) for b in blocks]
+    _act(dout, x)
+    pk1b = [_packed_weights(lib, pl.conv, pl.bwd_pass, b[0], b[6]) for b in blocks]
+    pk2b = [_packed_weights(lib, pl.conv, pl.bwd_pass, b[1], b[7]) for b in blocks]
     cur = torch.cuda.current_stream()
     side = side_stream_for(cur)
     wkey = (x.device, pl.ws_bytes)
@@ -888,15 +898,18 @@ def restrunk_bwd(pl, dout, x, saved, blocks):
     dxs = torch.empty((2,) + tuple(x.shape), dtype=x.dtype, device=x.device)
     scratch = torch.empty(nb * 5 * N * C, dtype=torch.float32, device=x.device)
     for t in (x, h, out, dy2, dy1, scratch, amax, xmax):      # read by the side stream after this call returns
-        t.record_stream(side)
-    _L.check(lib.pcgan_restrunk_bwd(pl.dref, nb, _p(dout), _p(x), _p(xmax), xmax.numel(), _p(y1), _p(h), _p(y2), _p(out), _p(stats), _p(amax),
+        if t is not None:
+            t.record_stream(side)
+    _L.check(lib.pcgan_restrunk_bwd(pl.dref, nb, _p(dout), _p(x), _p(xmax), 0 if pl.half else xmax.numel(), _p(y1), _p(h), _p(y2), _p(out), _p(stats), _p(amax),
                                     _ptr_array(pk1b), _ptr_array(pk2b), _ptr_array([b[2] for b in blocks]), _ptr_array([b[3] for b in blocks]),
                                     _ptr_array([b[4] for b in blocks]), _ptr_array([b[5] for b in blocks]), _p(dy2), _p(dh), _p(dy1), _p(dxs),
                                     _p(dx), _p(scratch), _p(ws), ws.numel(), _vp(cur.cuda_stream), _vp(side.cuda_stream),
                                     _fork_event(x.device)), 'restrunk_bwd')
-    ROUTE_STATS[('dgrad', 'hsplit')] = ROUTE_STATS.get(('dgrad', 'hsplit'), 0) + 2 * nb
+    dk = ('dgrad', 'bsplit' if pl.half else 'hsplit')
+    ROUTE_STATS[dk] = ROUTE_STATS.get(dk, 0) + 2 * nb
     ROUTE_STATS[('wgrad', 'hsplit')] = ROUTE_STATS.get(('wgrad', 'hsplit'), 0) + 2 * nb
-    AMAX_STATS['attached'] += 6 * nb
+    if not pl.half:
+        AMAX_STATS['attached'] += 6 * nb
     PLANE_SUM_STATS['fused'] += 2 * nb
     COMPOSITE_STATS['bwd'] += nb
     COMPOSITE_STATS['trunk_bwd'] = COMPOSITE_STATS.get('trunk_bwd', 0) + 1

@@ -33,7 +33,8 @@ def _run(blk, opt, xs, dys):
         x = x0.clone().requires_grad_(True)
         # the block input arrives from an instance-norm kernel in the generator: hand its operand maxima over the same way
         xin = x * 1.0
-        ops._attach_amax(xin, ops.amax_of(xin.detach()))
+        if xin.dtype == torch.float32:
+            ops._attach_amax(xin, ops.amax_of(xin.detach()))
         out = blk(xin)
         out.backward(dy)
         outs.append(out.detach().clone())
@@ -43,13 +44,17 @@ def _run(blk, opt, xs, dys):
     return outs, dxs, opt.gflat.detach().clone(), {k: v.detach().clone() for k, v in blk.state_dict().items() if 'running' in k}
 
 
-@pytest.mark.parametrize('N,C,H', [(4, 256, 32), (2, 256, 64), (32, 256, 32)])
-def test_resblock_composite_is_the_per_op_sequence(dev, monkeypatch, N, C, H):
+@pytest.mark.parametrize('N,C,H,dt', [(4, 256, 32, 'fp32'), (2, 256, 64, 'fp32'), (32, 256, 32, 'fp32'), (4, 256, 32, 'bf16'), (32, 256, 32, 'bf16'),
+                                      (2, 256, 64, 'bf16')])
+def test_resblock_composite_is_the_per_op_sequence(dev, monkeypatch, N, C, H, dt):
+    """fp32 tensors (fp16 two-piece route) and, since round 4, bf16 tensors (one-product kernels; the skip connection's gradient added by
+    pcgan_add where the per-op path lets autograd add it: one bf16 rounding of the fp32 sum either way)"""
     from pcgan_amd.hip import ops
     monkeypatch.setattr(ops, 'BSPLIT_MIN_PIXELS', 0)
     g = torch.Generator().manual_seed(N + H)
-    xs = [(torch.randn(N, C, H, H, generator=g) * 0.7).to(dev) for _ in range(2)]
-    dys = [torch.randn(N, C, H, H, generator=g).to(dev) for _ in range(2)]
+    tdt = torch.float32 if dt == 'fp32' else torch.bfloat16
+    xs = [(torch.randn(N, C, H, H, generator=g) * 0.7).to(dev).to(tdt) for _ in range(2)]
+    dys = [torch.randn(N, C, H, H, generator=g).to(dev).to(tdt) for _ in range(2)]
     b1, o1 = _block(dev, C)
     b2, o2 = _block(dev, C)
     assert all(torch.equal(p, q) for p, q in zip(b1.parameters(), b2.parameters()))
@@ -71,12 +76,14 @@ def test_resblock_composite_is_the_per_op_sequence(dev, monkeypatch, N, C, H):
     monkeypatch.setattr(ops, 'COMPOSITE', True)
     with torch.no_grad():
         xin = xs[0] * 1.0
-        ops._attach_amax(xin, ops.amax_of(xin))
+        if dt == 'fp32':
+            ops._attach_amax(xin, ops.amax_of(xin))
         y = b1(xin)
     monkeypatch.setattr(ops, 'COMPOSITE', False)
     with torch.no_grad():
         xin = xs[0] * 1.0
-        ops._attach_amax(xin, ops.amax_of(xin))
+        if dt == 'fp32':
+            ops._attach_amax(xin, ops.amax_of(xin))
         y2 = b2(xin)
     assert torch.equal(y, y2)
 
@@ -135,8 +142,8 @@ def test_full_size_step_composite_equals_per_op(tmp_path, dev, monkeypatch):
             assert torch.equal(a['bufs'][k], b['bufs'][k]), k
 
 
-@pytest.mark.parametrize('nb,N,H', [(3, 4, 32), (9, 32, 32), (2, 2, 64)])
-def test_restrunk_is_the_chain_of_block_calls(dev, monkeypatch, nb, N, H):
+@pytest.mark.parametrize('nb,N,H,dt', [(3, 4, 32, 'fp32'), (9, 32, 32, 'fp32'), (2, 2, 64, 'fp32'), (3, 4, 32, 'bf16'), (9, 32, 32, 'bf16')])
+def test_restrunk_is_the_chain_of_block_calls(dev, monkeypatch, nb, N, H, dt):
     """pcgan_restrunk_fwd / _bwd on a chain of nb ResnetBlocks inside an nn.Sequential (as in ResnetGenerator): output, input gradient,
     every weight / bias gradient accumulated over two passes and every running statistic BIT-IDENTICAL to one composite call per block;
     the chain's output carries its plane maxima for the next convolution"""
@@ -157,8 +164,9 @@ def test_restrunk_is_the_chain_of_block_calls(dev, monkeypatch, nb, N, H):
         return seq, FusedAdam(seq.parameters(), lr=2e-4, betas=(0.5, 0.999))
 
     g = torch.Generator().manual_seed(nb + N)
-    xs = [(torch.randn(N, C, H, H, generator=g) * 0.7).to(dev) for _ in range(2)]
-    dys = [torch.randn(N, C, H, H, generator=g).to(dev) for _ in range(2)]
+    tdt = torch.float32 if dt == 'fp32' else torch.bfloat16
+    xs = [(torch.randn(N, C, H, H, generator=g) * 0.7).to(dev).to(tdt) for _ in range(2)]
+    dys = [torch.randn(N, C, H, H, generator=g).to(dev).to(tdt) for _ in range(2)]
 
     def run(trunk):
         monkeypatch.setattr(ops, 'TRUNK', trunk)
@@ -169,9 +177,10 @@ def test_restrunk_is_the_chain_of_block_calls(dev, monkeypatch, nb, N, H):
         for x0, dy in zip(xs, dys):
             x = x0.clone().requires_grad_(True)
             xin = x * 1.0
-            ops._attach_amax(xin, ops.amax_of(xin.detach()))
+            if dt == 'fp32':
+                ops._attach_amax(xin, ops.amax_of(xin.detach()))
             out = hnn.run_sequential(seq, xin)
-            assert '_pcgan_amax' in out.__dict__ and out.__dict__['_pcgan_amax'][0] == out._version, 'the chain output lost its plane maxima'
+            assert dt != 'fp32' or ('_pcgan_amax' in out.__dict__ and out.__dict__['_pcgan_amax'][0] == out._version), 'the chain output lost its plane maxima'
             out.backward(dy)
             outs.append(out.detach().clone())
             dxs.append(x.grad.detach().clone())
