@@ -544,6 +544,82 @@ def check_nonfinite(where=''):
                            'inputs were already non-finite' % (n, (' (' + where + ')') if where else ''))
 
 
+# ---- the route table -------------------------------------------------------------------------------------------------------------------
+# Which kernel family a convolution call takes is DECLARED here: per pass an ordered list of (route, packed-weight pass, condition,
+# workspace query); the first entry whose condition holds wins.  A condition sees one context object `c`: the shape (N, C, H, W, K, R,
+# S, stride, pad, pad_mode, P, Q, dt, no_bias), the routing switches as they stand, the library handle and the descriptor.  The
+# measurements behind the order are in profiles/ (kernel dashboards, rNN_experiments.txt); the conditions that are pure shape limits of a
+# kernel live in the library (`*_supported`).
+class _RouteCtx(object):
+    pass
+
+
+def _ws_generic(pass_):
+    return lambda c: int(c.lib.pcgan_conv2d_workspace_bytes(c.dref, pass_))
+
+
+def _fills_chip(c):
+    """one-tile-shape kernels without split-K (window / per-tap split kernels): only where whole tiles fill the chip"""
+    return c.split and c.pixels >= BSPLIT_MIN_PIXELS
+
+
+_FWD_ROUTES = (
+    # residual-block convolutions, fp32 tensors: window kernel, two fp16 pieces
+    ('hsplit', PASS_FWD_HSPLIT, lambda c: _fills_chip(c) and c.K % 128 == 0 and c.lib.pcgan_conv2d_bsplit_supported(c.dref) and c.f16
+     and c.lib.pcgan_conv2d_hsplit_supported(c.dref, _L.PASS_FWD), _ws_generic(_L.PASS_FWD)),
+    # every other fp32 convolution with a multiple of 16 gathered channels: packed implicit GEMM, two fp16 pieces (before the three-piece
+    # kernel below: the encoder's 128-channel 28x28 layers were on its six products per term, 0.062 ms against 0.047)
+    ('hgemm', PASS_FWD_HGEMM, lambda c: c.f16 and HGEMM and c.lib.pcgan_conv2d_hgemm_supported(c.dref, _L.PASS_FWD), _ws_generic(_L.PASS_FWD)),
+    # three-piece bf16 split (PCGAN_SPLIT=bf16) / bf16 tensors: window or per-tap kernel
+    ('bsplit', PASS_FWD_BSPLIT, lambda c: _fills_chip(c) and c.K % 128 == 0 and c.lib.pcgan_conv2d_bsplit_supported(c.dref), _ws_generic(_L.PASS_FWD)),
+    # <= 4 gathered channels (7x7 stems, first PatchGAN layer)
+    ('thin', PASS_FWD_THIN, lambda c: c.f16 and THIN and (THIN_MASK & (1 if c.stride == 1 else 2)) and c.lib.pcgan_conv2d_thin_supported(c.dref, _L.PASS_FWD),
+     _ws_generic(_L.PASS_FWD)),
+    ('packed', _L.PASS_FWD, lambda c: True, _ws_generic(_L.PASS_FWD)),       # fp32-MFMA implicit GEMM / small-M kernels
+)
+
+_DGRAD_ROUTES = (
+    ('hsplit', PASS_BWD_HSPLIT, lambda c: c.split and c.no_bias and c.C % 128 == 0 and c.N * c.H * c.W >= BSPLIT_MIN_PIXELS
+     and c.lib.pcgan_conv2d_bsplit_dgrad_supported(c.dref) and c.f16 and c.lib.pcgan_conv2d_hsplit_supported(c.dref, _L.PASS_BWD_DATA),
+     _ws_generic(_L.PASS_BWD_DATA)),
+    ('bsplit', PASS_BWD_BSPLIT, lambda c: c.split and c.no_bias and c.C % 128 == 0 and c.N * c.H * c.W >= BSPLIT_MIN_PIXELS
+     and c.lib.pcgan_conv2d_bsplit_dgrad_supported(c.dref), _ws_generic(_L.PASS_BWD_DATA)),
+    ('hgemm', PASS_BWD_HGEMM, lambda c: c.f16 and HGEMM and c.lib.pcgan_conv2d_hgemm_supported(c.dref, _L.PASS_BWD_DATA), _ws_generic(_L.PASS_BWD_DATA)),
+    # the data gradient of the 64 -> 3 head as a forward-form convolution (no pack cache: the generic call; needs the padded-grid workspace)
+    ('thin', PASS_BWD_THIN, lambda c: c.f16 and THIN and (THIN_MASK & 4) and c.no_bias and c.lib.pcgan_conv2d_thin_supported(c.dref, _L.PASS_BWD_DATA),
+     lambda c: max(int(c.lib.pcgan_conv2d_workspace_bytes(c.dref, _L.PASS_BWD_DATA)), int(c.lib.pcgan_conv2d_thin_workspace_bytes(c.dref, _L.PASS_BWD_DATA)))),
+    ('packed', _L.PASS_BWD_DATA, lambda c: True, _ws_generic(_L.PASS_BWD_DATA)),
+)
+
+
+def _wgrad_on_matrix_pipe(c):
+    """fp16 / bf16 matrix-pipe weight gradient (hsplit_wgrad_kernel): the residual convolutions from the host's routing threshold on,
+    every other eligible layer (stride 1 / 2, output width handled by the kernel) from 4096 output pixels on"""
+    res_like = c.K == 256 and c.R == 3 and c.S == 3 and c.stride == 1 and c.pad_mode == 1
+    # 3- / 4-channel inputs: only the generator's 7x7 stride-1 stem gains (0.266 -> 0.215 ms); the PatchGAN's first layer and the encoder's
+    # strided stem are faster on the fp32-MFMA kernels (scripts/time_thin.py)
+    thin_stem = c.C <= 4 and THIN_WGRAD and c.R == 7 and c.S == 7 and c.stride == 1
+    # zero padding <= 1 is applied inside the gather (no padded copy): those layers go there whatever their size; a layer that needs the
+    # padded copy only while it costs less than the matrix pipe saves (80 MB; PCGAN_WGRAD_INLINE_BIG=0 applies the limit to all, for A/B)
+    no_copy = WGRAD_INLINE_BIG and bool(c.lib.pcgan_conv2d_hsplit_wgrad_inline(c.dref))
+    cheap_pad = (c.C % 16 == 0 or thin_stem) and (no_copy or c.N * c.C * c.H * c.W * 4 <= 80 * 1000 * 1000)
+    return bool(HSPLIT and BF16X6 and c.lib.pcgan_conv2d_hsplit_wgrad_supported(c.dref)
+                and (c.pixels >= BSPLIT_MIN_PIXELS if (res_like or not HGEMM) else c.pixels >= min(BSPLIT_MIN_PIXELS, 4096))
+                and (res_like or (HGEMM and cheap_pad))
+                # (a ragged output width under a half-empty 128-row tile loses to the fp32 kernel: ResNet-18 layer1, 64 -> 64 at 56 x 56,
+                # 0.092 vs 0.076 ms)
+                and (c.K >= 128 or c.Q % 16 == 0))
+
+
+_WGRAD_ROUTES = (
+    ('hsplit', None, _wgrad_on_matrix_pipe, lambda c: int(c.lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(c.dref))),
+    ('bsplit', None, lambda c: c.split and c.K in (128, 256) and c.N * c.H * c.W >= BSPLIT_MIN_PIXELS and c.lib.pcgan_conv2d_bsplit_wgrad_supported(c.dref),
+     lambda c: int(c.lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(c.dref))),
+    ('generic', None, lambda c: True, _ws_generic(_L.PASS_BWD_WEIGHT)),      # fp32-MFMA / small-M weight-gradient kernels
+)
+ROUTE_TABLE = {_L.PASS_FWD: _FWD_ROUTES, _L.PASS_BWD_DATA: _DGRAD_ROUTES, _L.PASS_BWD_WEIGHT: _WGRAD_ROUTES}
+
+
 def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
     key = (pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias, BF16X6, HSPLIT, HGEMM, THIN, THIN_WGRAD, BSPLIT_MIN_PIXELS)
     p = _PLANS.get(key)
@@ -555,64 +631,16 @@ def _plan(pass_, N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias=True):
     p.d = make_desc(N, C, H, W, K, R, S, stride, pad, pad_mode, dt)
     p.dref = ctypes.byref(p.d)
     p.P, p.Q = p.d.P, p.d.Q
-    split = BF16X6 or dt == BF16
-    f16 = HSPLIT and dt == F32
-    if pass_ == _L.PASS_FWD:
-        p.ws_bytes = int(lib.pcgan_conv2d_workspace_bytes(p.dref, _L.PASS_FWD))
-        # (one tile shape, no split-K: only where whole tiles fill the chip, i.e. the residual-block convolutions)
-        bsplit = split and K % 128 == 0 and N * p.P * p.Q >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_supported(p.dref)
-        if bsplit and f16 and lib.pcgan_conv2d_hsplit_supported(p.dref, _L.PASS_FWD):
-            p.route, p.pack_pass = 'hsplit', PASS_FWD_HSPLIT
-        elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_FWD):
-            # (before the three-piece kernel below: fp32 tensors whose shape the window kernel does not take -- the encoder's 128-channel
-            # 28x28 layers -- were still on its six products per term, 0.062 ms against 0.047 for the same layer's data gradient)
-            p.route, p.pack_pass = 'hgemm', PASS_FWD_HGEMM
-        elif bsplit:
-            p.route, p.pack_pass = 'bsplit', PASS_FWD_BSPLIT
-        elif f16 and THIN and (THIN_MASK & (1 if stride == 1 else 2)) and lib.pcgan_conv2d_thin_supported(p.dref, _L.PASS_FWD):
-            p.route, p.pack_pass = 'thin', PASS_FWD_THIN
-        else:
-            p.route, p.pack_pass = 'packed', _L.PASS_FWD
-    elif pass_ == _L.PASS_BWD_DATA:
-        p.ws_bytes = int(lib.pcgan_conv2d_workspace_bytes(p.dref, _L.PASS_BWD_DATA))
-        bsplit = split and no_bias and C % 128 == 0 and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_dgrad_supported(p.dref)
-        if bsplit and f16 and lib.pcgan_conv2d_hsplit_supported(p.dref, _L.PASS_BWD_DATA):
-            p.route, p.pack_pass = 'hsplit', PASS_BWD_HSPLIT
-        elif bsplit:
-            p.route, p.pack_pass = 'bsplit', PASS_BWD_BSPLIT
-        elif f16 and HGEMM and lib.pcgan_conv2d_hgemm_supported(p.dref, _L.PASS_BWD_DATA):
-            p.route, p.pack_pass = 'hgemm', PASS_BWD_HGEMM
-        elif f16 and THIN and (THIN_MASK & 4) and no_bias and lib.pcgan_conv2d_thin_supported(p.dref, _L.PASS_BWD_DATA):
-            p.route, p.pack_pass = 'thin', PASS_BWD_THIN
-            p.ws_bytes = max(p.ws_bytes, int(lib.pcgan_conv2d_thin_workspace_bytes(p.dref, _L.PASS_BWD_DATA)))    # (no pack cache: the generic call)
-        else:
-            p.route, p.pack_pass = 'packed', _L.PASS_BWD_DATA
-    else:
-        p.pack_pass = None
-        # fp16 / bf16 matrix-pipe weight gradient: the residual convolutions from the host's routing threshold on, every other
-        # eligible layer (stride 1 / 2, <= 256 output channels, output width a multiple of 16) from 4096 output pixels on
-        px = N * p.P * p.Q
-        res_like = K == 256 and R == 3 and S == 3 and stride == 1 and pad_mode == 1
-        # (not where the padded copy of x costs more than the matrix pipe saves: measured slower for the 134 MB inputs of the
-        # generator's outermost 64-channel layers, 0.235 vs 0.17 ms, and for 3- / 4-channel images)
-        # (3- / 4-channel inputs: only the generator's 7x7 stride-1 stem gains, 0.266 -> 0.215 ms; the PatchGAN's first layer and the
-        # encoder's strided stem are faster on the fp32-MFMA kernels, scripts/time_thin.py)
-        thin_stem = C <= 4 and THIN_WGRAD and R == 7 and S == 7 and stride == 1
-        # (fp32 tensors with zero padding <= 1 need no padded copy at all -- the padding is applied inside the gather: those go there
-        # whatever their size, PCGAN_WGRAD_INLINE_BIG=0 keeps the 80 MB limit for an A/B measurement)
-        no_copy = WGRAD_INLINE_BIG and bool(lib.pcgan_conv2d_hsplit_wgrad_inline(p.dref))
-        cheap_pad = (C % 16 == 0 or thin_stem) and (no_copy or N * C * H * W * 4 <= 80 * 1000 * 1000)
-        if (HSPLIT and BF16X6 and lib.pcgan_conv2d_hsplit_wgrad_supported(p.dref)
-                and (px >= BSPLIT_MIN_PIXELS if (res_like or not HGEMM) else px >= min(BSPLIT_MIN_PIXELS, 4096))
-                and (res_like or (HGEMM and cheap_pad))
-                # (a ragged output width under a half-empty 128-row tile loses to the fp32 kernel: ResNet-18 layer1, 64 -> 64 at
-                # 56 x 56, 0.092 vs 0.076 ms)
-                and (K >= 128 or p.Q % 16 == 0)):
-            p.route, p.ws_bytes = 'hsplit', int(lib.pcgan_conv2d_hsplit_wgrad_workspace_bytes(p.dref))
-        elif split and K in (128, 256) and N * H * W >= BSPLIT_MIN_PIXELS and lib.pcgan_conv2d_bsplit_wgrad_supported(p.dref):
-            p.route, p.ws_bytes = 'bsplit', int(lib.pcgan_conv2d_bsplit_wgrad_workspace_bytes(p.dref))
-        else:
-            p.route, p.ws_bytes = 'generic', int(lib.pcgan_conv2d_workspace_bytes(p.dref, _L.PASS_BWD_WEIGHT))
+    c = _RouteCtx()
+    c.N, c.C, c.H, c.W, c.K, c.R, c.S, c.stride, c.pad, c.pad_mode, c.dt, c.no_bias = N, C, H, W, K, R, S, stride, pad, pad_mode, dt, no_bias
+    c.P, c.Q, c.pixels = p.P, p.Q, N * p.P * p.Q
+    c.lib, c.dref = lib, p.dref
+    c.split = BF16X6 or dt == BF16          # the matrix-pipe split kernels may take the call (always for bf16 tensors)
+    c.f16 = HSPLIT and dt == F32            # fp32 tensors on the fp16 two-piece route
+    for route, pack_pass, cond, ws in ROUTE_TABLE[pass_]:
+        if cond(c):
+            p.route, p.pack_pass, p.ws_bytes = route, pack_pass, ws(c)
+            break
     _PLANS[key] = p
     return p
 

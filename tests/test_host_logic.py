@@ -190,3 +190,37 @@ def test_synthetic_dataset_dict_layout(tmp_path):
     assert batch['A'].shape == (4, 3, 16, 16) and batch['label'].dtype == torch.int64
     assert float(batch['A'].min()) >= -1 and float(batch['A'].max()) <= 1
     assert set(batch['label'].tolist()) <= {0, 2}
+
+
+def test_declared_route_table_for_the_benchmark_layers():
+    """hip/ops.py: ROUTE_TABLE (round 4: the nested conditions of _plan became an ordered table per pass).  The routes of config 2's
+    layers at batch 32 are pinned here -- forward / data gradient / weight gradient -- so that a re-ordering of the table or a changed
+    `*_supported` predicate in the library shows up on the CPU (the predicates are host code: no GPU needed)."""
+    from pcgan_amd.hip import ops, lib as L
+    ops._sentinel = lambda: None          # (no device word on the CPU)
+    expect = {
+        # name: (N, C, H, W, K, R, S, stride, pad, pad_mode) -> (fwd, dgrad, wgrad)
+        'G.res': ((32, 256, 32, 32, 256, 3, 3, 1, 1, 1), ('hsplit', 'hsplit', 'hsplit')),
+        'G.stem': ((32, 4, 128, 128, 64, 7, 7, 1, 3, 1), ('thin', 'packed', 'hsplit')),
+        'G.down1': ((32, 64, 128, 128, 128, 3, 3, 2, 1, 0), ('hgemm', 'hgemm', 'hsplit')),
+        'G.down2': ((32, 128, 64, 64, 256, 3, 3, 2, 1, 0), ('hgemm', 'hgemm', 'hsplit')),
+        'G.head': ((32, 64, 128, 128, 3, 7, 7, 1, 3, 1), ('packed', 'thin', 'generic')),
+        'D.c0': ((32, 4, 128, 128, 64, 4, 4, 2, 1, 0), ('thin', 'packed', 'generic')),
+        'D.c3': ((32, 256, 16, 16, 512, 4, 4, 1, 1, 0), ('hgemm', 'hgemm', 'hsplit')),
+        'D.c4': ((32, 512, 15, 15, 1, 4, 4, 1, 1, 0), ('packed', 'packed', 'generic')),
+        'E.conv1': ((32, 3, 224, 224, 64, 7, 7, 2, 3, 0), ('thin', 'packed', 'generic')),
+        'E.l1': ((32, 64, 56, 56, 64, 3, 3, 1, 1, 0), ('hgemm', 'hgemm', 'generic')),
+        'E.l4': ((32, 512, 7, 7, 512, 3, 3, 1, 1, 0), ('hgemm', 'hgemm', 'generic')),
+        'IP.c1': ((32, 3, 224, 224, 64, 11, 11, 4, 2, 0), ('packed', 'packed', 'generic')),
+    }
+    assert [r[0] for r in ops.ROUTE_TABLE[L.PASS_FWD]] == ['hsplit', 'hgemm', 'bsplit', 'thin', 'packed']
+    assert [r[0] for r in ops.ROUTE_TABLE[L.PASS_BWD_DATA]] == ['hsplit', 'bsplit', 'hgemm', 'thin', 'packed']
+    assert [r[0] for r in ops.ROUTE_TABLE[L.PASS_BWD_WEIGHT]] == ['hsplit', 'bsplit', 'generic']
+    got = {}
+    for name, (shape, want) in expect.items():
+        got[name] = tuple(ops._plan(ps, *shape, L.F32).route for ps in (L.PASS_FWD, L.PASS_BWD_DATA, L.PASS_BWD_WEIGHT))
+    wrong = {k: (got[k], expect[k][1]) for k in expect if got[k] != expect[k][1]}
+    assert not wrong, wrong
+    # bf16 tensors: the one-product forms
+    assert tuple(ops._plan(ps, 32, 256, 32, 32, 256, 3, 3, 1, 1, 1, L.BF16).route for ps in (L.PASS_FWD, L.PASS_BWD_DATA, L.PASS_BWD_WEIGHT)) == \
+        ('bsplit', 'bsplit', 'hsplit')
