@@ -227,3 +227,38 @@ def test_fullsize_step_bf16_vs_fp32_oracle(tmp_path, dev, monkeypatch):
                 continue
             assert errs[k] <= 2 * errs_s[k] + 5e-2, 'bf16 full-size grad%s %s: relative L2 %.3e (autocast %.3e)' % (tag, k, errs[k], errs_s[k])
     print('bf16 full-size step (HIP bf16 / CPU bf16 autocast of the oracle, relative L2 vs the fp32 oracle): ' + '; '.join(report))
+
+
+def test_partial_last_batch_between_full_batches(tmp_path, dev):
+    """ADVICE r3 (high), at the level of the model: an epoch ends with a partial batch (the loader has no drop_last, as in the reference),
+    so BatchNorm layers see N = 8, 5, 8 through ONE set of arrival tickets (the frozen encoder's 112^2 / 56^2 maps run the one-launch
+    statistics kernels at these sizes).  Round 3's never-cleared tickets picked a wrong last arriver from the second call on -- silently
+    wrong batch statistics for the rest of the run.  Three optimize_parameters() with the full networks against the oracle's CPU steps:
+    the encoder's ratings (frozen weights, train-mode BatchNorm: a function of the batch alone) and the image losses at every step."""
+    import bench
+    from oracle import networks_ref as N
+    from oracle import step_ref as S
+    torch.manual_seed(0)
+    model, opt = bench.build_model(0, 8, 128, str(tmp_path), seed=3)
+    G = N.ResnetGeneratorRef(3, 3, 1, 64, 'instance', 9)
+    D = N.NLayerDiscriminatorRef(3, 1, 64, 3, 'batch', True)
+    E = N.SiameseFeatureRef(N.ResNetFeatureRef('resnet18'), 'avg', (32, 1), 1, 0.7, False)
+    IP = N.AlexNetFeatureRef(3, 'None')
+    for ref, net in ((G, model.netG), (D, model.netD), (E, model.netE), (IP, model.netIP)):
+        ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    oracle = S.WSGANEmbStepRef(G, D, E, IP)
+    for it, n in enumerate((8, 5, 8)):
+        b = bench.synthetic_batch(n, 128, 7, it)
+        oracle.set_input(b['A'], b['B'], [int(v) for v in b['label']])
+        oracle.optimize_parameters()
+        model.set_input(b)
+        model.optimize_parameters()
+        torch.cuda.synchronize()
+        for k in ('y_A', 'y_B'):
+            assert_close(getattr(model, k), getattr(oracle, k).detach(), 2e-4, 'step %d (batch %d) %s' % (it, n, k), atol=1e-5)
+        got, want = model.get_current_losses(), oracle.losses()
+        for k in ('G_cycle', 'G_IP', 'D_real_right'):      # (unaligned steps: Adam's O(lr) drift of the two sides is inside this band)
+            assert abs(got[k] - want[k]) <= 1e-2 * max(1.0, abs(want[k])), 'step %d (batch %d) loss %s: hip %.6g oracle %.6g' % (it, n, k, got[k], want[k])
+    # (the encoder's running statistics also take in fake_B, which drifts apart by O(lr) per unaligned step: not compared; its batch
+    # counter is -- three passes per step, each counted once by the last arriver of channel 0)
+    assert int(model.netE.state_dict()['base.model.bn1.num_batches_tracked']) == int(E.state_dict()['base.model.bn1.num_batches_tracked']) == 9
