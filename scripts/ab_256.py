@@ -36,7 +36,9 @@ common = ['--dataroot', 'synthetic', '--checkpoints_dir', tmp, '--gpu_ids', '0',
 
 def ab(name, m, batch, nimg):
     dev = torch.device('cuda:0')
-    batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    # pinned host batch, uploaded by set_input every step (BaseModel.to_act: the upload carries the readiness event the ahead-of-step encoder
+    # passes wait for; a resident tensor nobody declared ready -- ops.mark_ready -- is taken in plain stream order and does not run ahead)
+    batch = {k: (v.pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
     routes = [('fp16x3 (default)', True, True), ('bf16x6', True, False), ('fp32 MFMA', False, False)]
     res = {r[0]: [] for r in routes}
     host = {r[0]: [] for r in routes}

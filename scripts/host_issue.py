@@ -9,7 +9,7 @@ from pcgan_amd.hip import ops
 tmp = tempfile.mkdtemp()
 model, opt = bench.build_model(0, 32, 128, tmp)
 bs = [bench.synthetic_batch(32, 128, 0, i) for i in range(2)]
-bs = [{k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()} for b in bs]
+bs = [{k: (v.pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in b.items()} for b in bs]      # uploaded by set_input, as in bench.py
 def step(i):
     model.set_input(bs[i % 2]); model.optimize_parameters()
 for comp, trunk in ((True, True), (True, False), (False, False), (True, True), (True, False)):

@@ -6,7 +6,7 @@ import torch, bench
 tmp = tempfile.mkdtemp()
 model, opt = bench.build_model(0, 32, 128, tmp)
 b = bench.synthetic_batch(32, 128, 0)
-b = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}     # inputs resident in HBM, as in bench.py
+b = {k: (v.pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}     # pinned host batch uploaded by set_input, as in bench.py
 def step():
     model.set_input(b); model.optimize_parameters()
 for _ in range(3):
