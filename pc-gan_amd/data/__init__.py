@@ -100,6 +100,10 @@ class CustomDatasetDataLoader(object):
             self.gpu_transform = GpuTransform(opt, 'cuda:%d' % opt.gpu_ids[0] if opt.gpu_ids else 'cpu')
         collate = _collate_keep_raw if self.gpu_transform else None
         self.sampler = None
+        # pinned batches: set_input's upload (BaseModel.to_act) is then an asynchronous copy on the upload stream whose event the
+        # ahead-of-step encoder passes wait for -- the form bench.py measures; from pageable memory the copy blocks the host.
+        # (The reference's loader, data/__init__.py:58-62, does not pin.)
+        pin = bool(torch.cuda.is_available() and getattr(opt, 'gpu_ids', None))
         if world > 1:
             seed = self.seed = shared_seed(opt)
             # the data set reshuffles its pair list whenever its length is taken (reference quirk); here every rank must hold the
@@ -117,10 +121,10 @@ class CustomDatasetDataLoader(object):
             np.random.seed(seed % (1 << 32))
             self.sampler = RankShardedBatchSampler(n_samples, opt.batchSize, world, rank, not opt.serial_batches, seed)
             self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_sampler=self.sampler, num_workers=int(opt.nThreads),
-                                                          collate_fn=collate)
+                                                          collate_fn=collate, pin_memory=pin)
         else:
             self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=opt.batchSize, num_workers=int(opt.nThreads),
-                                                          shuffle=not opt.serial_batches, collate_fn=collate)
+                                                          shuffle=not opt.serial_batches, collate_fn=collate, pin_memory=pin)
         self._epochs = 0
         return self
 
