@@ -219,6 +219,13 @@ def main():
                     help='skip the extra (not headline) run with the residual convolutions routed back to the fp32 MFMA kernels')
     args = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: native libraries write to file descriptor 1 behind Python's back (RCCL prints
+    # a five-line version banner on rank 0's stdout when its communicator comes up -- seen on the first RCCL run, round 4), so the
+    # descriptor itself points at stderr until the line is printed
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from pcgan_amd.hip import parallel
     world, rank, local = parallel.init_process_group()
     assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
@@ -250,25 +257,26 @@ def main():
     _progress('model built, warm-up')
     for i in range(args.warmup):
         step(i)
+    dist_on = parallel.is_distributed()     # more than one rank, or the one-rank RCCL rehearsal (PCGAN_FORCE_COLLECTIVES=1)
     _progress('timed region')
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     # HIP events on the launch stream around every launch of the three residual-convolution kernels inside the timed region
     # (recorded inside the library, pcgan_timer_*: whichever host path -- per-op call or composite -- issues the launch)
     ops.timer_enable(36 * args.steps + 8)
-    if world > 1:
+    if dist_on:
         parallel.COMM_TIMER = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     t_issued = time.perf_counter() - t0     # host side done issuing (the GPU may still be running): launch-bound if ~ dt
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     dt = dt_rank = time.perf_counter() - t0
     per_rank = None
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -279,6 +287,11 @@ def main():
         mine = {'rank': rank, 'ms_per_step': round(dt_rank / args.steps * 1e3, 3), 'allreduce_ms_per_step': round(comm_ms, 3),
                 'allreduces_per_step': round(len(comm) / args.steps, 2), 'host_issue_ms_per_step': round(t_issued / args.steps * 1e3, 3)}
         mine.update(parallel.rank_identity(device))       # device uuid / PCI bus / RCCL version: the record proves N distinct GPUs
+        # replicas must be bit-identical after the timed steps (same start, same averaged gradients, same Adam arithmetic): compared
+        # once, outside the timed region; a divergence ends the job with exit code 3 and every rank's hash on stderr
+        model.sync_parameter_updates()
+        mine['replicas_bit_equal'] = bool(parallel.ddp_check(model.optimizer_G, 'bench_G', every=1)
+                                          and parallel.ddp_check(model.optimizer_D, 'bench_D', every=1))
         per_rank = [None] * world
         torch.distributed.all_gather_object(per_rank, mine)
         uuids = {(r['host'], r.get('device_uuid'), r.get('pci_bus_id')) for r in per_rank}
@@ -463,8 +476,14 @@ def main():
         _progress('cpu baseline')
         out['cpu_baseline'] = cpu_baseline()
     _progress('done')
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + '\n').encode())
+    os.close(json_fd)
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    finally:
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()

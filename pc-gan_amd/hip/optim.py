@@ -80,8 +80,9 @@ class FusedAdam(torch.optim.Optimizer):
                     p.data = view
                 o += (n + _ALIGN - 1) // _ALIGN * _ALIGN
 
-    def step_on_grad_stream(self):
-        """The same update, queued on the parameter-gradient stream: behind the weight- / bias-gradient kernels that stream still holds
+    def step_on_grad_stream(self, before=None):
+        """The same update, queued on the parameter-gradient stream (`before`: a callable run on that stream first -- data parallel: the
+        all-reduce of the flat gradient buffer, which then also runs off the main stream): behind the weight- / bias-gradient kernels that stream still holds
         and behind everything the current stream has queued so far (gradients autograd accumulated there: BatchNorm's affine
         parameters).  The current stream does NOT wait: it goes on with work that needs neither these gradients nor the new weights
         (wsgan_emb: backward_D after the generator's update, the next step's forward after the discriminator's).  `self.updated` is the
@@ -90,6 +91,8 @@ class FusedAdam(torch.optim.Optimizer):
         side = ops.side_stream_for(cur)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            if before is not None:
+                before()
             self.step(_joined=True)
             ev = torch.cuda.Event()
             ev.record(side)

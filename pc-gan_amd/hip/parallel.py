@@ -18,6 +18,12 @@ import torch
 import torch.distributed as dist
 
 
+# PCGAN_FORCE_COLLECTIVES=1: a world of ONE rank still builds the process group and runs every collective of the step (RCCL on a
+# GPU box: communicator set-up, ReduceOp.AVG, the launched-now / waited-later all-reduce next to the side streams, broadcast) -- the
+# rehearsal a one-GPU box allows (RCCL refuses two ranks on one device); tests/test_gpu_ddp.py::test_one_rank_over_rccl
+FORCE_COLLECTIVES = os.environ.get('PCGAN_FORCE_COLLECTIVES', '0') == '1'
+
+
 def env_world():
     return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), \
         int(os.environ.get('LOCAL_RANK', '0'))
@@ -26,9 +32,12 @@ def env_world():
 def init_process_group(backend=None):
     """Initialise torch.distributed from the torchrun environment; no-op for a single process."""
     world, rank, local = env_world()
-    if world <= 1:
+    if world <= 1 and not FORCE_COLLECTIVES:
         return world, rank, local
     if not dist.is_initialized():
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
+        os.environ.setdefault('MASTER_PORT', '29533')
         if backend is None:
             backend = os.environ.get('PCGAN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -141,7 +150,7 @@ def ddp_check(optimizer, name='', every=None, exit_on_divergence=True):
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def shard_batch(t, rank=None, world=None):

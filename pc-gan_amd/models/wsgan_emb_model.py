@@ -45,6 +45,14 @@ _IP_BRANCH = os.environ.get('PCGAN_IP_BRANCH', '0') == '1'
 # (profiles/r04_experiments.txt) -- the step is bound by the total time of its matrix-pipe kernels, not by the join.  Single process
 # only (under torch.distributed the all-reduce sits between backward and update).
 _ADAM_ON_GRAD_STREAM = os.environ.get('PCGAN_ADAM_ON_GRAD_STREAM', '0') == '1'
+# Data parallel, the default (PCGAN_DDP_GRAD_STREAM=0 restores the blocking all-reduce on the main stream): the same form with the all-reduce of the flat gradient buffer queued on the gradient
+# stream in front of the update -- RCCL orders the collective behind that stream only, so the generator's 45.5 MB all-reduce and its
+# Adam pass run under backward_D on the main stream, the discriminator's under the next step's forward passes (the main stream waits
+# for `optimizer.updated` where it reads the new weights).  Unlike PCGAN_DDP_OVERLAP=1 the order of the step is untouched.  One rank
+# over RCCL and two ranks over gloo give bit-equal results (tests/test_gpu_ddp.py) and on one rank the step time is unchanged
+# (profiles/r04_experiments.txt section 10); the gain needs a fabric to be measured on.  bench.py --gpus N compares the replicas'
+# parameter hashes after its timed steps.
+_DDP_GRAD_STREAM = os.environ.get('PCGAN_DDP_GRAD_STREAM', '1') == '1'
 
 MAGIC_EPS = 1e-20
 
@@ -439,12 +447,15 @@ class WSGANEmbModel(BaseModel):
     def _on_grad_stream(self, optimizer):
         """may this optimizer's update run on the parameter-gradient stream?  (the stock FusedAdam.step on a GPU, one process; an
         instance-level `step` -- the tests' gradient grabbers -- takes the joined path and reads finished gradients)"""
-        return (_ADAM_ON_GRAD_STREAM and hip_ops.SIDE_STREAM and isinstance(optimizer, FusedAdam) and 'step' not in optimizer.__dict__
-                and optimizer.flat.is_cuda and not parallel.is_distributed())
+        on = _DDP_GRAD_STREAM if parallel.is_distributed() else _ADAM_ON_GRAD_STREAM
+        return on and hip_ops.SIDE_STREAM and isinstance(optimizer, FusedAdam) and 'step' not in optimizer.__dict__ and optimizer.flat.is_cuda
 
     def _step(self, optimizer, name):
         if self._on_grad_stream(optimizer):
-            optimizer.step_on_grad_stream()
+            dist = parallel.is_distributed()
+            optimizer.step_on_grad_stream(before=(lambda: parallel.allreduce_mean_(optimizer.gflat)) if dist else None)
+            if dist and parallel.DDP_CHECK_EVERY:
+                self._wait_updated(optimizer)      # the replica hash reads the new parameters on this stream
         else:
             hip_ops.join_side_stream(force=True)
             parallel.sync_gradients(optimizer)

@@ -27,22 +27,27 @@ def main():
     # every rank builds from its own seed: broadcast_parameters must then install rank 0's weights everywhere
     model, opt = bench.build_model(0, hi - lo, 32, tmp, seed=7 + (rank if world > 1 else 0), ngf=8, ndf=8, fine_e=64, n_blocks=2, dtype=dtype)
     grabbed = {}
-    for tag, optim in (('G', model.optimizer_G), ('D', model.optimizer_D)):
-        orig = optim.step
+    # the flat gradient buffers as the update kernel reads them (after the all-reduce), grabbed on whichever stream the update is queued
+    # on (the main stream, or the parameter-gradient stream under PCGAN_DDP_GRAD_STREAM=1)
+    from pcgan_amd.hip import ops
+    tags = {model.optimizer_G.flat.data_ptr(): 'gG', model.optimizer_D.flat.data_ptr(): 'gD'}
+    real_adam = ops.adam_step_dev
 
-        def stepper(orig=orig, tag=tag, optim=optim):
-            grabbed['g' + tag] = optim.gflat.detach().clone().cpu()
-            return orig()
-        optim.step = stepper
+    def adam(flat, gflat, *a, **k):
+        grabbed[tags[flat.data_ptr()]] = gflat.detach().clone()
+        return real_adam(flat, gflat, *a, **k)
+    ops.adam_step_dev = adam
     b = bench.synthetic_batch(4, 32, 0)
     batch = {k: v[lo:hi] for k, v in b.items()}
     model.set_input(batch)
     model.optimize_parameters()
     torch.cuda.synchronize()
+    grabbed['gG'], grabbed['gD'] = grabbed['gG'].cpu(), grabbed['gD'].cpu()
     grabbed['pG'] = model.optimizer_G.flat.detach().clone().cpu()
     grabbed['pD'] = model.optimizer_D.flat.detach().clone().cpu()
     grabbed['losses'] = dict(model.get_current_losses())
     grabbed['distributed'] = parallel.is_distributed()
+    grabbed['identity'] = parallel.rank_identity()
     torch.save(grabbed, out)
     if parallel.is_distributed():
         torch.distributed.barrier()

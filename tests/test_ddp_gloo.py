@@ -193,3 +193,33 @@ def test_replica_divergence_ends_the_job_with_exit_code_3():
     with pytest.raises(mp.ProcessExitedException) as e:
         mp.spawn(_diag_worker, args=(2, _free_port(), 'exit'), nprocs=2, join=True)
     assert e.value.exit_code == 3
+
+
+def _one_rank_worker(rank, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PCGAN_FORCE_COLLECTIVES='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        os.environ.pop(k, None)
+    torch.set_num_threads(1)
+    from pcgan_amd.hip import parallel
+    from pcgan_amd.hip.optim import FusedAdam
+    from pcgan_amd.models import networks
+    assert parallel.FORCE_COLLECTIVES
+    assert parallel.init_process_group('gloo')[:2] == (1, 0) and dist.is_initialized() and parallel.is_distributed()
+    D = networks.define_D(3, 1, 8, 'n_layers', 3, 'batch', True, 'normal')
+    parallel.broadcast_parameters(D)
+    opt = FusedAdam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    opt.gflat.copy_(torch.arange(opt.gflat.numel(), dtype=torch.float32))
+    want = opt.gflat.clone()
+    parallel.sync_gradients(opt)
+    parallel.sync_gradients(opt, async_op=True)()
+    assert torch.equal(opt.gflat, want)          # the average over one rank
+    assert parallel.ddp_check(opt, 'D', every=1) is True
+    assert parallel.shard_batch(torch.arange(4)).tolist() == [0, 1, 2, 3]
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_one_rank_rehearsal_runs_every_collective():
+    """PCGAN_FORCE_COLLECTIVES=1: the one-GPU box's way to run the RCCL branch (tests/test_gpu_ddp.py::test_one_rank_over_rccl);
+    here the same switch over gloo -- the group exists, the collectives run, and averaging over one rank changes nothing"""
+    mp.spawn(_one_rank_worker, args=(_free_port(),), nprocs=1, join=True)

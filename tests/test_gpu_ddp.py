@@ -35,7 +35,8 @@ def _env(rank, world, port, overlap='0'):
     env = dict(os.environ)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    env['PCGAN_DDP_OVERLAP'] = overlap
+    env['PCGAN_DDP_OVERLAP'] = '1' if overlap == '1' else '0'
+    env['PCGAN_DDP_GRAD_STREAM'] = '1' if overlap == 'grad-stream' else '0'
     if world > 1:
         env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    PCGAN_DIST_BACKEND='gloo')
@@ -44,8 +45,9 @@ def _env(rank, world, port, overlap='0'):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('dtype,overlap', [('fp32', '0'), ('fp32', '1'), ('bf16', '0')],
-                         ids=['fp32-sequential', 'fp32-overlapped-allreduce', 'bf16-sequential(config 3: bf16 x ranks)'])
+@pytest.mark.parametrize('dtype,overlap', [('fp32', '0'), ('fp32', '1'), ('fp32', 'grad-stream'), ('bf16', '0')],
+                         ids=['fp32-sequential', 'fp32-overlapped-allreduce', 'fp32-allreduce-on-gradient-stream',
+                              'bf16-sequential(config 3: bf16 x ranks)'])
 def test_two_ranks_product_step(dev, tmp_path, dtype, overlap):
     port = _free_port()
     outs = [str(tmp_path / ('rank%d.pt' % r)) for r in range(2)]
@@ -77,3 +79,28 @@ def test_two_ranks_product_step(dev, tmp_path, dtype, overlap):
     for h in range(2):
         for k, v in singles[h]['losses'].items():
             assert abs(ranks[h]['losses'][k] - v) <= 1e-5 * max(1.0, abs(v)), 'rank %d loss %s' % (h, k)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('overlap', ['0', '1', 'grad-stream'], ids=['sequential', 'overlapped-allreduce', 'allreduce-on-gradient-stream'])
+def test_one_rank_over_rccl(dev, tmp_path, overlap):
+    """The RCCL branch itself on the hardware there is: RCCL refuses two ranks on one device, so a world of ONE rank runs the whole
+    collective side of the step (PCGAN_FORCE_COLLECTIVES=1): communicator set-up, the start-up self-check, broadcast_parameters,
+    ReduceOp.AVG on the flat gradient buffers -- in the launched-now / waited-later form too, RCCL's stream beside the step's
+    side and branch streams -- and the work.wait() hand-back.  Averaging over one rank is the identity, so gradients at each
+    optimizer step, parameters after it and losses must be BIT-equal to the run without a process group."""
+    env = _env(0, 1, 0, overlap)
+    env.update(PCGAN_FORCE_COLLECTIVES='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               PCGAN_DIST_BACKEND='nccl', PCGAN_DDP_CHECK='1')
+    outs = {}
+    for tag, e in (('rccl', env), ('plain', _env(0, 1, 0, overlap))):
+        o = str(tmp_path / (tag + '.pt'))
+        p = subprocess.run([sys.executable, WORKER, o, '0', '4', 'fp32'], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, '%s run failed:\n%s' % (tag, (p.stdout + p.stderr)[-3000:])
+        outs[tag] = torch.load(o)
+    r, s = outs['rccl'], outs['plain']
+    assert r['distributed'] and not s['distributed']
+    assert r['identity']['backend'] == 'nccl' and r['identity']['rccl_version'][0].isdigit(), r['identity']
+    for tag in ('gG', 'gD', 'pG', 'pD'):
+        assert torch.equal(r[tag], s[tag]), '%s differs between the one-rank RCCL run and the plain run' % tag
+    assert r['losses'] == s['losses']
