@@ -548,6 +548,75 @@ def golden_fid(outdir):
     print('fid.npz', [float(out['fid_%d' % i]) for i in range(len(cases))], [float(out['fid_self_%d' % i]) for i in range(len(cases))])
 
 
+LR_E_ARGS = ['--lr_E', '0.0001']
+
+
+def golden_step_lr_E(rn, outdir):
+    """`--lr_E > 0`: the reference's OWN update_G_and_E / backward_GE / backward_G_alone (models/wsgan_emb_model.py:331-369,
+    439-449, 463-476), two iterations.  That branch steps G and E and then back-propagates through the retained graph, which
+    torch >= 1.5 refuses when a stock optimizer wrote the parameters; here `torch.optim.Adam` is replaced -- while the
+    reference builds its optimizers, and only there -- by oracle.step_ref.AdamThroughData (same update, written through p.data as
+    the optimizers of the reference's era did).  The optimizer's semantics are DEFINED by that class; everything else in the run
+    is the reference's code."""
+    from options.train_options import TrainOptions
+    from models import create_model
+    from oracle import step_ref as S
+    tmp = tempfile.mkdtemp(prefix='pcgan_golden_lrE_')
+    e = rn.SiameseFeature(rn.ResNetFeature(3, 'resnet18', dropout=0.0), pooling='avg', cnn_dim=[32, 1], cnn_pad=1,
+                          cnn_relu_slope=0.7, noisy=False, drop_layer=rn.get_dropout_layer(0.0))
+    e_path = os.path.join(tmp, 'E.pth')
+    torch.save(W.fill_state_dict(e.state_dict(), 30), e_path)
+    ip = rn.AlexNetFeature(input_nc=3, pooling='None')
+    ip_path = os.path.join(tmp, 'IP.pth')
+    torch.save(W.fill_state_dict(ip.state_dict(), 40), ip_path)
+    sys.argv = ['train.py', '--dataroot', tmp, '--model', 'wsgan_emb', '--name', 'g_lrE', '--checkpoints_dir', tmp, '--gpu_ids', '-1',
+                '--which_model_netG', 'resnet_9blocks', '--which_model_netD', 'n_layers', '--n_layers_D', '3', '--ngf', '8',
+                '--ndf', '8', '--fineSize', '32', '--loadSize', '32', '--fineSize_E', '64', '--fineSize_IP', '64', '--batchSize', '4',
+                '--pretrained_model_path_E', e_path, '--pretrained_model_path_IP', ip_path, '--display_id', '-1',
+                '--embedding_bins', '[-1.0, 0.0, 1.5]', '--embedding_mean', '0.1', '--embedding_std', '0.8'] + LR_E_ARGS
+    opt = TrainOptions().parse()
+    stock = torch.optim.Adam
+    torch.optim.Adam = S.AdamThroughData
+    try:
+        model = create_model(opt)
+        model.setup(opt)
+    finally:
+        torch.optim.Adam = stock
+    assert isinstance(model.optimizer_E, S.AdamThroughData) and isinstance(model.optimizer_G, S.AdamThroughData)
+    model.netG.load_state_dict(W.damp_generator_head(W.fill_state_dict(model.netG.state_dict(), 19)))
+    model.netD.load_state_dict(W.fill_state_dict(model.netD.state_dict(), 20))
+    out = {}
+    for it in range(2):
+        torch.manual_seed(1234 + it)
+        np.random.seed(NP_SEED + it)
+        grabbed, origs = [], {}
+        for tag, optim, net in (('G', model.optimizer_G, model.netG), ('E', model.optimizer_E, model.netE), ('D', model.optimizer_D, model.netD)):
+            orig = origs[tag] = optim.step
+
+            def stepper(orig=orig, tag=tag, net=net):
+                grabbed.append((tag, [(k, None if p.grad is None else p.grad.detach().clone()) for k, p in net.named_parameters()]))
+                return orig()
+            optim.step = stepper
+        model.set_input(step_batch('default', it))
+        model.optimize_parameters()
+        model.optimizer_G.step, model.optimizer_E.step, model.optimizer_D.step = origs['G'], origs['E'], origs['D']
+        assert [t for t, _ in grabbed] == ['G', 'E', 'G', 'D'], [t for t, _ in grabbed]
+        p = 'it%d' % it
+        losses = model.get_current_losses()
+        out[p + '/losses'] = np.array([losses[k] for k in model.loss_names], dtype=np.float64)
+        for k in ('fake_B', 'rec_A', 'embedding_A', 'embedding_B', 'y_A', 'y_B'):
+            out['%s/%s' % (p, k)] = t2n(getattr(model, k))
+        for (tag, grads), name in zip(grabbed, ('gradG', 'gradE', 'gradG_alone', 'gradD')):
+            grads_summary(grads, '%s/%s' % (p, name), out, full=(name == 'gradG_alone'))
+        for tag, net in (('G', model.netG), ('D', model.netD), ('E', model.netE)):
+            for k, v in net.state_dict().items():
+                a = t2n(v).astype(np.float64)
+                out['%s/after%s/%s' % (p, tag, k)] = np.array([a.sum(), np.abs(a).sum()])
+    out['loss_names'] = np.array(model.loss_names)
+    np.savez_compressed(os.path.join(outdir, 'step_lr_E.npz'), **out)
+    print('step_lr_E.npz: %d arrays, losses it0 %s it1 %s' % (len(out), out['it0/losses'], out['it1/losses']))
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
@@ -575,3 +644,5 @@ if __name__ == '__main__':
         golden_siamese_variants(rn, a.out)
     if a.only in ('', 'fid'):
         golden_fid(a.out)
+    if a.only in ('', 'lr_E'):
+        golden_step_lr_E(rn, a.out)

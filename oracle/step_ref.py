@@ -72,9 +72,47 @@ def gan_loss(pred, target, lsgan=False):
 DEFAULTS = dict(
     fineSize_E=224, fineSize_IP=224, embedding_mean=[0.0], embedding_std=[1.0],
     noisy=False, noisy_D=True, noisy_rec=True, noisy_var_type='', bayesian=False, bnn_T=10,
-    lambda_L1=0.0, lambda_IP=1.0, lambda_z=1.0, lambda_A=0.5, lambda_A_GAN=0.0, lr_E=0.0,
+    lambda_L1=0.0, lambda_IP=1.0, lambda_z=1.0, lambda_A=0.5, lambda_A_GAN=0.0, lr_E=0.0, update_logvar_E=False,
     use_real_A=False, relabel_D=[0, 1, 0], detach_fake_B=False, lr=2e-4, beta1=0.5,
     identity_preserving_criterion='mse')
+
+
+class AdamThroughData(torch.optim.Optimizer):
+    """torch.optim.Adam's update (betas, eps 1e-8, no weight decay / amsgrad) applied through `p.data`, i.e. without telling
+    autograd that the parameter changed -- how optimizers stepped in the PyTorch (<= 0.4) the reference was written for.  Only the
+    `--lr_E > 0` branch needs it: update_G_and_E steps G and E and then back-propagates through the graph it RETAINED
+    (models/wsgan_emb_model.py:463-476); torch >= 1.5 refuses that, the old one silently used the updated weights
+    where a backward formula reads a weight and the activations saved by the old forward pass elsewhere.  The optimizer's
+    SEMANTICS are defined here, not taken from a run of the reference's era; with it substituted for torch.optim.Adam the
+    reference's own update_G_and_E / backward_GE / backward_G_alone run on torch 2.10, and that run pins the restatement
+    below (oracle/make_golden.py golden_step_lr_E -> tests/golden/step_lr_E.npz)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g['params']:
+                p.grad = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for g in self.param_groups:
+            b1, b2 = g['betas']
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st['t'], st['m'], st['v'] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st['t'] += 1
+                m, v, t = st['m'], st['v'], st['t']
+                grad = p.grad
+                m.mul_(b1).add_(grad, alpha=1 - b1)
+                v.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+                bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+                denom = (v.sqrt() / (bc2 ** 0.5)).add_(g['eps'])
+                p.data.addcdiv_(m, denom, value=-g['lr'] / bc1)
 
 
 class WSGANEmbStepRef:
@@ -88,9 +126,15 @@ class WSGANEmbStepRef:
         # models/wsgan_emb_model.py:153-165
         self.optimizer_G = torch.optim.Adam(netG.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
         self.optimizer_D = torch.optim.Adam(netD.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
-        assert self.opt.lr_E <= 0.0, 'lr_E > 0 does not run on torch 2.x in the reference (SURVEY D13)'
-        for p in netE.parameters():
-            p.requires_grad = False
+        if self.opt.lr_E > 0.0:
+            # models/wsgan_emb_model.py:157-163 under the defined semantics of AdamThroughData (parity unpinned, see there)
+            betas = (self.opt.beta1, 0.999)
+            self.optimizer_G = AdamThroughData(netG.parameters(), self.opt.lr, betas)
+            e_params = netE.cnn_logvar.parameters() if self.opt.update_logvar_E else netE.parameters()
+            self.optimizer_E = AdamThroughData(e_params, self.opt.lr_E, betas)
+        else:
+            for p in netE.parameters():
+                p.requires_grad = False
         self.draws = []          # every random tensor drawn, in order
         self.inject = None       # optional iterator of tensors to use instead of drawing
         self.grads_G = self.grads_D = None
@@ -202,20 +246,38 @@ class WSGANEmbStepRef:
             if 'a' in o.noisy_var_type:
                 self.resample_A = self.embedding_normalize(self.resample(y_A, y_A_s2 + y_A_var))
                 self.resample_B = self.embedding_normalize(self.resample(y_B, y_B_s2 + y_B_var))
-        self.y_A, self.y_B = y_A.detach(), y_B.detach()
-        self.embedding_A = self.embedding_normalize(y_A).detach()
-        self.embedding_B = self.embedding_normalize(y_B).detach()
-        if o.noisy_var_type:
-            self.resample_A = self.resample_A.detach()
-            self.resample_B = self.resample_B.detach()
+        self.y_A, self.y_B = y_A, y_B
+        self.embedding_A = self.embedding_normalize(y_A)
+        self.embedding_B = self.embedding_normalize(y_B)
+        if o.lr_E <= 0.0:
+            self.y_A, self.y_B = self.y_A.detach(), self.y_B.detach()
+            self.embedding_A, self.embedding_B = self.embedding_A.detach(), self.embedding_B.detach()
+            if o.noisy_var_type:
+                self.resample_A = self.resample_A.detach()
+                self.resample_B = self.resample_B.detach()
         self.fake_B = self.netG(self.real_A, self.embedding_B)
         self.fake_B_IP = upsample2d(self.fake_B, o.fineSize_IP)
         self.fake_B_E = upsample2d(self.fake_B, o.fineSize_E)
         src = self.fake_B.detach() if o.detach_fake_B else self.fake_B
         self.rec_A = self.netG(src, self.embedding_A)
 
-    def backward_G(self):
-        """models/wsgan_emb_model.py:371-437"""
+    def backward_GE(self):
+        """models/wsgan_emb_model.py:331-369: the generator's losses without the rating reconstruction, graph retained"""
+        self._common_G_losses()
+        self.loss_G = self.loss_G_GAN + self.loss_G_IP + self.loss_G_L1 + self.loss_G_cycle + self.loss_G_GAN_cycle
+        self.loss_G.backward(retain_graph=True)
+
+    def backward_G_alone(self):
+        """models/wsgan_emb_model.py:439-449: the rating reconstruction through the RETAINED graph of fake_B"""
+        o = self.opt
+        self.loss_z_rec = 0.0
+        if o.lambda_z > 0.0:
+            pred = self.netE(self.fake_B_E)
+            pred = self.embedding_normalize(pred[0] if o.noisy else pred)
+            self.loss_z_rec = F.mse_loss(pred, self.embedding_B.detach()) * o.lambda_z
+            self.loss_z_rec.backward()
+
+    def _common_G_losses(self):
         o = self.opt
         zB = self.resample_B if (o.noisy_var_type and o.noisy_D) else self.embedding_B
         self.loss_G_GAN = gan_loss(self.netD(self.fake_B, zB), True)
@@ -229,6 +291,11 @@ class WSGANEmbStepRef:
             crit = F.mse_loss if o.identity_preserving_criterion.lower() == 'mse' else F.l1_loss
             self.loss_G_IP = crit(self.netIP(self.fake_B_IP), feature_A) * o.lambda_IP
         self.loss_G_cycle = F.l1_loss(self.rec_A, self.real_A) * o.lambda_A if o.lambda_A > 0.0 else 0.0
+
+    def backward_G(self):
+        """models/wsgan_emb_model.py:371-437"""
+        o = self.opt
+        self._common_G_losses()
         self.loss_z_rec = 0.0
         if o.lambda_z > 0.0:
             if not o.bayesian and not o.noisy:
@@ -277,11 +344,26 @@ class WSGANEmbStepRef:
         self.forward()
         for p in self.netD.parameters():
             p.requires_grad = False
-        self.optimizer_G.zero_grad()
-        self.backward_G()
-        self.grads_G = {k: (p.grad.detach().clone() if p.grad is not None else None)
-                        for k, p in self.netG.named_parameters()}
-        self.optimizer_G.step()
+        grab = lambda net: {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in net.named_parameters()}  # noqa: E731
+        if self.opt.lr_E > 0.0:
+            # update_G_and_E, models/wsgan_emb_model.py:463-476 (AdamThroughData: defined semantics, parity unpinned)
+            self.optimizer_G.zero_grad()
+            self.optimizer_E.zero_grad()
+            self.backward_GE()
+            self.grads_G, self.grads_E = grab(self.netG), grab(self.netE)
+            self.optimizer_G.step()
+            self.optimizer_E.step()
+            if self.opt.lambda_z > 0.0:
+                self.optimizer_G.zero_grad()
+                self.optimizer_E.zero_grad()
+                self.backward_G_alone()
+                self.grads_G_alone = grab(self.netG)
+                self.optimizer_G.step()
+        else:
+            self.optimizer_G.zero_grad()
+            self.backward_G()
+            self.grads_G = grab(self.netG)
+            self.optimizer_G.step()
         for p in self.netD.parameters():
             p.requires_grad = True
         self.optimizer_D.zero_grad()
@@ -294,7 +376,7 @@ class WSGANEmbStepRef:
 
     def losses(self):
         """models/base_model.py:87-93"""
-        return {n: float(getattr(self, 'loss_' + n)) for n in self.LOSS_NAMES}
+        return {n: float(v.detach() if isinstance(v, torch.Tensor) else v) for n, v in ((n, getattr(self, 'loss_' + n)) for n in self.LOSS_NAMES)}
 
 
 # ============================================================================= wsgan_cycle (SURVEY 8f rank 1)

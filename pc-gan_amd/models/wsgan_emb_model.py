@@ -9,8 +9,11 @@ pcgan_amd.hip.  What is different by design:
   * Adam is the fused flat-buffer kernel (pcgan_amd.hip.optim.FusedAdam);
   * per-sample GAN targets are gathered from a device-resident look-up table instead of being
     rebuilt from a Python list every step (keeps the step free of host syncs);
-  * `--lr_E > 0` (update_G_and_E) raises: the reference's own branch fails on torch >= 1.5 with
-    an in-place-modification error, so there is no behaviour to reproduce.
+  * `--lr_E > 0` (update_G_and_E): the reference's own branch fails on torch >= 1.5 with an in-place-modification error
+    (SURVEY.md D13); here it runs with the semantics of the PyTorch it was written for -- the optimizers step without telling
+    autograd, and the second backward pass through the RETAINED graph reads the updated weights where a backward formula reads
+    a weight and the old forward pass's saved activations elsewhere (oracle/step_ref.py: AdamThroughData; parity unpinned, the
+    semantics are DEFINED there).  FusedAdam updates the flat buffer through raw pointers, which is exactly that.
 """
 import os
 from collections import OrderedDict
@@ -176,11 +179,16 @@ class WSGANEmbModel(BaseModel):
             self.optimizer_G = self.make_optimizer(self.netG.parameters(), opt.lr, (opt.beta1, 0.999))
             self.optimizer_D = self.make_optimizer(self.netD.parameters(), opt.lr, (opt.beta1, 0.999))
             self.optimizers = [self.optimizer_G, self.optimizer_D]
-            if opt.lr_E > 0.0:
-                raise NotImplementedError(
-                    'pcgan_amd: --lr_E > 0 (update_G_and_E) is not supported: the reference branch itself fails on '
-                    'torch >= 1.5 (in-place parameter update under retain_graph), see SURVEY.md D13')
-            self.set_requires_grad(self.netE, False)
+            if opt.lr_E > 0.0:      # reference models/wsgan_emb_model.py:157-163
+                if opt.update_logvar_E:
+                    assert opt.noisy
+                    e_params = self.netE.cnn_logvar.parameters()
+                else:
+                    e_params = self.netE.parameters()
+                self.optimizer_E = self.make_optimizer(e_params, opt.lr_E, (opt.beta1, 0.999))
+                self.optimizers.append(self.optimizer_E)
+            else:
+                self.set_requires_grad(self.netE, False)
             self.set_requires_grad(self.netIP, False)   # frozen in the reference too: it has no optimizer
 
         mean, std = opt.embedding_mean[0], opt.embedding_std[0]
@@ -269,6 +277,8 @@ class WSGANEmbModel(BaseModel):
         o = self.opt
         if self.isTrain:
             self._wait_updated(self.optimizer_G)      # generator passes on this stream (and on branches forked from it): after its last update
+            if o.lr_E > 0.0:
+                self._wait_updated(self.optimizer_E)
         self.real_A_IP = upsample2d(self.real_A, o.fineSize_IP)
         frozen = o.lr_E <= 0.0
         # The frozen encoder's passes over the two real image sets depend on the batch and on the encoder's own state only (weights
@@ -412,6 +422,27 @@ class WSGANEmbModel(BaseModel):
         if isinstance(self.loss_G, torch.Tensor) and self.loss_G.requires_grad:
             self.loss_G.backward()
 
+    def backward_GE(self):
+        """reference models/wsgan_emb_model.py:331-369: the generator's losses without the rating reconstruction; the graph is kept
+        for backward_G_alone"""
+        b_ip = self._common_G_losses()
+        if b_ip is not None:
+            b_ip.join(self.loss_G_IP)
+        self.loss_G = self.loss_G_GAN + self.loss_G_IP + self.loss_G_L1 + self.loss_G_cycle + self.loss_G_GAN_cycle
+        self.loss_G.backward(retain_graph=True)
+
+    def backward_G_alone(self):
+        """reference models/wsgan_emb_model.py:439-449: the rating reconstruction, back-propagated through the encoder's NEW pass
+        over fake_B and then through the retained graph of fake_B (updated weights, old activations: see the module docstring)"""
+        o = self.opt
+        if o.lambda_z > 0.0:
+            pred = self.netE(self.transform_E(self.fake_B_E))
+            pred = self.embedding_normalize(pred[0] if o.noisy else pred)
+            self.loss_z_rec = self.criterionRec(pred, self.embedding_B.detach()) * o.lambda_z
+            self.loss_z_rec.backward()
+        else:
+            self.loss_z_rec = 0.0
+
     def _z_rec_loss(self):
         """loss_z_rec of backward_G (reference models/wsgan_emb_model.py:400-435), its four encoder variants."""
         o = self.opt
@@ -484,6 +515,25 @@ class WSGANEmbModel(BaseModel):
         self._step(self.optimizer_G, 'G')
         self._mark_g_updated()
 
+    def update_G_and_E(self):
+        """reference models/wsgan_emb_model.py:463-476"""
+        self.set_requires_grad(self.netD, False)
+        self.optimizer_G.zero_grad()
+        self.optimizer_E.zero_grad()
+        self._wait_updated(self.optimizer_D)
+        self.loss_z_rec = 0.0
+        self.backward_GE()
+        self._step(self.optimizer_G, 'G')
+        self._step(self.optimizer_E, 'E')
+        if self.opt.lambda_z > 0.0:      # update G only
+            self.optimizer_G.zero_grad()
+            self.optimizer_E.zero_grad()
+            self._wait_updated(self.optimizer_G)
+            self._wait_updated(self.optimizer_E)
+            self.backward_G_alone()
+            self._step(self.optimizer_G, 'G')
+        self._mark_g_updated()
+
     def _mark_g_updated(self):
         """the point in the current stream after which the generator's weights are those of this update (forward(): G1 branch)"""
         if self.real_A.is_cuda:
@@ -495,6 +545,10 @@ class WSGANEmbModel(BaseModel):
 
     def optimize_parameters(self):
         self.forward()
+        if self.opt.lr_E > 0.0:
+            self.update_G_and_E()
+            self.update_D()
+            return
         if not (parallel.is_distributed() and _DDP_OVERLAP):
             self.update_G()          # (under torch.distributed each ends in a blocking all-reduce of its flat gradient buffer)
             self.update_D()

@@ -324,3 +324,114 @@ def test_get_current_visuals_matches_reference(tmp_path, dev):
     model.get_current_visuals()
     model.optimize_parameters()
     assert all(v == v for v in model.get_current_losses().values())
+
+
+def test_update_G_and_E_step_vs_oracle(tmp_path, dev):
+    """`--lr_E > 0` (update_G_and_E, backward_GE, backward_G_alone): the encoder trains inside the step and the
+    rating reconstruction is back-propagated through the RETAINED graph after G and E have stepped.  Semantics: oracle/step_ref.py
+    AdamThroughData (defined there; the branch's algorithm is pinned by the reference's own code run with that optimizer,
+    tests/golden/step_lr_E.npz).  Checked against the oracle side by side: losses, images, the four gradient sets at the moment of their
+    optimizer steps (G, E, G after backward_G_alone, D) -- SHARP against the float64 twin on the HIP run's own decisions -- and the
+    running statistics.  Between the two phases the HIP model and the twin take the oracle's stepped G / E weights (Adam turns
+    noise-level gradients into +-lr moves: the second phase is compared on identical weights, like the iterations of the test above)."""
+    from oracle.make_golden import LR_E_ARGS
+    from pcgan_amd.hip import ops
+    model, opt = build_hip_model('default', tmp_path, LR_E_ARGS)
+    assert opt.lr_E > 0 and model.optimizer_E in model.optimizers
+    oracle = build_oracle_step('default', LR_E_ARGS)
+    twin = build_oracle_step('default', LR_E_ARGS)
+    for net in (twin.netG, twin.netD, twin.netE, twin.netIP):
+        net.double()
+    grabbed = []
+    for tag, optim, net in (('G', model.optimizer_G, model.netG), ('E', model.optimizer_E, model.netE), ('D', model.optimizer_D, model.netD)):
+        def stepper(orig=optim.step, tag=tag, net=net):
+            grabbed.append((tag, {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}))
+            return orig()
+        optim.step = stepper
+    stepped = {}
+
+    def snap(orig=oracle.backward_G_alone):      # the oracle's weights after G's and E's first update
+        stepped['G'] = {k: v.detach().clone() for k, v in oracle.netG.named_parameters()}
+        stepped['E'] = {k: v.detach().clone() for k, v in oracle.netE.named_parameters()}
+        return orig()
+    oracle.backward_G_alone = snap
+
+    def align(nets, orig, dtype):
+        def run():
+            with torch.no_grad():
+                for tag, net in nets:
+                    for k, p in net.named_parameters():
+                        p.data.copy_(stepped[tag][k].to(dtype))      # through .data: the retained graph must not notice (the semantics under test)
+            ops.invalidate_packed_weights()
+            return orig()
+        return run
+    model.backward_G_alone = align((('G', model.netG), ('E', model.netE)), model.backward_G_alone, torch.float32)
+    twin.backward_G_alone = align((('G', twin.netG), ('E', twin.netE)), twin.backward_G_alone, torch.float64)
+    for it in range(2):
+        prev = {t: {k: v.detach().clone() for k, v in n.named_parameters()} for t, n in (('G', oracle.netG), ('D', oracle.netD), ('E', oracle.netE))}
+        torch.manual_seed(1234 + it)
+        oracle_set_input(oracle, 'default', it)
+        oracle.optimize_parameters()
+        del grabbed[:]
+        with record_decisions({'G': model.netG, 'D': model.netD, 'E': model.netE, 'IP': model.netIP}) as rec:
+            model.set_input(step_batch('default', it))
+            model.optimize_parameters()
+        assert [t for t, _ in grabbed] == ['G', 'E', 'G', 'D']
+        with torch.no_grad():
+            for tag, tnet in (('G', twin.netG), ('D', twin.netD), ('E', twin.netE)):
+                for k, tp in tnet.named_parameters():
+                    tp.data.copy_(prev[tag][k].double())
+        queues = {k: iter(v) for k, v in rec.tapes.items()}
+        for name, tnet in (('G', twin.netG), ('D', twin.netD), ('E', twin.netE), ('IP', twin.netIP)):
+            N.DecisionTape.bind(tnet, queues[name])
+        try:
+            oracle_set_input(twin, 'default', it, torch.float64)
+            twin.optimize_parameters()
+            for name, q in queues.items():
+                assert next(q, None) is None, 'the twin consumed fewer %s decisions than the HIP step recorded' % name
+        finally:
+            for tnet in (twin.netG, twin.netD, twin.netE, twin.netIP):
+                N.DecisionTape.bind(tnet, None)
+        got, ol = model.get_current_losses(), oracle.losses()
+        for n, v in ol.items():
+            assert abs(got[n] - v) <= 1e-4 * max(1.0, abs(v)), 'lr_E it%d loss %s: hip %r vs oracle %r' % (it, n, got[n], v)
+        for k in ('fake_B', 'rec_A', 'embedding_A', 'embedding_B', 'y_A', 'y_B'):
+            assert_close(getattr(model, k), getattr(oracle, k), 2e-4, 'lr_E it%d %s vs oracle' % (it, k))
+        sets = (('G', grabbed[0][1], oracle.grads_G, twin.grads_G), ('E', grabbed[1][1], oracle.grads_E, twin.grads_E),
+                ('G_alone', grabbed[2][1], oracle.grads_G_alone, twin.grads_G_alone), ('D', grabbed[3][1], oracle.grads_D, twin.grads_D))
+        for tag, hgrads, ograds, tgrads in sets:
+            checked = 0
+            for k, og in ograds.items():
+                if og is None:
+                    continue
+                hg, g64 = hgrads[k], tgrads[k]
+                if tag.startswith('G') and ((k.endswith('.bias') and k != 'model.26.bias') or k == 'model.1.weight'):
+                    # in front of an affine-less InstanceNorm (bias; the constant rating plane's filter slice): true gradient 0, noise only
+                    wmax = float(ograds[k[:-4] + 'weight'].abs().max()) if k.endswith('.bias') else float(og.abs().max())
+                    noise = hg if k.endswith('.bias') else hg[:, -opt.embedding_nc:]
+                    assert float(noise.abs().max()) <= 1e-3 * wmax + 1e-6, 'lr_E grad %s %s should be ~0' % (tag, k)
+                    if k.endswith('.bias'):
+                        continue
+                    hg, og, g64 = hg[:, :-opt.embedding_nc], og[:, :-opt.embedding_nc], g64[:, :-opt.embedding_nc]
+                if float(g64.abs().max()) < 1e-9:
+                    continue
+                e_hip = _rel_l2(hg, g64)
+                assert e_hip <= 5e-4, 'lr_E it%d grad %s %s: SHARP rel-L2 vs the fp64 twin on the HIP decisions %.3e' % (it, tag, k, e_hip)
+                assert _rel_l2(hg, og) <= 2e-1, 'lr_E it%d grad %s %s: LOOSE vs the fp32 oracle' % (it, tag, k)
+                checked += 1
+            assert checked > 0, tag
+        for tag, hnet, onet in (('G', model.netG, oracle.netG), ('D', model.netD, oracle.netD), ('E', model.netE, oracle.netE)):
+            osd = onet.state_dict()
+            for k, v in hnet.state_dict().items():
+                if k.endswith('num_batches_tracked'):
+                    assert int(v) == int(osd[k]), k
+                elif 'running' in k:
+                    assert_close(v, osd[k], 1e-3, 'lr_E %s %s after step' % (tag, k), atol=1e-5)
+                elif v.dim() > 1:
+                    lr = opt.lr_E if tag == 'E' else opt.lr
+                    assert float((v.cpu() - osd[k]).abs().max()) <= 2.5 * lr * 2, 'lr_E %s %s after step' % (tag, k)
+        with torch.no_grad():      # re-align the parameters for the next iteration (see the test above)
+            for hnet, onet in ((model.netG, oracle.netG), (model.netD, oracle.netD), (model.netE, oracle.netE)):
+                op = dict(onet.named_parameters())
+                for k, hp in hnet.named_parameters():
+                    hp.copy_(op[k])

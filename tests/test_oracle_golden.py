@@ -84,10 +84,10 @@ def test_alexnet_feature_matches_reference():
     _check_net(ip, [W.seeded_tensor((2, 3, 64, 64), 103)], 303, gold, 'IP', False)
 
 
-def build_oracle_step(variant):
+def build_oracle_step(variant, extra_args=()):
     """The oracle-side twin of make_golden.golden_steps for one variant."""
     from oracle.make_golden import STEP_VARIANTS
-    extra = STEP_VARIANTS[variant]
+    extra = list(STEP_VARIANTS[variant]) + list(extra_args)
     kv = {}
     i = 0
     while i < len(extra):
@@ -113,7 +113,8 @@ def build_oracle_step(variant):
                 bayesian=bayes, noisy_var_type=kv.get('noisy_var_type', ''), bnn_T=int(kv.get('bnn_T', 10)),
                 lambda_L1=float(kv.get('lambda_L1', 0.0)), lambda_IP=float(kv.get('lambda_IP', 1.0)),
                 lambda_z=float(kv.get('lambda_z', 1.0)), lambda_A_GAN=float(kv.get('lambda_A_GAN', 0.0)),
-                use_real_A=bool(kv.get('use_real_A', False)), detach_fake_B=bool(kv.get('detach_fake_B', False)))
+                use_real_A=bool(kv.get('use_real_A', False)), detach_fake_B=bool(kv.get('detach_fake_B', False)),
+                lr_E=float(kv.get('lr_E', 0.0)))
     return S.WSGANEmbStepRef(G, D, E, IP, **opts)
 
 
@@ -172,6 +173,47 @@ def test_step_matches_reference(variant):
                 ref = gold['%s/after%s/%s' % (p, tag, k)]
                 a = v.double()
                 assert abs(float(a.abs().sum()) - ref[1]) <= 1e-4 * (ref[1] + 1e-3), 'after-step %s %s' % (tag, k)
+
+
+def test_lr_E_step_matches_the_reference_run_with_the_defined_optimizer():
+    """a1 / a4 / a6, `--lr_E > 0`: update_G_and_E, backward_GE, backward_G_alone.  The golden vectors are the reference's OWN code for
+    that branch, run on torch 2.10 with torch.optim.Adam replaced by oracle.step_ref.AdamThroughData while it built its optimizers
+    (make_golden.golden_step_lr_E): the optimizer's semantics are defined by the oracle, the branch's algorithm is pinned here."""
+    from oracle.make_golden import LR_E_ARGS
+    torch.set_num_threads(4)
+    gold = _load('step_lr_E.npz')
+    m = build_oracle_step('default', LR_E_ARGS)
+    assert isinstance(m.optimizer_E, S.AdamThroughData)
+    names = list(gold['loss_names'])
+    for it in range(2):
+        torch.manual_seed(1234 + it)
+        oracle_set_input(m, 'default', it)
+        m.optimize_parameters()
+        p = 'it%d' % it
+        got = m.losses()
+        for i, n in enumerate(names):
+            ref = gold[p + '/losses'][i]
+            assert abs(got[n] - ref) <= 2e-5 * max(1.0, abs(ref)), 'lr_E loss %s: %r vs %r' % (n, got[n], ref)
+        for k in ('fake_B', 'rec_A', 'embedding_A', 'embedding_B', 'y_A', 'y_B'):
+            assert_close(getattr(m, k), torch.from_numpy(gold['%s/%s' % (p, k)]), 2e-5, 'lr_E %s' % k)
+        for tag, grads in (('gradG', m.grads_G), ('gradE', m.grads_E), ('gradG_alone', m.grads_G_alone), ('gradD', m.grads_D)):
+            checked = 0
+            for k, g in grads.items():
+                if g is None:
+                    continue
+                st = gold['%s/%s/stat/%s' % (p, tag, k)]
+                l2 = float(g.double().pow(2).sum().sqrt())
+                assert abs(l2 - st[2]) <= 2e-3 * st[2] + 1e-6, 'lr_E %s %s l2 %g vs %g' % (tag, k, l2, st[2])
+                if tag == 'gradG_alone':
+                    full = torch.from_numpy(gold['%s/%s/full/%s' % (p, tag, k)])
+                    if full.abs().max() > 1e-5:
+                        assert_close(g, full, 2e-3, 'lr_E %s %s' % (tag, k))
+                checked += 1
+            assert checked > 0, tag
+        for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+            for k, v in net.state_dict().items():
+                ref = gold['%s/after%s/%s' % (p, tag, k)]
+                assert abs(float(v.double().abs().sum()) - ref[1]) <= 1e-4 * (ref[1] + 1e-3), 'lr_E after-step %s %s' % (tag, k)
 
 
 def test_get_current_visuals_matches_reference():
