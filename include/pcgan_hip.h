@@ -475,6 +475,9 @@ int pcgan_set_nonfinite_counter(unsigned int* dev_word);
  *   "wgrad_direct"  0  1: pcgan_conv2d_bwd_weight_hsplit hands the shapes pcgan_conv2d_wgrad_direct_supported takes to the
  *                      image-innermost form below (round-4 experiment: same results level, no step gain); the workspace query follows
  *   "wgd_look"      3  K steps the operand loads of that form's main kernel run ahead of its MFMAs (2, 3 or 4)
+ *   "hgemm_tile"    0  packed implicit GEMM, layers with > 32 output rows: 0 = the library's tile heuristic; BM * 1000 + BP with
+ *                      BM, BP in {64, 128} forces the workgroup tile (measurement: scripts/sweep_hgemm.py)
+ *   "hgemm_ks"      0  ... and the K split: 0 = heuristic, 1 .. 8 forced (every layer's workspace query then includes the partial sums)
  * Unknown keys / values return non-zero. */
 int pcgan_set_option(const char* key, int value);
 int pcgan_get_option(const char* key, int* value);

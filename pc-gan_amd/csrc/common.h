@@ -48,7 +48,7 @@ static inline int timer_kind_res(const pcgan_conv_desc* d, int kind) {
 // ---- routing options (include/pcgan_hip.h: pcgan_set_option) ------------------------------------------------------------------------
 // The library reads NO environment variables (round 4): the few A/B switches that live below the C-ABI are explicit options with
 // measured-best defaults, set by the host through pcgan_set_option(key, value) before the calls they affect.
-enum { OPT_BSPLIT_HALO = 0, OPT_WGRAD_GEN = 1, OPT_WGRAD_PADCOPY = 2, OPT_WGRAD_CW = 3, OPT_HGEMM_BF16 = 4, OPT_WGD_LOOK = 5, OPT_WGRAD_DIRECT = 6, OPT_COUNT = 7 };
+enum { OPT_BSPLIT_HALO = 0, OPT_WGRAD_GEN = 1, OPT_WGRAD_PADCOPY = 2, OPT_WGRAD_CW = 3, OPT_HGEMM_BF16 = 4, OPT_WGD_LOOK = 5, OPT_WGRAD_DIRECT = 6, OPT_HGEMM_TILE = 7, OPT_HGEMM_KS = 8, OPT_COUNT = 9 };
 int option(int id);
 
 // ---- non-finite sentinel of the fp16 route --------------------------------------------------------------------------------------------

@@ -2407,6 +2407,7 @@ static inline long tile_blocks(int M, int ptot_max, int nphase, int mm, int pp) 
 }
 static inline long split_below() { return 192; }     // tiles (BP = 128) below which a long-K layer is cut along K (profiles/r01_tile_sweep.txt)
 static inline bool may_split(int M, int ptot_max, int nphase) {
+    if (option(OPT_HGEMM_KS) > 1) return M > 4;      // forced K split (measurement): every layer gets the room
     const int m = M > 64 ? 128 : (M > 32 ? 64 : 32);
     return M > 4 && tile_blocks(M, ptot_max, nphase, m, 128) < split_below();
 }
@@ -2414,6 +2415,25 @@ static void choose_tile(int M, int ptot_max, int nphase, int nst, bool allow_spl
     int m = M > 64 ? 128 : (M > 32 ? 64 : 32);
     int p = 128;
     *ks = 1;
+    // options "hgemm_tile" / "hgemm_ks" (measurement, scripts/sweep_hgemm.py): a forced tile and K split for layers with > 32 rows
+    const int ft = option(OPT_HGEMM_TILE), fk = option(OPT_HGEMM_KS);
+    if ((ft || fk) && M > 32) {
+        if (ft) {
+            m = ft / 1000;
+            p = ft % 1000;
+        } else {      // the heuristic's tile for an unsplit launch
+            if (tile_blocks(M, ptot_max, nphase, m, p) < 384) p = 64;
+            if (m == 128 && tile_blocks(M, ptot_max, nphase, m, p) < 384) m = 64;
+        }
+        if (M <= 64 && m == 128) m = 64;
+        int k = fk > 0 ? fk : 1;
+        if (!allow_split) k = 1;
+        if (k > nst / 4) k = nst / 4 > 0 ? nst / 4 : 1;
+        *bm = m;
+        *bp = p;
+        *ks = k;
+        return;
+    }
     if (allow_split && may_split(M, ptot_max, nphase) && nst >= 32) {
         const long b = tile_blocks(M, ptot_max, nphase, m, 128);
         int k = (int)(512 / b);

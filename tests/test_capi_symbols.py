@@ -95,7 +95,8 @@ def test_library_reads_no_environment_and_options_are_explicit():
     for src in glob.glob(os.path.join(ROOT, 'pc-gan_amd', 'csrc', '*')):
         assert 'getenv' not in open(src).read(), src
     h = lib.load()
-    for key, default in (('bsplit_halo', 1), ('wgrad_gen', 1), ('wgrad_padcopy', 0), ('wgrad_cw', 0), ('hgemm_bf16', 1)):
+    for key, default in (('bsplit_halo', 1), ('wgrad_gen', 1), ('wgrad_padcopy', 0), ('wgrad_cw', 0), ('hgemm_bf16', 1), ('wgrad_direct', 0),
+                         ('hgemm_tile', 0), ('hgemm_ks', 0)):
         if not any(os.environ.get(e) for e, k, _ in lib._ENV_OPTIONS if k == key):
             assert lib.get_option(key) == default, key
     lib.set_option('wgrad_cw', 256)
@@ -103,3 +104,4 @@ def test_library_reads_no_environment_and_options_are_explicit():
     lib.set_option('wgrad_cw', 0)
     assert h.pcgan_set_option(b'no_such_option', 1) != 0 and b'unknown option' in h.pcgan_last_error()
     assert h.pcgan_set_option(b'wgrad_cw', 77) != 0
+    assert h.pcgan_set_option(b'hgemm_tile', 96096) != 0 and h.pcgan_set_option(b'hgemm_ks', 9) != 0
