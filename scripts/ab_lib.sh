@@ -15,5 +15,5 @@ PY
 done
 for V in "" "$OTHER"; do
   echo "== dashboard, ${V:-in-tree}"
-  env PCGAN_LIB=$V python scripts/bench_kernels.py 2>/dev/null | grep -E "layer|G.down|G.up|D.c[1-3]|E.l|IP.c[2-5]|sum of"
+  env PCGAN_LIB=$V python scripts/bench_kernels.py 2>/dev/null | grep -E "layer|G.res|G.down|G.up|D.c[1-3]|E.l|IP.c[2-5]|sum of"
 done
