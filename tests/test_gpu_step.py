@@ -435,3 +435,30 @@ def test_update_G_and_E_step_vs_oracle(tmp_path, dev):
                 op = dict(onet.named_parameters())
                 for k, hp in hnet.named_parameters():
                     hp.copy_(op[k])
+
+
+def test_update_logvar_E_trains_only_the_variance_head(tmp_path, dev):
+    """`--lr_E > 0 --update_logvar_E true --noisy true` (reference models/wsgan_emb_model.py:158-160): optimizer_E holds cnn_logvar's
+    parameters only -- after a step they have moved and every other encoder parameter is bit-unchanged; G and D train as usual."""
+    model, opt = build_hip_model('noisy_a', tmp_path, ['--lr_E', '0.0001', '--update_logvar_E', 'true'])
+    assert opt.update_logvar_E and opt.noisy
+    head = {id(p) for p in model.netE.cnn_logvar.parameters()}
+    assert {id(p) for g in model.optimizer_E.param_groups for p in g['params']} == head
+    before = {k: v.detach().clone() for k, v in model.netE.named_parameters()}
+    g_before = model.optimizer_G.flat.detach().clone()
+    torch.manual_seed(7)
+    for it in range(2):
+        model.set_input(step_batch('noisy_a', it))
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    losses = model.get_current_losses()
+    assert all(v == v and abs(v) < 1e4 for v in losses.values()), losses
+    moved = unchanged = 0
+    for k, p in model.netE.named_parameters():
+        if id(p) in head:
+            moved += int(not torch.equal(p, before[k]))
+        else:
+            assert torch.equal(p, before[k]), 'encoder parameter %s outside the variance head moved' % k
+            unchanged += 1
+    assert moved > 0 and unchanged > 0
+    assert not torch.equal(model.optimizer_G.flat, g_before)
