@@ -46,6 +46,12 @@ TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r04_residual_kernel_traffic.json'
 N_BATCHES = 4                    # distinct synthetic batches cycled through (pinned host memory; uploaded INSIDE the timed region)
 
 
+def lib_option(key):
+    """a routing option of the library as this run had it (pcgan_get_option)"""
+    from pcgan_amd.hip import lib as _lib
+    return _lib.get_option(key)
+
+
 def measured_traffic(route):
     """HBM bytes per launch of the three residual-convolution kernels from this round's separate rocprofv3 --pmc passes
     (FETCH_SIZE and WRITE_SIZE cannot share a pass), committed under profiles/: {'fwd' | 'dgrad' | 'wgrad': {...}}; None when
@@ -357,8 +363,11 @@ def main():
         names = {'res_fwd': 'bsplit_halo_kernel<BH_FWD,PK_F16X2,float,32> (two scaled fp16 pieces per operand, 3 x v_mfma_f32_32x32x16_f16 per '
                             'K=16 step, 256 x 128 tile, input window split once per 16-channel chunk)',
                  'res_dgrad': 'bsplit_halo_kernel<BH_DGRAD,PK_F16X2,float,32> (the same window kernel on dy with its sum rows / columns)',
-                 'res_wgrad': 'hsplit_wgrad_kernel<256,1,float,1> + bsplit_wgrad_reduce_kernel (x gathered with the reflection applied in '
-                              'the loads, 14 splits of the pixel reduction, fixed-order reduce into the gradient buffer)'}
+                 'res_wgrad': ('rowring_wgrad_kernel + wgd_reduce_kernel (column tile = 32 input channels x all nine taps walking down a 16-pixel strip: '
+                               'padded rows in a ring of four LDS slots, each element of x loaded and split once per strip; dy straight from memory; '
+                               '32 splits of the pixel reduction, fixed-order reduce into the gradient buffer)') if lib_option('wgrad_rowring') else
+                              ('hsplit_wgrad_kernel<256,1,float,1> + bsplit_wgrad_reduce_kernel (x gathered with the reflection applied in '
+                               'the loads, 14 splits of the pixel reduction, fixed-order reduce into the gradient buffer)')}
     elif split:
         route, peak = 'bf16x3', BF16_MFMA_PEAK_TFLOPS / BF16_SPLIT_PRODUCTS
         basis = 'dense bf16 MFMA %.0f TFLOP/s / %d piece products per fp32 product' % (BF16_MFMA_PEAK_TFLOPS, BF16_SPLIT_PRODUCTS)

@@ -1940,7 +1940,10 @@ extern "C" size_t pcgan_conv2d_hsplit_wgrad_workspace_bytes(const pcgan_conv_des
     const size_t own = xpad + (size_t)splits * d->K * d->C * d->R * d->S * 4;
     // (option "wgrad_direct": the residual-block shape is handed to the image-innermost form of wgrad_direct.hip, which needs more room)
     const size_t direct = pcgan::option(pcgan::OPT_WGRAD_DIRECT) ? pcgan_conv2d_wgrad_direct_workspace_bytes(d) : 0;
-    return own > direct ? own : direct;
+    // (option "wgrad_rowring": the same shapes' row-ring form, wgrad_rowring.hip)
+    const size_t ring = pcgan::option(pcgan::OPT_WGRAD_ROWRING) ? pcgan_conv2d_wgrad_rowring_workspace_bytes(d) : 0;
+    const size_t other = direct > ring ? direct : ring;
+    return own > other ? own : other;
 }
 
 extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_xamax, const void* dy,
@@ -1952,6 +1955,8 @@ extern "C" int pcgan_conv2d_bwd_weight_hsplit(const pcgan_conv_desc* d, const vo
     PCGAN_CHECK(half || (x_amax && dy_amax && n_xamax > 0 && n_dyamax > 0), "conv2d_bwd_weight_hsplit: fp32 tensors need their operand maxima");
     if (pcgan::option(pcgan::OPT_WGRAD_DIRECT) && pcgan_conv2d_wgrad_direct_supported(d))
         return pcgan_conv2d_bwd_weight_direct(d, x, x_amax, n_xamax, dy, dy_amax, n_dyamax, dw, accumulate, ws, ws_bytes, s);
+    if (pcgan::option(pcgan::OPT_WGRAD_ROWRING) && pcgan_conv2d_wgrad_rowring_supported(d))
+        return pcgan_conv2d_bwd_weight_rowring(d, x, x_amax, n_xamax, dy, dy_amax, n_dyamax, dw, accumulate, ws, ws_bytes, s);
     hipStream_t st = (hipStream_t)s;
     const bool res_like = pcgan::timer_kind_res(d, 0) == 0;
     pcgan::TimerScope timer(res_like ? pcgan::TIMER_RES_WGRAD : -1, st);       // padded copy + main kernel + reduce

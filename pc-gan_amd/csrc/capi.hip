@@ -97,8 +97,8 @@ extern "C" int pcgan_set_nonfinite_counter(unsigned int* dev_word) {
 }
 
 namespace pcgan {
-static const char* const g_opt_names[OPT_COUNT] = {"bsplit_halo", "wgrad_gen", "wgrad_padcopy", "wgrad_cw", "hgemm_bf16", "wgd_look", "wgrad_direct", "hgemm_tile", "hgemm_ks"};
-static std::atomic<int> g_opt[OPT_COUNT] = {{1}, {1}, {0}, {0}, {1}, {3}, {0}, {0}, {0}};
+static const char* const g_opt_names[OPT_COUNT] = {"bsplit_halo", "wgrad_gen", "wgrad_padcopy", "wgrad_cw", "hgemm_bf16", "wgd_look", "wgrad_direct", "hgemm_tile", "hgemm_ks", "wgrad_rowring"};
+static std::atomic<int> g_opt[OPT_COUNT] = {{1}, {1}, {0}, {0}, {1}, {3}, {0}, {0}, {0}, {1}};
 int option(int id) { return (id >= 0 && id < OPT_COUNT) ? g_opt[id].load(std::memory_order_relaxed) : 0; }
 static int option_index(const char* key) {
     for (int i = 0; key && i < OPT_COUNT; ++i)
@@ -109,7 +109,7 @@ static int option_index(const char* key) {
 extern "C" int pcgan_set_option(const char* key, int value) {
     using namespace pcgan;
     const int i = option_index(key);
-    PCGAN_CHECK(i >= 0, "set_option: unknown option '%s' (bsplit_halo, wgrad_gen, wgrad_padcopy, wgrad_cw, hgemm_bf16, wgd_look, wgrad_direct, hgemm_tile, hgemm_ks)", key ? key : "(null)");
+    PCGAN_CHECK(i >= 0, "set_option: unknown option '%s' (bsplit_halo, wgrad_gen, wgrad_padcopy, wgrad_cw, hgemm_bf16, wgd_look, wgrad_direct, hgemm_tile, hgemm_ks, wgrad_rowring)", key ? key : "(null)");
     PCGAN_CHECK(i != OPT_WGRAD_CW || value == 0 || value == 128 || value == 256, "set_option: wgrad_cw takes 0 (default), 128 or 256, got %d", value);
     PCGAN_CHECK(i != OPT_HGEMM_TILE || value == 0 || value == 128128 || value == 128064 || value == 64128 || value == 64064,
                 "set_option: hgemm_tile takes 0 (heuristic) or BM * 1000 + BP with BM, BP in {64, 128}, got %d", value);

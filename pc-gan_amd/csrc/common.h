@@ -48,7 +48,7 @@ static inline int timer_kind_res(const pcgan_conv_desc* d, int kind) {
 // ---- routing options (include/pcgan_hip.h: pcgan_set_option) ------------------------------------------------------------------------
 // The library reads NO environment variables (round 4): the few A/B switches that live below the C-ABI are explicit options with
 // measured-best defaults, set by the host through pcgan_set_option(key, value) before the calls they affect.
-enum { OPT_BSPLIT_HALO = 0, OPT_WGRAD_GEN = 1, OPT_WGRAD_PADCOPY = 2, OPT_WGRAD_CW = 3, OPT_HGEMM_BF16 = 4, OPT_WGD_LOOK = 5, OPT_WGRAD_DIRECT = 6, OPT_HGEMM_TILE = 7, OPT_HGEMM_KS = 8, OPT_COUNT = 9 };
+enum { OPT_BSPLIT_HALO = 0, OPT_WGRAD_GEN = 1, OPT_WGRAD_PADCOPY = 2, OPT_WGRAD_CW = 3, OPT_HGEMM_BF16 = 4, OPT_WGD_LOOK = 5, OPT_WGRAD_DIRECT = 6, OPT_HGEMM_TILE = 7, OPT_HGEMM_KS = 8, OPT_WGRAD_ROWRING = 9, OPT_COUNT = 10 };
 int option(int id);
 
 // ---- non-finite sentinel of the fp16 route --------------------------------------------------------------------------------------------
@@ -58,6 +58,8 @@ int option(int id);
 // null = off) and the host raises when it next looks (hip/ops.py: check_nonfinite) -- loud instead of silent.  One class test per
 // result and one ballot per wave: nothing in the K loop.
 unsigned* nonfinite_counter();
+// wgrad_direct.hip: fixed-order sum of [split][tap][k][c] partial sums, scaled back by 1 / (scales[0] * scales[1]), into dW[k][c][tap]
+int launch_wgd_reduce(const float* part, float* dw, const float* scales, int splits, int K, int C, int accumulate, hipStream_t st);
 __device__ __forceinline__ bool is_nonfinite(float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; }
 __device__ __forceinline__ void report_nonfinite(unsigned* counter, bool bad) {
     if (counter != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(counter, 1u);

@@ -272,6 +272,15 @@ __global__ void __launch_bounds__(256) wgd_reduce_kernel(const float* __restrict
     report_nonfinite(ovf, bad);
 }
 
+// the reduce alone, for the other producer of [split][tap][k][c] partial sums (wgrad_rowring.hip)
+int launch_wgd_reduce(const float* part, float* dw, const float* scales, int splits, int K, int C, int accumulate, hipStream_t st) {
+    const size_t quads = (size_t)9 * K * C / 4;
+    hipLaunchKernelGGL(wgd_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, part, dw, scales, splits, K, C, accumulate,
+                       nonfinite_counter());
+    PCGAN_LAUNCH_CHECK();
+    return 0;
+}
+
 static inline bool wgd_shape(const pcgan_conv_desc* d) {
     return d && d->dtype == PCGAN_F32 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == 1 && d->P == d->H && d->Q == d->W &&
            d->H >= 3 && d->W >= 3 && d->N >= 16 && d->N % 16 == 0 && d->K % 128 == 0 && d->C % 32 == 0;

@@ -135,6 +135,9 @@ SIGNATURES = {
     'pcgan_restrunk_fwd': (_i, [_rp, _i, _vp, _vp, _i] + [_vp] * 8 + [_vp] * 6 + [_vp]),
     'pcgan_restrunk_bwd': (_i, [_rp, _i, _vp, _vp, _vp, _i] + [_vp] * 6 + [_vp] * 6 + [_vp] * 6 + [_vp, _sz, _vp, _vp, _vp]),
     'pcgan_conv2d_wgrad_direct_supported': (_i, [_dp]),
+    'pcgan_conv2d_wgrad_rowring_supported': (_i, [_dp]),
+    'pcgan_conv2d_wgrad_rowring_workspace_bytes': (_sz, [_dp]),
+    'pcgan_conv2d_bwd_weight_rowring': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     'pcgan_conv2d_wgrad_direct_workspace_bytes': (_sz, [_dp]),
     'pcgan_conv2d_bwd_weight_direct': (_i, [_dp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     'pcgan_image_transform_band': (_i, [_ip, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
@@ -174,7 +177,7 @@ def load():
 # onto pcgan_set_option once, when the library is loaded.  (switch, option, value parser)
 _ENV_OPTIONS = (('PCGAN_BSPLIT_HALO', 'bsplit_halo', int), ('PCGAN_WGRAD_GEN', 'wgrad_gen', int), ('PCGAN_WGRAD_PADCOPY', 'wgrad_padcopy', int),
                 ('PCGAN_WGRAD_CW', 'wgrad_cw', int), ('PCGAN_HGEMM', 'hgemm_bf16', int), ('PCGAN_WGRAD_DIRECT', 'wgrad_direct', int),
-                ('PCGAN_WGD_LOOK', 'wgd_look', int))
+                ('PCGAN_WGD_LOOK', 'wgd_look', int), ('PCGAN_WGRAD_ROWRING', 'wgrad_rowring', int))
 
 
 def _options_from_environment(lib):

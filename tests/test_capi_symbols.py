@@ -96,7 +96,7 @@ def test_library_reads_no_environment_and_options_are_explicit():
         assert 'getenv' not in open(src).read(), src
     h = lib.load()
     for key, default in (('bsplit_halo', 1), ('wgrad_gen', 1), ('wgrad_padcopy', 0), ('wgrad_cw', 0), ('hgemm_bf16', 1), ('wgrad_direct', 0),
-                         ('hgemm_tile', 0), ('hgemm_ks', 0)):
+                         ('hgemm_tile', 0), ('hgemm_ks', 0), ('wgrad_rowring', 1)):
         if not any(os.environ.get(e) for e, k, _ in lib._ENV_OPTIONS if k == key):
             assert lib.get_option(key) == default, key
     lib.set_option('wgrad_cw', 256)

@@ -636,3 +636,55 @@ def test_weight_gradient_image_innermost_form(dev, N, C, H, W):
     for bad in (ops.make_desc(8, C, H, W, K, 3, 3, 1, 1, 1), ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 0), ops.make_desc(N, 48, H, W, K, 3, 3, 1, 1, 1),
                 ops.make_desc(N, C, H, W, K, 3, 3, 2, 1, 1)):
         assert not lib.pcgan_conv2d_wgrad_direct_supported(ctypes.byref(bad))
+
+
+@pytest.mark.parametrize('N,C,K,H,W', [(32, 256, 256, 32, 32), (3, 32, 128, 5, 16), (5, 64, 256, 7, 48), (8, 128, 128, 64, 64), (1, 32, 128, 3, 16)])
+def test_weight_gradient_row_ring_form(dev, N, C, K, H, W):
+    """csrc/wgrad_rowring.hip (round 4, library option "wgrad_rowring", default on): the residual convolution's weight gradient with a
+    column tile of 32 input channels x all nine taps walking down a 16-pixel strip -- padded rows in a ring of four LDS slots, three
+    element-shifted copies per row, dy straight from memory.  Against float64 on a slice of output channels (3e-6, the per-tap kernel's
+    bound), against the per-tap kernel on the whole tensor, accumulation into an existing gradient; odd heights (the unrolled stage pair's
+    tail), one image, three strips per row, a single strip (mirror columns on both sides of the same quad), the smallest height."""
+    import ctypes
+    from pcgan_amd.hip import ops, lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(N + C + K + H + W)
+    x = torch.randn(N, C, H, W, generator=g).relu_().to(dev)
+    dy = (torch.randn(N, K, H, W, generator=g) * 0.05).to(dev)
+    d = ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 1)
+    assert lib.pcgan_conv2d_wgrad_rowring_supported(ctypes.byref(d))
+    nb = int(lib.pcgan_conv2d_wgrad_rowring_workspace_bytes(ctypes.byref(d)))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    xmax, dmax = ops.amax_of(x), ops.amax_of(dy)
+    vp = ctypes.c_void_p
+    dw = torch.full((K, C, 3, 3), 0.5, device=dev)
+    for acc in (0, 1):
+        L.check(lib.pcgan_conv2d_bwd_weight_rowring(ctypes.byref(d), vp(x.data_ptr()), vp(xmax.data_ptr()), xmax.numel(), vp(dy.data_ptr()),
+                                                    vp(dmax.data_ptr()), dmax.numel(), vp(dw.data_ptr()), acc, vp(ws.data_ptr()), nb,
+                                                    vp(torch.cuda.current_stream().cuda_stream)), 'bwd_weight_rowring')
+    torch.cuda.synchronize()
+    once = dw / 2           # overwritten, then accumulated once more: exactly twice the gradient
+    ks = sorted({0, 1, K // 3, K - 1})
+    w = torch.zeros(len(ks), C, 3, 3, dtype=torch.float64, requires_grad=True)
+    xp = torch.nn.functional.pad(x.double().cpu(), (1, 1, 1, 1), mode='reflect')
+    for n0 in range(0, N, 8):
+        torch.nn.functional.conv2d(xp[n0:n0 + 8], w).backward(dy[n0:n0 + 8, ks].double().cpu())
+    err = float((once[ks].double().cpu() - w.grad).norm() / w.grad.norm())
+    assert err < 3e-6, err
+    # the per-tap kernel on the same inputs (option off), and the routed entry point with the option on = this form, bit for bit
+    assert L.get_option('wgrad_rowring') == 1
+    routed = ops.conv2d_bwd_weight(x, dy, (K, C, 3, 3), 1, 1, 1)
+    L.set_option('wgrad_rowring', 0)
+    ops.clear_plans()
+    try:
+        ref = ops.conv2d_bwd_weight(x, dy, (K, C, 3, 3), 1, 1, 1)
+    finally:
+        L.set_option('wgrad_rowring', 1)
+        ops.clear_plans()
+    assert float((once.double() - ref.double()).norm() / ref.double().norm()) < 3e-6
+    if N * H * W >= ops.BSPLIT_MIN_PIXELS:      # (smaller problems are routed to other kernels by the host)
+        assert torch.equal(routed, once)
+    # refusals: what the form does not take is said so, not computed wrongly
+    for bad in (ops.make_desc(N, C, H, 24, K, 3, 3, 1, 1, 1), ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 0), ops.make_desc(N, 48, H, W, K, 3, 3, 1, 1, 1),
+                ops.make_desc(N, C, H, W, 64, 3, 3, 1, 1, 1), ops.make_desc(N, C, H, W, K, 3, 3, 2, 1, 1), ops.make_desc(N, C, 2, W, K, 3, 3, 1, 1, 1)):
+        assert not lib.pcgan_conv2d_wgrad_rowring_supported(ctypes.byref(bad))
