@@ -354,7 +354,8 @@ def main():
         route, peak, basis = 'bf16', None, None
         names = {'res_fwd': 'bsplit_halo_kernel<BH_FWD,PK_BF16,bf16,32> (bf16 activations and weights, v_mfma_f32_32x32x16_bf16, fp32 accumulate)',
                  'res_dgrad': 'bsplit_halo_kernel<BH_DGRAD,PK_BF16,bf16,32>',
-                 'res_wgrad': 'bsplit_pad_wave_kernel + hsplit_wgrad_kernel<256,1,bf16,2> + bsplit_wgrad_reduce_kernel'}
+                 'res_wgrad': ('rowring_wgrad_bf16_kernel + wgd_reduce_kernel (row ring in LDS, one bf16 product per tap, loads four stages ahead)'
+                               if lib_option('wgrad_rowring') in (1, 2) else 'bsplit_pad_wave_kernel + hsplit_wgrad_kernel<256,1,bf16,2> + bsplit_wgrad_reduce_kernel')}
     elif hsplit:
         # the fp32 contraction runs as 3 fp16 piece products per term (two scaled fp16 pieces per operand) on the f16 matrix pipe:
         # the MFMA roofline in ALGORITHMIC (fp32) FLOP is the dense f16 peak / 3

@@ -452,8 +452,9 @@ int pcgan_conv2d_wgrad_direct_supported(const pcgan_conv_desc* d);
 /* ---- ... and in the "row ring" form (round 4; csrc/wgrad_rowring.hip): a workgroup's column tile is 32 input channels x all nine taps and it
  * walks down a 16-pixel-wide strip of one image, keeping the padded rows in a ring of four LDS slots -- every element of x is loaded and split
  * once per strip instead of once per tap.  Same arguments, workspace rule and results level as pcgan_conv2d_bwd_weight_hsplit, which hands the
- * shapes this form takes to it under option "wgrad_rowring": fp32 tensors, 3x3, stride 1, reflection padding 1, W % 16 == 0, K % 128 == 0,
- * C % 32 == 0, H >= 3.  Replaces autograd's weight gradient of nn.Conv2d in ResnetBlock (models/networks.py:616-652). */
+ * shapes this form takes to it under option "wgrad_rowring": fp32 or bf16 tensors, 3x3, stride 1, reflection padding 1, W % 16 == 0, K % 128 == 0,
+ * C % 32 == 0, H >= 3; bf16 tensors too (one bf16 product per tap, x_amax / dy_amax unused and may be NULL).  Replaces autograd's weight
+ * gradient of nn.Conv2d in ResnetBlock (models/networks.py:616-652). */
 int pcgan_conv2d_wgrad_rowring_supported(const pcgan_conv_desc* d);
 size_t pcgan_conv2d_wgrad_rowring_workspace_bytes(const pcgan_conv_desc* d);
 int pcgan_conv2d_bwd_weight_rowring(const pcgan_conv_desc* d, const void* x, const float* x_amax, int n_xamax, const void* dy, const float* dy_amax,
@@ -485,7 +486,8 @@ int pcgan_set_nonfinite_counter(unsigned int* dev_word);
  *                      image-innermost form below (round-4 experiment: same results level, no step gain); the workspace query follows
  *   "wgd_look"      3  K steps the operand loads of that form's main kernel run ahead of its MFMAs (2, 3 or 4)
  *   "wgrad_rowring" 1  pcgan_conv2d_bwd_weight_hsplit hands the shapes pcgan_conv2d_wgrad_rowring_supported takes to the row-ring form
- *                      (0.125-0.137 ms against 0.158-0.166 per residual-block call, step + 0.5 %); 0: the per-tap kernel for every shape
+ *                      (fp32 tensors: 0.125-0.137 ms against 0.158-0.166 per residual-block call, step + 0.5 %; bf16 tensors: 0.060
+ *                      against 0.119, step + 7 %); 0: the per-tap kernel for every shape; 3: the row-ring form for fp32 tensors only
  *   "hgemm_tile"    0  packed implicit GEMM, layers with > 32 output rows: 0 = the library's tile heuristic; BM * 1000 + BP with
  *                      BM, BP in {64, 128} forces the workgroup tile (measurement: scripts/sweep_hgemm.py)
  *   "hgemm_ks"      0  ... and the K split: 0 = heuristic, 1 .. 8 forced (every layer's workspace query then includes the partial sums)

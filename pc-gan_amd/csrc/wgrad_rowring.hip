@@ -261,15 +261,161 @@ __global__ void __launch_bounds__(256, 2) rowring_wgrad_kernel(RowRingArgs a) {
     }
 }
 
+// ---- bf16 tensors: the same walk with ONE product per tap -------------------------------------------------------------------------------
+// The stored bf16 patterns go to LDS and to the A fragment as they are (no scaling, no split, no vector arithmetic apart from the element
+// shifts of the row copies), 9 MFMAs and 9 LDS reads per wave and stage.  A stage is then only ~300 matrix cycles long, far shorter than a
+// trip to memory: dy fragments and x rows are loaded FOUR stages ahead into register rings (the stage loop is unrolled by four, ring slots
+// are compile-time; stages past the last row multiply zeros: their dy loads are killed by an out-of-range offset).
+typedef __bf16 rr_b8 __attribute__((ext_vector_type(8)));
+typedef unsigned int rr_w4 __attribute__((ext_vector_type(4)));
+typedef unsigned int rr_w2 __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(256, 2) rowring_wgrad_bf16_kernel(RowRingArgs a) {
+    __shared__ __attribute__((aligned(16))) rr_h8 Xs[4 * 3 * 2 * 32 + 128];      // [row slot][shift s][k half][channel] records of 8 pixels + dump bytes
+    const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if (wg >= a.nwg) return;
+    const int tiles = a.nmt * a.ncb;
+    const int split = wg / tiles, tile = wg - split * tiles;
+    const int mt = tile % a.nmt, cb = tile / a.nmt;
+    const int H = a.H, W = a.W, HW = H * W;
+    if (wg == 0 && tid == 0) {
+        a.scales[0] = 1.f;
+        a.scales[1] = 1.f;
+    }
+    const int ch = tid >> 3, q = tid & 7;
+    char* const xs_bytes = reinterpret_cast<char*>(&Xs[0]);
+    auto rec_off = [&](int slot, int s, int khalf, int c) -> unsigned { return (unsigned)(((((slot * 3 + s) * 2 + khalf) * 32) + c) * 16); };
+    rr_f16v acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int wq = W >> 4;
+    const int s_begin = split * a.strips_per_split;
+    const int s_end = s_begin + a.strips_per_split < a.strips ? s_begin + a.strips_per_split : a.strips;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((size_t)a.N * a.C * HW * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.DY), 0, (int)((size_t)a.N * a.K * HW * 2), 0x00020000);
+    const unsigned vod = (unsigned)(((mt * 128 + wave * 32 + lo) * HW + 8 * hi) * 2);
+    const bool owns = q >= 1 && q <= 4;
+    const int jq = q - 1;
+    const unsigned wbase = owns ? (unsigned)(((jq >> 1) * 32 + ch) * 16 + (jq & 1) * 8) : (unsigned)(4 * 3 * 2 * 32 * 16 + tid * 8);
+    const unsigned wmul = owns ? 1u : 0u;
+    for (int strip = s_begin; strip < s_end; ++strip) {
+        const int n = strip / wq, x0 = (strip - n * wq) << 4;
+        const int colq = q == 0 ? (x0 == 0 ? 1 : x0 - 1) : (q >= 5 ? (x0 + 16 >= W ? W - 2 : x0 + 16) : x0 + 4 * (q - 1));
+        const int esel = colq & 3;
+        const unsigned vox = (unsigned)((ch * HW + (colq & ~3)) * 2);
+        const unsigned sox = (unsigned)((n * a.C + cb * 32) * HW * 2);
+        const unsigned sod = (unsigned)((n * a.K * HW + x0) * 2);
+        auto ldrow = [&](int py) -> rr_w2 {      // padded row py (clamped to H + 1), mirrored at the image edge
+            int sy = (py > H + 1 ? H + 1 : py) - 1;
+            sy = sy < 0 ? -sy : sy;
+            sy = sy >= H ? 2 * (H - 1) - sy : sy;
+            return __builtin_amdgcn_raw_buffer_load_b64(rX, vox, sox + (unsigned)(sy * W * 2), 0);
+        };
+        auto lddy = [&](int y) -> rr_w4 {        // dy of stage y; a stage past the last row loads zeros
+            return __builtin_amdgcn_raw_buffer_load_b128(rD, y < H ? vod : 0x80000000u, y < H ? sod + (unsigned)(y * W * 2) : 0u, 0);
+        };
+        struct RowRegs {
+            unsigned E01, E23, left, right;
+        };
+        auto take_row = [&](const rr_w2& raw, RowRegs& g) {
+            const unsigned w = (esel & 2) ? raw[1] : raw[0];
+            const unsigned pick = (esel & 1) ? (w >> 16) : (w & 0xffffu);
+            g.E01 = q >= 5 ? ((raw[0] & 0xffff0000u) | pick) : raw[0];
+            g.E23 = q == 0 ? ((raw[1] & 0xffffu) | (pick << 16)) : raw[1];
+        };
+        auto edges = [&](RowRegs& g) {
+            g.left = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(g.E23 >> 16), 0x111, 0xf, 0xf, false);        // element 3 of lane - 1
+            g.right = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(g.E01 & 0xffffu), 0x101, 0xf, 0xf, false);   // element 0 of lane + 1
+        };
+        auto write_copy = [&](int slot, int sc, const RowRegs& g) {
+            const unsigned mid = __builtin_amdgcn_alignbyte(g.E23, g.E01, 2);
+            rr_w2 v;
+            if (sc == 0) v = rr_w2{g.left | (g.E01 << 16), mid};
+            else if (sc == 1) v = rr_w2{g.E01, g.E23};
+            else v = rr_w2{mid, (g.E23 >> 16) | (g.right << 16)};
+            *reinterpret_cast<rr_w2*>(xs_bytes + wbase + wmul * rec_off(slot, sc, 0, 0)) = v;
+        };
+        auto build = [&](int slot, const rr_w2& raw) {
+            RowRegs g;
+            take_row(raw, g);
+            edges(g);
+            write_copy(slot, 0, g);
+            write_copy(slot, 1, g);
+            write_copy(slot, 2, g);
+        };
+        rr_h8 Bq[3];
+        auto rdB = [&](int buf, int ybase, int tap) {
+            const int r = tap / 3, sc = tap % 3;
+            Bq[buf] = *reinterpret_cast<const rr_h8*>(xs_bytes + rec_off((ybase + r) & 3, sc, hi, lo));
+        };
+        // rings: dring[k] holds dy of the next stage with y % 4 == k, xring[k] the padded row that stage builds (row y + 3)
+        rr_w4 dring[4];
+        rr_w2 xring[4];
+        const rr_w2 r0 = ldrow(0), r1 = ldrow(1), r2 = ldrow(2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dring[k] = lddy(k);
+            xring[k] = ldrow(k + 3);
+        }
+        __syncthreads();        // the previous strip's last stage has read its rows
+        build(0, r0);
+        build(1, r1);
+        build(2, r2);
+        __syncthreads();
+        rdB(0, 0, 0);
+        rdB(1, 0, 1);
+#pragma unroll 1
+        for (int y0 = 0; y0 < H; y0 += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = y0 + k;
+                const rr_b8 A = __builtin_bit_cast(rr_b8, dring[k]);
+                RowRegs g;
+                const int wslot = (y + 3) & 3;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 2 < 9) rdB((t + 2) % 3, y, t + 2);
+                    else rdB((t + 2) % 3, y + 1, t + 2 - 9);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(rr_b8, Bq[t % 3]), acc[t], 0, 0, 0);
+                    if (t == 0) take_row(xring[k], g);
+                    if (t == 1) edges(g);
+                    if (t == 2) write_copy(wslot, 0, g);
+                    if (t == 3) write_copy(wslot, 1, g);
+                    if (t == 4) write_copy(wslot, 2, g);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                dring[k] = lddy(y + 4);           // four stages ahead, into the ring slot this stage has just finished with
+                xring[k] = ldrow(y + 7);
+                // (as in the fp32 kernel: the row's writes are followed by at least the four reads of groups 5 .. 8)
+                __builtin_amdgcn_s_waitcnt(0xC47F);      // lgkmcnt(4)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* out = a.part + (((size_t)split * 9 + t) * a.K + mt * 128 + wave * 32) * a.C + cb * 32 + lo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(size_t)((r >> 2) * 8 + hi * 4 + (r & 3)) * a.C] = acc[t][r];
+    }
+}
+
 struct RowRingPlan {
     int nmt, ncb, strips, per, splits;
     size_t part_bytes, total;
 };
 static bool rowring_plan(const pcgan_conv_desc* d, RowRingPlan* p) {
-    if (!d || d->dtype != PCGAN_F32 || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 1 || d->P != d->H || d->Q != d->W)
+    if (!d || (d->dtype != PCGAN_F32 && d->dtype != PCGAN_BF16) || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 1 || d->P != d->H || d->Q != d->W)
         return false;
     if (d->H < 3 || d->W < 16 || d->W % 16 != 0 || d->K % 128 != 0 || d->C % 32 != 0 || d->N < 1) return false;
     if ((size_t)d->N * d->C * d->H * d->W * 4 >= 0x80000000ull || (size_t)d->N * d->K * d->H * d->W * 4 >= 0x80000000ull) return false;
+    if (d->dtype == PCGAN_BF16 && option(OPT_WGRAD_ROWRING) == 3) return false;      // option value 3: fp32 tensors only (A/B measurement of the bf16 form)
     p->nmt = d->K / 128;
     p->ncb = d->C / 32;
     p->strips = d->N * (d->W / 16);
@@ -304,7 +450,8 @@ extern "C" int pcgan_conv2d_bwd_weight_rowring(const pcgan_conv_desc* d, const v
     using namespace pcgan;
     RowRingPlan p;
     PCGAN_CHECK(rowring_plan(d, &p), "conv2d_bwd_weight_rowring: unsupported shape (3x3 stride 1 reflection padding 1, fp32, W %% 16 == 0, K %% 128 == 0, C %% 32 == 0)");
-    PCGAN_CHECK(x && dy && dw && ws && x_amax && dy_amax && n_xamax > 0 && n_dyamax > 0, "conv2d_bwd_weight_rowring: null pointer");
+    const bool half = d->dtype == PCGAN_BF16;
+    PCGAN_CHECK(x && dy && dw && ws && (half || (x_amax && dy_amax && n_xamax > 0 && n_dyamax > 0)), "conv2d_bwd_weight_rowring: null pointer");
     PCGAN_CHECK(ws_bytes >= p.total, "conv2d_bwd_weight_rowring: workspace too small (%zu < %zu)", ws_bytes, p.total);
     hipStream_t st = (hipStream_t)s;
     RowRingArgs a;
@@ -320,7 +467,8 @@ extern "C" int pcgan_conv2d_bwd_weight_rowring(const pcgan_conv_desc* d, const v
         TimerScope whole(timer_kind_res(d, TIMER_RES_WGRAD), st);
         {
             TimerScope main_only(timer_kind_res(d, TIMER_RES_WGRAD_MAIN), st);
-            hipLaunchKernelGGL(rowring_wgrad_kernel, dim3((unsigned)((a.nwg + 7) / 8 * 8)), dim3(256), 0, st, a);
+            if (half) hipLaunchKernelGGL(rowring_wgrad_bf16_kernel, dim3((unsigned)((a.nwg + 7) / 8 * 8)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(rowring_wgrad_kernel, dim3((unsigned)((a.nwg + 7) / 8 * 8)), dim3(256), 0, st, a);
         }
         if (launch_wgd_reduce(a.part, dw, a.scales, p.splits, d->K, d->C, accumulate, st)) return 2;
     }

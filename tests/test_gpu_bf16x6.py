@@ -688,3 +688,43 @@ def test_weight_gradient_row_ring_form(dev, N, C, K, H, W):
     for bad in (ops.make_desc(N, C, H, 24, K, 3, 3, 1, 1, 1), ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 0), ops.make_desc(N, 48, H, W, K, 3, 3, 1, 1, 1),
                 ops.make_desc(N, C, H, W, 64, 3, 3, 1, 1, 1), ops.make_desc(N, C, H, W, K, 3, 3, 2, 1, 1), ops.make_desc(N, C, 2, W, K, 3, 3, 1, 1, 1)):
         assert not lib.pcgan_conv2d_wgrad_rowring_supported(ctypes.byref(bad))
+
+
+@pytest.mark.parametrize('N,C,K,H,W', [(32, 256, 256, 32, 32), (3, 32, 128, 5, 16), (5, 64, 256, 7, 48), (1, 32, 128, 3, 16), (2, 128, 128, 9, 32)])
+def test_weight_gradient_row_ring_form_bf16(dev, N, C, K, H, W):
+    """bf16 tensors through rowring_wgrad_bf16_kernel (one bf16 product per tap, stored patterns straight to LDS / the A fragment, dy and x
+    rows loaded four stages ahead, stage loop unrolled by four: heights that are not multiples of four run zero stages at the end): against
+    float64 of the SAME bf16 inputs on a slice of output channels (bf16 x bf16 products are exact in fp32: only the accumulation order
+    differs, 1e-6), against the per-tap kernel, and accumulation."""
+    import ctypes
+    from pcgan_amd.hip import ops, lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(N + C + K + H + W)
+    x = torch.randn(N, C, H, W, generator=g).relu_().to(dev).to(torch.bfloat16)
+    dy = (torch.randn(N, K, H, W, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    d = ops.make_desc(N, C, H, W, K, 3, 3, 1, 1, 1, ops.BF16)
+    assert lib.pcgan_conv2d_wgrad_rowring_supported(ctypes.byref(d))
+    nb = int(lib.pcgan_conv2d_wgrad_rowring_workspace_bytes(ctypes.byref(d)))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    vp = ctypes.c_void_p
+    dw = torch.full((K, C, 3, 3), 0.5, device=dev)
+    for acc in (0, 1):
+        L.check(lib.pcgan_conv2d_bwd_weight_rowring(ctypes.byref(d), vp(x.data_ptr()), None, 0, vp(dy.data_ptr()), None, 0, vp(dw.data_ptr()), acc,
+                                                    vp(ws.data_ptr()), nb, vp(torch.cuda.current_stream().cuda_stream)), 'bwd_weight_rowring')
+    torch.cuda.synchronize()
+    once = dw / 2
+    ks = sorted({0, 1, K // 3, K - 1})
+    w = torch.zeros(len(ks), C, 3, 3, dtype=torch.float64, requires_grad=True)
+    xp = torch.nn.functional.pad(x.double().cpu(), (1, 1, 1, 1), mode='reflect')
+    for n0 in range(0, N, 8):
+        torch.nn.functional.conv2d(xp[n0:n0 + 8], w).backward(dy[n0:n0 + 8, ks].double().cpu())
+    err = float((once[ks].double().cpu() - w.grad).norm() / w.grad.norm())
+    assert err < 1e-6, err
+    L.set_option('wgrad_rowring', 0)
+    ops.clear_plans()
+    try:
+        ref = ops.conv2d_bwd_weight(x, dy, (K, C, 3, 3), 1, 1, 1)
+    finally:
+        L.set_option('wgrad_rowring', 1)
+        ops.clear_plans()
+    assert float((once.double() - ref.double()).norm() / ref.double().norm()) < 1e-6
