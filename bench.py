@@ -423,6 +423,8 @@ def main():
                 'frac_alone': dom.get('frac_alone'), 'ms_per_launch_alone': dom.get('ms_per_launch_alone'),
                 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                 'ms_per_launch': round(conv_ms, 4), 'launches_timed': conv_launches, 'flop_per_launch': conv_flop, 'peak_basis': basis,
+                'clock_note': 'peak quoted at the 2.4 GHz boost clock; in steady state the fp32 step is held at ~2.0 GHz / ~1255 W by the '
+                              'chip\'s power management (profiles/r04_power.txt, scripts/power_sample.sh): the same bound at that clock is 17 % lower',
                 # memory-side bytes per launch from this round's separate rocprofv3 --pmc passes (profiles/README.md); null when no
                 # counter file of this round is committed
                 'traffic': dom['traffic'], 'traffic_detail': dom.get('traffic_detail'), 'mfma_busy': dom.get('mfma_busy'),
