@@ -49,3 +49,46 @@ def test_no_packed_fp32_high_broadcast_form_in_the_library():
         assert not bad, 'packed fp32 op_sel:[0,1,0] form (scripts/micro/head_wgrad_isa.md) in: %s' % sorted({b[0] for b in bad})[:5]
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+@pytest.mark.timeout(600)
+def test_row_ring_kernels_keep_scalar_loads_out_of_their_stage_loops():
+    """csrc/wgrad_rowring.hip ends a stage with `s_waitcnt lgkmcnt(N)` + a raw `s_barrier`: "the row's LDS writes are older than the N
+    newest LDS operations, so they have completed".  That holds because a wave's LDS operations return in order -- scalar memory loads count
+    on the same counter and return OUT of order, so none may be in flight there.  Guard: in both kernels every s_load / s_buffer_load sits in
+    front of the first matrix instruction (kernel arguments, read once), and the counted waits are the ones the source asks for."""
+    if not (os.path.exists(LIB) and os.path.exists(OBJDUMP)):
+        pytest.skip('library or llvm-objdump not present (build() first)')
+    tmp = tempfile.mkdtemp(prefix='pcgan_isa_')
+    try:
+        work = os.path.join(tmp, 'lib.so')
+        shutil.copy(LIB, work)
+        subprocess.run([OBJDUMP, '--offloading', work], cwd=tmp, check=True, capture_output=True)
+        seen = {}
+        for o in glob.glob(work + '.*gfx950*'):
+            cur = None
+            p = subprocess.Popen([OBJDUMP, '-d', o], stdout=subprocess.PIPE, text=True)
+            for line in p.stdout:
+                m = re.match(r'^[0-9a-f]+ <(.+)>:', line)
+                if m:
+                    cur = m.group(1) if 'rowring_wgrad' in m.group(1) else None
+                    if cur:
+                        seen[cur] = {'mfma': False, 'late_sload': [], 'waits': set()}
+                    continue
+                if cur is None:
+                    continue
+                code = line.split('//')[0]
+                if 'v_mfma' in code:
+                    seen[cur]['mfma'] = True
+                elif re.search(r'\bs_(buffer_)?load_', code) and seen[cur]['mfma']:
+                    seen[cur]['late_sload'].append(code.strip())
+                w = re.search(r's_waitcnt lgkmcnt\((\d+)\)\s*$', code.strip())
+                if w:
+                    seen[cur]['waits'].add(int(w.group(1)))
+            p.wait()
+        assert len(seen) == 2, 'expected the fp32 and the bf16 row-ring kernel, found %r' % sorted(seen)
+        for k, v in seen.items():
+            assert v['mfma'] and not v['late_sload'], '%s: scalar loads behind the first MFMA: %r' % (k, v['late_sload'][:3])
+            assert (4 if 'bf16' in k else 8) in v['waits'], '%s: the counted end-of-stage wait is gone (%r)' % (k, sorted(v['waits']))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
