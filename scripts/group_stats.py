@@ -4,7 +4,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 groups = collections.OrderedDict([
-    ('residual convs (bsplit main)', r'bsplit_conv_fwd_kernel|bsplit_halo_kernel|hsplit_wgrad_kernel|rowring_wgrad_kernel'), ('residual wgrad aux (pad / pack / reduce)', r'bsplit_(pad|pack_dy|wgrad_reduce)|wgd_reduce_kernel'),
+    ('residual convs (bsplit main)', r'bsplit_conv_fwd_kernel|bsplit_halo_kernel|hsplit_wgrad_kernel|rowring_wgrad'), ('residual wgrad aux (pad / pack / reduce)', r'bsplit_(pad|pack_dy|wgrad_reduce)|wgd_reduce_kernel'),
     ('bsplit weight packs, absmax', r'bsplit_pack|absmax'), ('other MFMA convs fwd+dgrad (igemm2 / igemm)', r'igemm2?_kernel|hgemm_kernel'),
     ('other MFMA wgrad (wgrad2 / wgrad + reduce)', r'::wgrad2?_kernel|::wgrad_reduce|\d\dwgrad2?_kernelI'), ('<=4-channel convs (smallm, thin_conv)', r'smallm|thin_conv|thin_pack'),
     ('split-K reduce / repack / fold', r'splitk|repack|reflect_fold|transpose4|pack_strip'), ('instance norm', r'instnorm|in_running'),
